@@ -1,0 +1,1164 @@
+/* mw_oracle.c - CPU restatement of the gym-miniworld hot path (see mw_oracle.h for status).
+ *
+ * TEST INFRASTRUCTURE ONLY - never linked into or called by the product.
+ *
+ * State half: float64, one env at a time, written to follow the reference's operation
+ * order so results are bit-identical to the reference run in this container
+ * (tests/golden/state_*.npz).  Citations are file:line under /root/reference/.
+ * Render half: float32 restatement of the fixed-function GL pipeline as configured by
+ * miniworld.py:1014-1085,1160-1220 and opengl.py:85-103,283-371 - the frozen choices are
+ * listed in DESIGN.md ("render spec") and in the comments below.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -shared -fPIC (see oracle/Makefile).
+ * -ffp-contract=off matters: a fused multiply-add would change last bits.
+ */
+#include "mw_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ===================================================================== MT19937 / numpy */
+/* numpy.random.RandomState (legacy) draw recipes; reference random.py:4-65 calls
+ * randint / uniform / choice on gym's RandomState. */
+typedef struct {
+    uint32_t key[624];
+    int pos;
+} MT;
+
+static void mt_init_genrand(MT *m, uint32_t s) {
+    m->key[0] = s;
+    for (int i = 1; i < 624; i++) m->key[i] = 1812433253u * (m->key[i - 1] ^ (m->key[i - 1] >> 30)) + (uint32_t)i;
+    m->pos = 624;
+}
+
+static void mt_init_by_array(MT *m, const uint32_t *init_key, int key_length) {
+    int i = 1, j = 0, k;
+    mt_init_genrand(m, 19650218u);
+    k = (624 > key_length ? 624 : key_length);
+    for (; k; k--) {
+        m->key[i] = (m->key[i] ^ ((m->key[i - 1] ^ (m->key[i - 1] >> 30)) * 1664525u)) + init_key[j] + (uint32_t)j;
+        i++; j++;
+        if (i >= 624) { m->key[0] = m->key[623]; i = 1; }
+        if (j >= key_length) j = 0;
+    }
+    for (k = 623; k; k--) {
+        m->key[i] = (m->key[i] ^ ((m->key[i - 1] ^ (m->key[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        i++;
+        if (i >= 624) { m->key[0] = m->key[623]; i = 1; }
+    }
+    m->key[0] = 0x80000000u;
+    m->pos = 624;
+}
+
+static void mt_twist(MT *m) {
+    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
+    uint32_t y;
+    int i;
+    for (i = 0; i < 624 - 397; i++) {
+        y = (m->key[i] & UPPER) | (m->key[i + 1] & LOWER);
+        m->key[i] = m->key[i + 397] ^ (y >> 1) ^ ((y & 1) ? MATRIX_A : 0);
+    }
+    for (; i < 623; i++) {
+        y = (m->key[i] & UPPER) | (m->key[i + 1] & LOWER);
+        m->key[i] = m->key[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1) ? MATRIX_A : 0);
+    }
+    y = (m->key[623] & UPPER) | (m->key[0] & LOWER);
+    m->key[623] = m->key[396] ^ (y >> 1) ^ ((y & 1) ? MATRIX_A : 0);
+    m->pos = 0;
+}
+
+static uint32_t mt_next32(MT *m) {
+    if (m->pos == 624) mt_twist(m);
+    uint32_t y = m->key[m->pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+static double mt_double(MT *m) {
+    uint32_t a = mt_next32(m) >> 5, b = mt_next32(m) >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+/* RandomState.uniform scalar/array element: loc + scale*u with scale = high - low */
+static double rs_uniform(MT *m, double lo, double hi) {
+    double scale = hi - lo;
+    return lo + scale * mt_double(m);
+}
+
+/* RandomState.randint(low, high) int64 default, masked rejection on 32-bit words */
+static long rs_randint(MT *m, long lo, long hi) {
+    uint64_t rng = (uint64_t)(hi - 1 - lo);
+    if (rng == 0) return lo;
+    uint64_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+    uint32_t v;
+    do { v = mt_next32(m) & (uint32_t)mask; } while (v > rng);
+    return lo + (long)v;
+}
+
+/* RandomState.choice(n, p): one double, cdf.searchsorted(u, side='right') */
+static int rs_choice_cdf(MT *m, const double *cdf, int n) {
+    double u = mt_double(m);
+    int lo = 0, hi = n;
+    while (lo < hi) { /* first index with cdf[idx] > u */
+        int mid = (lo + hi) / 2;
+        if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+/* numpy add.reduce over a contiguous double vector (pairwise summation, numpy
+ * core/src/umath/loops_utils.h.src pairwise_sum): used by np.sum in miniworld.py:998 */
+static double np_pairwise_sum(const double *a, int n) {
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        int i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; k++) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+    }
+}
+
+/* ============================================================================ world */
+typedef struct { double start, end, min_y, max_y; } Portal;
+
+typedef struct {
+    double verts[4][3];
+    double norm[3];
+    float texcs[4][2];
+} Quad;
+
+typedef struct {
+    double outline[4][3];      /* miniworld.py:90-97, y = 0 */
+    double min_x, max_x, min_z, max_z, mid_x, mid_z, area;
+    double edge_dirs[4][3], edge_norms[4][3];
+    double wall_height;
+    int no_ceiling;
+    int wall_tex_name, floor_tex_name, ceil_tex_name; /* texture family ids */
+    int n_portals[4];
+    Portal portals[4][MWO_MAX_PORTALS];
+    /* static data (miniworld.py:234-388) */
+    int wall_tex, floor_tex, ceil_tex; /* concrete texture ids */
+    int n_quads, n_segs;
+    Quad *quads;
+    double (*segs)[2][3];
+    double floor_texcs[4][2], ceil_texcs[4][2];
+} Room;
+
+typedef struct { double pos[3], dir, radius, height; } Ent;
+
+/* texture families (name -> list of <name>_<i>.png, opengl.py:40-69) */
+enum { TEXF_FLOOR_TILES_BW = 0, TEXF_CONCRETE, TEXF_CONCRETE_TILES, TEXF_BRICK_WALL, N_TEXF };
+static const int TEXF_FIRST[N_TEXF] = {0, 1, 5, 6};
+static const int TEXF_COUNT[N_TEXF] = {1, 4, 1, 1};
+
+typedef struct {
+    int w, h, n_levels;
+    uint8_t *data;
+    size_t level_off[MWO_MAX_LEVELS];
+    int lw[MWO_MAX_LEVELS], lh[MWO_MAX_LEVELS];
+} Tex;
+static Tex g_tex[MWO_MAX_TEX];
+
+typedef struct { double def[3], lo[3], hi[3]; int n, is_int; } Param;
+
+struct MwoEnv {
+    int task;
+    double task_args[4];
+    int max_episode_steps, domain_rand;
+    Param params[MWO_NPARAM];
+    MT rng;
+    int step_count;
+    int n_rooms;
+    Room rooms[MWO_MAX_ROOMS];
+    int static_done;
+    int n_segs;
+    double (*wall_segs)[2][3];
+    double room_probs[MWO_MAX_ROOMS], room_cdf[MWO_MAX_ROOMS];
+    Ent box, agent;
+    int n_ents; /* placement order: box(0), agent(1) */
+    double box_size[3], box_color[3];
+    double cam_height, cam_fwd_disp, cam_pitch, cam_fov_y;
+    double sky_color[3], light_pos[3], light_color[3], light_ambient[3];
+    double max_forward_step;
+};
+
+static void fail(const char *msg) {
+    fprintf(stderr, "mw_oracle: %s\n", msg);
+    abort();
+}
+
+int mwo_set_texture(int id, int w, int h, int n_levels, const uint8_t *rgba) {
+    if (id < 0 || id >= MWO_MAX_TEX || n_levels > MWO_MAX_LEVELS) return -1;
+    Tex *t = &g_tex[id];
+    free(t->data);
+    t->w = w; t->h = h; t->n_levels = n_levels;
+    size_t off = 0;
+    int lw = w, lh = h;
+    for (int l = 0; l < n_levels; l++) {
+        t->level_off[l] = off; t->lw[l] = lw; t->lh[l] = lh;
+        off += (size_t)lw * lh * 4;
+        lw = lw > 1 ? lw / 2 : 1; lh = lh > 1 ? lh / 2 : 1;
+    }
+    t->data = (uint8_t *)malloc(off);
+    memcpy(t->data, rgba, off);
+    return 0;
+}
+
+static void default_params(Param *p) {
+    /* params.py:110-123 */
+    static const double T[MWO_NPARAM][10] = {
+        /* n, def[3], lo[3], hi[3] */
+        {3, 0.25, 0.82, 1, 0.1, 0.1, 0.1, 1.0, 1.0, 1.0},
+        {3, 0, 2.5, 0, -40, 2.5, -40, 40, 5, 40},
+        {3, 0.7, 0.7, 0.7, 0.45, 0.45, 0.45, 0.8, 0.8, 0.8},
+        {3, 0.45, 0.45, 0.45, 0.35, 0.35, 0.35, 0.55, 0.55, 0.55},
+        {3, 0, 0, 0, -0.2, -0.2, -0.2, 0.2, 0.2, 0.2},
+        {1, 0.15, 0, 0, 0.12, 0, 0, 0.17, 0, 0},
+        {1, 0, 0, 0, -0.05, 0, 0, 0.05, 0, 0},
+        {1, 15, 0, 0, 10, 0, 0, 20, 0, 0},
+        {1, 0.4, 0, 0, 0.38, 0, 0, 0.42, 0, 0},
+        {1, 0, 0, 0, -5, 0, 0, 5, 0, 0},
+        {1, 60, 0, 0, 55, 0, 0, 65, 0, 0},
+        {1, 1.5, 0, 0, 1.45, 0, 0, 1.55, 0, 0},
+        {1, 0, 0, 0, -0.05, 0, 0, 0.10, 0, 0},
+    };
+    for (int i = 0; i < MWO_NPARAM; i++) {
+        p[i].n = (int)T[i][0]; p[i].is_int = 0;
+        for (int k = 0; k < 3; k++) { p[i].def[k] = T[i][1 + k]; p[i].lo[k] = T[i][4 + k]; p[i].hi[k] = T[i][7 + k]; }
+    }
+}
+
+/* params.py:81-99 DomainParams.sample: default when rng is None, else rng.float(min,max) */
+static void sample_param(MwoEnv *e, int use_rng, int name, double *out) {
+    Param *p = &e->params[name];
+    for (int k = 0; k < p->n; k++)
+        out[k] = use_rng ? rs_uniform(&e->rng, p->lo[k], p->hi[k]) : p->def[k];
+}
+
+MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int domain_rand, const double *params) {
+    MwoEnv *e = (MwoEnv *)calloc(1, sizeof(MwoEnv));
+    e->task = task;
+    static const double dflt[4][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}};
+    for (int i = 0; i < 4; i++) e->task_args[i] = task_args ? task_args[i] : dflt[task][i];
+    if (max_episode_steps <= 0) {
+        /* hallway.py:18, oneroom.py:14, fourrooms.py:15, maze.py:27 */
+        if (task == MWO_HALLWAY) max_episode_steps = 250;
+        else if (task == MWO_ONEROOM) max_episode_steps = 180;
+        else if (task == MWO_FOURROOMS) max_episode_steps = 250;
+        else max_episode_steps = (int)e->task_args[0] * (int)e->task_args[1] * 24;
+    }
+    e->max_episode_steps = max_episode_steps;
+    e->domain_rand = domain_rand;
+    default_params(e->params);
+    if (params)
+        for (int i = 0; i < MWO_NPARAM; i++)
+            for (int k = 0; k < 3; k++) {
+                e->params[i].def[k] = params[i * 9 + k];
+                e->params[i].lo[k] = params[i * 9 + 3 + k];
+                e->params[i].hi[k] = params[i * 9 + 6 + k];
+            }
+    uint32_t k0 = 0;
+    mt_init_by_array(&e->rng, &k0, 1);
+    return e;
+}
+
+static void free_rooms(MwoEnv *e) {
+    for (int i = 0; i < e->n_rooms; i++) { free(e->rooms[i].quads); free(e->rooms[i].segs); e->rooms[i].quads = NULL; e->rooms[i].segs = NULL; }
+    free(e->wall_segs); e->wall_segs = NULL;
+    e->n_rooms = 0; e->n_segs = 0; e->static_done = 0;
+}
+
+void mwo_destroy(MwoEnv *e) { if (!e) return; free_rooms(e); free(e); }
+
+void mwo_seed_key(MwoEnv *e, const uint32_t *key, int n) { mt_init_by_array(&e->rng, key, n); }
+
+static double norm3(const double *v) { /* np.linalg.norm(axis=1): sqrt(add.reduce(v*v)) */
+    return sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+}
+
+/* Room.__init__, miniworld.py:75-138 */
+static Room *add_room(MwoEnv *e, const double outline2[4][2], double wall_height, int wall_tex, int floor_tex, int ceil_tex, int no_ceiling) {
+    if (e->static_done) fail("cannot add rooms after static data is generated");
+    if (e->n_rooms >= MWO_MAX_ROOMS) fail("too many rooms");
+    Room *r = &e->rooms[e->n_rooms++];
+    memset(r, 0, sizeof(*r));
+    for (int i = 0; i < 4; i++) { r->outline[i][0] = outline2[i][0]; r->outline[i][1] = 0; r->outline[i][2] = outline2[i][1]; }
+    r->min_x = r->max_x = r->outline[0][0]; r->min_z = r->max_z = r->outline[0][2];
+    for (int i = 1; i < 4; i++) {
+        if (r->outline[i][0] < r->min_x) r->min_x = r->outline[i][0];
+        if (r->outline[i][0] > r->max_x) r->max_x = r->outline[i][0];
+        if (r->outline[i][2] < r->min_z) r->min_z = r->outline[i][2];
+        if (r->outline[i][2] > r->max_z) r->max_z = r->outline[i][2];
+    }
+    r->mid_x = (r->max_x + r->min_x) / 2; r->mid_z = (r->max_z + r->min_z) / 2;
+    r->area = (r->max_x - r->min_x) * (r->max_z - r->min_z);
+    for (int i = 0; i < 4; i++) {
+        const double *p0 = r->outline[i], *p1 = r->outline[(i + 1) % 4];
+        double d[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+        double n = norm3(d);
+        for (int k = 0; k < 3; k++) r->edge_dirs[i][k] = d[k] / n;
+        /* -cross(edge_dir, Y_VEC) then normalise (miniworld.py:119-120) */
+        const double *ed = r->edge_dirs[i];
+        double c[3] = {ed[1] * 0 - ed[2] * 1, ed[2] * 0 - ed[0] * 0, ed[0] * 1 - ed[1] * 0};
+        double en[3] = {-c[0], -c[1], -c[2]};
+        double nn = norm3(en);
+        for (int k = 0; k < 3; k++) r->edge_norms[i][k] = en[k] / nn;
+    }
+    r->wall_height = wall_height; r->no_ceiling = no_ceiling;
+    r->wall_tex_name = wall_tex; r->floor_tex_name = floor_tex; r->ceil_tex_name = ceil_tex;
+    return r;
+}
+
+/* add_rect_room, miniworld.py:718-743 */
+static Room *add_rect_room(MwoEnv *e, double min_x, double max_x, double min_z, double max_z, int wall_tex) {
+    double o[4][2] = {{max_x, max_z}, {max_x, min_z}, {min_x, min_z}, {min_x, max_z}};
+    return add_room(e, o, 2.74, wall_tex, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES, 0);
+}
+
+/* Room.add_portal, miniworld.py:140-218.  mode 0: start/end given; 1: min_x/max_x; 2: min_z/max_z */
+static void add_portal(Room *r, int edge, int mode, double a, double b, int has_max_y, double max_y_in, double *start_out, double *end_out) {
+    double max_y = has_max_y ? max_y_in : r->wall_height, min_y = 0;
+    const double *p0 = r->outline[edge], *p1 = r->outline[(edge + 1) % 4];
+    double diff[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    /* 1-D np.linalg.norm = sqrt(dot(x,x)); exact for the axis-aligned edges of every configured task */
+    double e_len = sqrt(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
+    double dx = diff[0] / e_len, dz = diff[2] / e_len;
+    double start, end;
+    if (mode == 1) {
+        double m0 = (a - p0[0]) / dx, m1 = (b - p0[0]) / dx;
+        if (m1 < m0) { double t = m0; m0 = m1; m1 = t; }
+        start = m0; end = m1;
+    } else if (mode == 2) {
+        double m0 = (a - p0[2]) / dz, m1 = (b - p0[2]) / dz;
+        if (m1 < m0) { double t = m0; m0 = m1; m1 = t; }
+        start = m0; end = m1;
+    } else { start = a; end = b; }
+    if (!(end > start) || !(start >= 0) || !(end <= e_len)) fail("portal outside of wall extents");
+    int n = r->n_portals[edge];
+    if (n >= MWO_MAX_PORTALS) fail("too many portals on one edge");
+    Portal np_ = {start, end, min_y, max_y};
+    /* list.append + stable sort by start_pos */
+    int k = n;
+    r->portals[edge][n] = np_;
+    while (k > 0 && r->portals[edge][k - 1].start > r->portals[edge][k].start) {
+        Portal t = r->portals[edge][k - 1]; r->portals[edge][k - 1] = r->portals[edge][k]; r->portals[edge][k] = t; k--;
+    }
+    r->n_portals[edge]++;
+    if (start_out) { *start_out = start; *end_out = end; }
+}
+
+/* connect_rooms, miniworld.py:757-843 */
+static void connect_rooms(MwoEnv *e, int ia, int ib, int mode, double lo, double hi, int has_max_y, double max_y) {
+    Room *A = &e->rooms[ia], *B = &e->rooms[ib];
+    int idx_a = -1, idx_b = -1;
+    for (int i = 0; i < 4 && idx_a < 0; i++)
+        for (int j = 0; j < 4; j++) {
+            const double *na = A->edge_norms[i], *nb = B->edge_norms[j];
+            double dotn = na[0] * nb[0] + na[1] * nb[1] + na[2] * nb[2];
+            if (dotn > -0.9) continue;
+            double dir[3] = {B->outline[j][0] - A->outline[i][0], B->outline[j][1] - A->outline[i][1], B->outline[j][2] - A->outline[i][2]};
+            double dd = na[0] * dir[0] + na[1] * dir[1] + na[2] * dir[2];
+            if (dd > 0.05) continue;
+            idx_a = i; idx_b = j; break;
+        }
+    if (idx_a < 0) fail("matching edges not found in connect_rooms");
+    double sa, ea, sb, eb;
+    add_portal(A, idx_a, mode, lo, hi, has_max_y, max_y, &sa, &ea);
+    add_portal(B, idx_b, mode, lo, hi, has_max_y, max_y, &sb, &eb);
+    double a[3], b[3], c[3], d[3];
+    for (int k = 0; k < 3; k++) {
+        a[k] = A->outline[idx_a][k] + A->edge_dirs[idx_a][k] * sa;
+        b[k] = A->outline[idx_a][k] + A->edge_dirs[idx_a][k] * ea;
+        c[k] = B->outline[idx_b][k] + B->edge_dirs[idx_b][k] * sb;
+        d[k] = B->outline[idx_b][k] + B->edge_dirs[idx_b][k] * eb;
+    }
+    double ad[3] = {a[0] - d[0], a[1] - d[1], a[2] - d[2]};
+    if (sqrt(ad[0] * ad[0] + ad[1] * ad[1] + ad[2] * ad[2]) < 0.001) return;
+    double ba[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, dc[3] = {d[0] - c[0], d[1] - c[1], d[2] - c[2]};
+    double len_a = sqrt(ba[0] * ba[0] + ba[1] * ba[1] + ba[2] * ba[2]);
+    double len_b = sqrt(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]);
+    double o[4][2] = {{c[0], c[2]}, {b[0], b[2]}, {a[0], a[2]}, {d[0], d[2]}};
+    double my = has_max_y ? max_y : A->wall_height;
+    int wall_tex = A->wall_tex_name, floor_tex = A->floor_tex_name, ceil_tex = A->ceil_tex_name, noc = A->no_ceiling;
+    Room *R = add_room(e, o, my, wall_tex, floor_tex, ceil_tex, noc);
+    add_portal(R, 1, 0, 0, len_a, 0, 0, NULL, NULL);
+    add_portal(R, 3, 0, 0, len_b, 0, 0, NULL, NULL);
+}
+
+/* Texture.get, opengl.py:40-69: variant 1 unless rng, then rng.int(0, n) */
+static int tex_get(MwoEnv *e, int family, int use_rng) {
+    int idx = use_rng ? (int)rs_randint(&e->rng, 0, TEXF_COUNT[family]) : 0;
+    return TEXF_FIRST[family] + idx;
+}
+
+static int tex_width(int id) { return g_tex[id].w > 0 ? g_tex[id].w : (id == 3 || id == 5 ? 768 : id == 6 ? 1024 : 512); }
+static int tex_height(int id) { return g_tex[id].h > 0 ? g_tex[id].h : tex_width(id); }
+
+typedef struct { Room *r; Quad *q; int nq, capq; double (*s)[2][3]; int ns, caps; } GenCtx;
+
+/* gen_seg_poly, miniworld.py:267-309 */
+static void gen_seg_poly(GenCtx *g, const double *edge_p0, const double *side_vec, double seg_start, double seg_end, double min_y, double max_y) {
+    if (seg_end == seg_start) return;
+    if (min_y == max_y) return;
+    double s_p0[3], s_p1[3];
+    for (int k = 0; k < 3; k++) { s_p0[k] = edge_p0[k] + seg_start * side_vec[k]; s_p1[k] = edge_p0[k] + seg_end * side_vec[k]; }
+    if (min_y == 0) {
+        if (g->ns == g->caps) { g->caps = g->caps ? g->caps * 2 : 8; g->s = realloc(g->s, sizeof(double[2][3]) * g->caps); }
+        memcpy(g->s[g->ns][0], s_p1, sizeof(s_p1)); memcpy(g->s[g->ns][1], s_p0, sizeof(s_p0)); g->ns++;
+    }
+    if (g->nq == g->capq) { g->capq = g->capq ? g->capq * 2 : 8; g->q = realloc(g->q, sizeof(Quad) * g->capq); }
+    Quad *q = &g->q[g->nq++];
+    const double Y[3] = {0, 1, 0};
+    for (int k = 0; k < 3; k++) {
+        q->verts[0][k] = s_p0[k] + min_y * Y[k]; q->verts[1][k] = s_p0[k] + max_y * Y[k];
+        q->verts[2][k] = s_p1[k] + max_y * Y[k]; q->verts[3][k] = s_p1[k] + min_y * Y[k];
+    }
+    double d[3] = {s_p1[0] - s_p0[0], s_p1[1] - s_p0[1], s_p1[2] - s_p0[2]};
+    double c[3] = {d[1] * 0 - d[2] * 1, d[2] * 0 - d[0] * 0, d[0] * 1 - d[1] * 0};
+    double n = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    for (int k = 0; k < 3; k++) q->norm[k] = -c[k] / n;
+    /* gen_texcs_wall, miniworld.py:19-46 (float32 result) */
+    double xc = 512.0 / tex_width(g->r->wall_tex), yc = 512.0 / tex_height(g->r->wall_tex);
+    double width = seg_end - seg_start, height = max_y - min_y;
+    double min_u = seg_start * xc, max_u = (seg_start + width) * xc, min_v = min_y * yc, max_v = (min_y + height) * yc;
+    q->texcs[0][0] = (float)min_u; q->texcs[0][1] = (float)min_v; q->texcs[1][0] = (float)min_u; q->texcs[1][1] = (float)max_v;
+    q->texcs[2][0] = (float)max_u; q->texcs[2][1] = (float)max_v; q->texcs[3][0] = (float)max_u; q->texcs[3][1] = (float)min_v;
+}
+
+/* Room._gen_static_data, miniworld.py:234-388 */
+static void room_gen_static(MwoEnv *e, Room *r, int use_rng) {
+    r->wall_tex = tex_get(e, r->wall_tex_name, use_rng);
+    r->floor_tex = tex_get(e, r->floor_tex_name, use_rng);
+    r->ceil_tex = tex_get(e, r->ceil_tex_name, use_rng);
+    /* gen_texcs_floor, miniworld.py:48-68 */
+    for (int i = 0; i < 4; i++) {
+        r->floor_texcs[i][0] = r->outline[i][0] * (512.0 / tex_width(r->floor_tex));
+        r->floor_texcs[i][1] = r->outline[i][2] * (512.0 / tex_height(r->floor_tex));
+        const double *cv = r->outline[3 - i]; /* np.flip(outline, axis=0) */
+        r->ceil_texcs[i][0] = (cv[0] + r->wall_height * 0) * (512.0 / tex_width(r->ceil_tex));
+        r->ceil_texcs[i][1] = (cv[2] + r->wall_height * 0) * (512.0 / tex_height(r->ceil_tex));
+    }
+    GenCtx g = {r, NULL, 0, 0, NULL, 0, 0};
+    for (int w = 0; w < 4; w++) {
+        const double *p0 = r->outline[w], *p1 = r->outline[(w + 1) % 4];
+        double d[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+        double wall_width = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        double side[3] = {d[0] / wall_width, d[1] / wall_width, d[2] / wall_width};
+        int np_ = r->n_portals[w];
+        double seg_end = np_ > 0 ? r->portals[w][0].start : wall_width;
+        gen_seg_poly(&g, p0, side, 0, seg_end, 0, r->wall_height);
+        for (int k = 0; k < np_; k++) {
+            Portal *p = &r->portals[w][k];
+            gen_seg_poly(&g, p0, side, p->start, p->end, 0, p->min_y);
+            gen_seg_poly(&g, p0, side, p->start, p->end, p->max_y, r->wall_height);
+            double next_start = (k < np_ - 1) ? r->portals[w][k + 1].start : wall_width;
+            gen_seg_poly(&g, p0, side, p->end, next_start, 0, r->wall_height);
+        }
+    }
+    r->quads = g.q; r->n_quads = g.nq; r->segs = g.s; r->n_segs = g.ns;
+}
+
+/* MiniWorldEnv._gen_static_data, miniworld.py:981-998 */
+static void gen_static_data(MwoEnv *e) {
+    int total = 0;
+    for (int i = 0; i < e->n_rooms; i++) { room_gen_static(e, &e->rooms[i], e->domain_rand); total += e->rooms[i].n_segs; }
+    e->wall_segs = malloc(sizeof(double[2][3]) * (total > 0 ? total : 1));
+    int k = 0;
+    for (int i = 0; i < e->n_rooms; i++)
+        for (int s = 0; s < e->rooms[i].n_segs; s++) memcpy(e->wall_segs[k++], e->rooms[i].segs[s], sizeof(double[2][3]));
+    e->n_segs = total;
+    double areas[MWO_MAX_ROOMS];
+    for (int i = 0; i < e->n_rooms; i++) areas[i] = e->rooms[i].area;
+    double sum = np_pairwise_sum(areas, e->n_rooms);
+    for (int i = 0; i < e->n_rooms; i++) e->room_probs[i] = areas[i] / sum;
+    /* RandomState.choice: cdf = p.cumsum(); cdf /= cdf[-1] */
+    double acc = 0;
+    for (int i = 0; i < e->n_rooms; i++) { acc = (i == 0) ? e->room_probs[0] : acc + e->room_probs[i]; e->room_cdf[i] = acc; }
+    double last = e->room_cdf[e->n_rooms - 1];
+    for (int i = 0; i < e->n_rooms; i++) e->room_cdf[i] /= last;
+    e->static_done = 1;
+}
+
+/* math.py:25-57 */
+int mwo_intersect_circle_segs(const double *point, double radius, const double *segs, int n) {
+    double px = point[0], pz = point[2];
+    for (int i = 0; i < n; i++) {
+        const double *a = segs + i * 6, *b = a + 3;
+        double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+        double ap[3] = {px - a[0], 0 - a[1], pz - a[2]};
+        double dotAPAB = (ap[0] * ab[0] + ap[1] * ab[1]) + ap[2] * ab[2];
+        double dotABAB = (ab[0] * ab[0] + ab[1] * ab[1]) + ab[2] * ab[2];
+        double proj = dotAPAB / dotABAB;
+        if (proj < 0) proj = 0; else if (proj > 1) proj = 1; /* np.clip; nan propagates */
+        double c[3] = {a[0] + proj * ab[0], a[1] + proj * ab[1], a[2] + proj * ab[2]};
+        double dv[3] = {c[0] - px, c[1] - 0, c[2] - pz};
+        double dist = sqrt((dv[0] * dv[0] + dv[1] * dv[1]) + dv[2] * dv[2]);
+        if (dist < radius) return 1;
+    }
+    return 0;
+}
+
+/* MiniWorldEnv.intersect, miniworld.py:933-959. returns 1 wall, 2+k entity k, 0 none */
+static int intersect(MwoEnv *e, const Ent *self, const double *pos, double radius) {
+    double p[3] = {pos[0], 0, pos[2]};
+    if (mwo_intersect_circle_segs(p, radius, &e->wall_segs[0][0][0], e->n_segs)) return 1;
+    const Ent *ents[2] = {&e->box, &e->agent};
+    for (int k = 0; k < e->n_ents; k++) {
+        const Ent *o = ents[k];
+        if (o == self) continue;
+        double d3[3] = {o->pos[0] - p[0], 0 - p[1], o->pos[2] - p[2]};
+        double d = sqrt(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
+        if (d < radius + o->radius) return 2 + k;
+    }
+    return 0;
+}
+
+int mwo_intersect(MwoEnv *e, int ent, double x, double z, double radius) {
+    double p[3] = {x, 0, z};
+    return intersect(e, ent == 0 ? &e->box : &e->agent, p, radius);
+}
+
+/* Room.point_inside, miniworld.py:220-232 */
+static int point_inside(const Room *r, const double *p) {
+    for (int i = 0; i < 4; i++) {
+        double ap[3] = {p[0] - r->outline[i][0], p[1] - r->outline[i][1], p[2] - r->outline[i][2]};
+        const double *n = r->edge_norms[i];
+        double dot = (n[0] * ap[0] + n[1] * ap[1]) + n[2] * ap[2];
+        if (!(dot > 0)) return 0;
+    }
+    return 1;
+}
+
+#define NOVAL (-1e300)
+/* place_entity, miniworld.py:845-907 (pos=None path) */
+static void place_entity(MwoEnv *e, Ent *ent, int has_dir, double dir, double min_x, double max_x, double min_z, double max_z) {
+    if (e->n_rooms <= 0) fail("create rooms before calling place_entity");
+    if (!e->static_done) gen_static_data(e);
+    for (;;) {
+        Room *r = &e->rooms[rs_choice_cdf(&e->rng, e->room_cdf, e->n_rooms)];
+        double lx = min_x == NOVAL ? r->min_x : min_x, hx = max_x == NOVAL ? r->max_x : max_x;
+        double lz = min_z == NOVAL ? r->min_z : min_z, hz = max_z == NOVAL ? r->max_z : max_z;
+        double pos[3];
+        pos[0] = rs_uniform(&e->rng, lx + ent->radius, hx - ent->radius);
+        pos[1] = rs_uniform(&e->rng, 0, 0);
+        pos[2] = rs_uniform(&e->rng, lz + ent->radius, hz - ent->radius);
+        if (!point_inside(r, pos)) continue;
+        if (intersect(e, ent, pos, ent->radius)) continue;
+        double d = has_dir ? dir : rs_uniform(&e->rng, -M_PI, M_PI);
+        memcpy(ent->pos, pos, sizeof(pos));
+        ent->dir = d;
+        break;
+    }
+    e->n_ents++;
+}
+
+static void new_box(MwoEnv *e) {
+    /* entity.py:362-379 Box(color='red', size=0.8) */
+    double sx = 0.8, sy = 0.8, sz = 0.8;
+    e->box_size[0] = sx; e->box_size[1] = sy; e->box_size[2] = sz;
+    e->box.radius = sqrt(sx * sx + sz * sz) / 2;
+    e->box.height = sy;
+}
+
+/* envs/maze.py:34-104 */
+typedef struct { int i, j; int order[4][2]; int next; } Frame;
+static void gen_maze(MwoEnv *e) {
+    int num_rows = (int)e->task_args[0], num_cols = (int)e->task_args[1];
+    double room_size = e->task_args[2], gap = 0.25;
+    for (int j = 0; j < num_rows; j++)
+        for (int i = 0; i < num_cols; i++) {
+            double min_x = i * (room_size + gap), max_x = min_x + room_size;
+            double min_z = j * (room_size + gap), max_z = min_z + room_size;
+            add_rect_room(e, min_x, max_x, min_z, max_z, TEXF_BRICK_WALL);
+        }
+    char *visited = calloc(num_rows * num_cols, 1);
+    Frame *stack = malloc(sizeof(Frame) * (num_rows * num_cols + 1));
+    int sp = 0;
+    static const int NB[4][2] = {{0, 1}, {0, -1}, {-1, 0}, {1, 0}}; /* (dj, di) */
+#define PUSH(I, J) do { Frame *f = &stack[sp++]; f->i = (I); f->j = (J); f->next = 0; visited[(J) * num_cols + (I)] = 1; \
+        int lst[4] = {0, 1, 2, 3}, n = 4; \
+        for (int q = 0; q < 4; q++) { /* RandGen.subset: choice + list.remove, random.py:50-65 */ \
+            int idx = (int)rs_randint(&e->rng, 0, n); \
+            f->order[q][0] = NB[lst[idx]][0]; f->order[q][1] = NB[lst[idx]][1]; \
+            for (int w = idx; w < n - 1; w++) { lst[w] = lst[w + 1]; } \
+            n--; } } while (0)
+    PUSH(0, 0);
+    while (sp > 0) {
+        Frame *f = &stack[sp - 1];
+        if (f->next >= 4) { sp--; continue; }
+        int dj = f->order[f->next][0], di = f->order[f->next][1];
+        f->next++;
+        int ni = f->i + di, nj = f->j + dj;
+        if (nj < 0 || nj >= num_rows || ni < 0 || ni >= num_cols) continue;
+        if (visited[nj * num_cols + ni]) continue;
+        int ra = f->j * num_cols + f->i, rb = nj * num_cols + ni;
+        Room *room = &e->rooms[ra];
+        if (di == 0) connect_rooms(e, ra, rb, 1, room->min_x, room->max_x, 0, 0);
+        else if (dj == 0) connect_rooms(e, ra, rb, 2, room->min_z, room->max_z, 0, 0);
+        PUSH(ni, nj);
+    }
+#undef PUSH
+    free(visited); free(stack);
+    new_box(e);
+    place_entity(e, &e->box, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+    place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+}
+
+static void gen_world(MwoEnv *e) {
+    switch (e->task) {
+    case MWO_HALLWAY: { /* envs/hallway.py:25-42 */
+        double length = e->task_args[0];
+        Room *room = add_rect_room(e, -1, -1 + length, -2, 2, TEXF_CONCRETE);
+        double rmax = room->max_x;
+        new_box(e);
+        place_entity(e, &e->box, 0, 0, rmax - 2, NOVAL, NOVAL, NOVAL);
+        double dir = rs_uniform(&e->rng, -M_PI / 4, M_PI / 4);
+        place_entity(e, &e->agent, 1, dir, NOVAL, rmax - 2, NOVAL, NOVAL);
+        break;
+    }
+    case MWO_ONEROOM: { /* envs/oneroom.py:26-35 */
+        double size = e->task_args[0];
+        add_rect_room(e, 0, size, 0, size, TEXF_CONCRETE);
+        new_box(e);
+        place_entity(e, &e->box, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        break;
+    }
+    case MWO_FOURROOMS: { /* envs/fourrooms.py:22-52 */
+        add_rect_room(e, -7, -1, 1, 7, TEXF_CONCRETE);
+        add_rect_room(e, 1, 7, 1, 7, TEXF_CONCRETE);
+        add_rect_room(e, 1, 7, -7, -1, TEXF_CONCRETE);
+        add_rect_room(e, -7, -1, -7, -1, TEXF_CONCRETE);
+        connect_rooms(e, 0, 1, 2, 3, 5, 1, 2.2);
+        connect_rooms(e, 1, 2, 1, 3, 5, 1, 2.2);
+        connect_rooms(e, 2, 3, 2, -5, -3, 1, 2.2);
+        connect_rooms(e, 3, 0, 1, -5, -3, 1, 2.2);
+        new_box(e);
+        place_entity(e, &e->box, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        break;
+    }
+    case MWO_MAZE: gen_maze(e); break;
+    default: fail("unknown task");
+    }
+}
+
+/* MiniWorldEnv.reset, miniworld.py:532-592 */
+void mwo_reset(MwoEnv *e) {
+    e->step_count = 0;
+    free_rooms(e);
+    e->n_ents = 0;
+    memset(&e->agent, 0, sizeof(Ent));
+    e->agent.radius = 0.4; e->agent.height = 1.6; /* entity.py:436-455 */
+    gen_world(e);
+    int dr = e->domain_rand;
+    sample_param(e, dr, MWO_P_SKY_COLOR, e->sky_color);
+    sample_param(e, dr, MWO_P_LIGHT_POS, e->light_pos);
+    sample_param(e, dr, MWO_P_LIGHT_COLOR, e->light_color);
+    sample_param(e, dr, MWO_P_LIGHT_AMBIENT, e->light_ambient);
+    e->max_forward_step = e->params[MWO_P_FORWARD_STEP].hi[0];
+    /* Box.randomize, entity.py:381-383: COLORS['red'] + bias, clipped */
+    double bias[3];
+    sample_param(e, dr, MWO_P_OBJ_COLOR_BIAS, bias);
+    const double red[3] = {1.0, 0.0, 0.0};
+    for (int k = 0; k < 3; k++) { double v = red[k] + bias[k]; e->box_color[k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
+    /* Agent.randomize, entity.py:486-492 */
+    sample_param(e, dr, MWO_P_CAM_HEIGHT, &e->cam_height);
+    sample_param(e, dr, MWO_P_CAM_FWD_DISP, &e->cam_fwd_disp);
+    sample_param(e, dr, MWO_P_CAM_PITCH, &e->cam_pitch);
+    sample_param(e, dr, MWO_P_CAM_FOV_Y, &e->cam_fov_y);
+    if (!e->static_done) gen_static_data(e);
+}
+
+/* MiniWorldEnv.near, miniworld.py:961-971 */
+static int near_box(MwoEnv *e) {
+    double d[3] = {e->box.pos[0] - e->agent.pos[0], e->box.pos[1] - e->agent.pos[1], e->box.pos[2] - e->agent.pos[2]};
+    double dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    return dist < e->box.radius + e->agent.radius + 1.1 * e->max_forward_step;
+}
+
+/* MiniWorldEnv.step miniworld.py:658-716 + task rule (e.g. envs/maze.py:106-113) */
+void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
+    e->step_count += 1;
+    int dr = e->domain_rand;
+    double fwd_step, fwd_drift, turn_step;
+    sample_param(e, dr, MWO_P_FORWARD_STEP, &fwd_step);
+    sample_param(e, dr, MWO_P_FORWARD_DRIFT, &fwd_drift);
+    sample_param(e, dr, MWO_P_TURN_STEP, &turn_step);
+    if (action == 2 || action == 3) { /* move_agent miniworld.py:608-633 */
+        double fd = action == 2 ? fwd_step : -fwd_step;
+        double dv[3] = {cos(e->agent.dir), 0, -sin(e->agent.dir)}; /* entity.py:72-80 */
+        double rv[3] = {sin(e->agent.dir), 0, cos(e->agent.dir)};  /* entity.py:82-90 */
+        double np_[3];
+        for (int k = 0; k < 3; k++) np_[k] = (e->agent.pos[k] + dv[k] * fd) + rv[k] * fwd_drift;
+        if (!intersect(e, &e->agent, np_, e->agent.radius)) memcpy(e->agent.pos, np_, sizeof(np_));
+    } else if (action == 0 || action == 1) { /* turn_agent miniworld.py:635-656 */
+        double ta = action == 0 ? turn_step : -turn_step;
+        ta *= (M_PI / 180);
+        e->agent.dir += ta;
+    }
+    double r = 0; int d = 0;
+    if (e->step_count >= e->max_episode_steps) { d = 1; r = 0; }
+    if (near_box(e)) { r += 1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps); d = 1; }
+    *reward = r; *done = d;
+}
+
+/* math.py:9-23 */
+void mwo_gen_rot_matrix(const double *axis_in, double angle, double *m) {
+    double n = sqrt(axis_in[0] * axis_in[0] + axis_in[1] * axis_in[1] + axis_in[2] * axis_in[2]);
+    double axis[3] = {axis_in[0] / n, axis_in[1] / n, axis_in[2] / n};
+    double a = cos(angle / 2.0), s = sin(angle / 2.0);
+    double b = -axis[0] * s, c = -axis[1] * s, d = -axis[2] * s;
+    m[0] = a * a + b * b - c * c - d * d; m[1] = 2 * (b * c - a * d); m[2] = 2 * (b * d + a * c);
+    m[3] = 2 * (b * c + a * d); m[4] = a * a + c * c - b * b - d * d; m[5] = 2 * (c * d - a * b);
+    m[6] = 2 * (b * d - a * c); m[7] = 2 * (c * d + a * b); m[8] = a * a + d * d - b * b - c * c;
+}
+
+static void vec_mat(const double *v, const double *m, double *out) { /* np.dot(v, M) */
+    for (int j = 0; j < 3; j++) out[j] = (v[0] * m[0 * 3 + j] + v[1] * m[1 * 3 + j]) + v[2] * m[2 * 3 + j];
+}
+
+/* Agent.cam_pos / cam_dir, entity.py:457-484 */
+static void camera(MwoEnv *e, double *cam_pos, double *cam_dir) {
+    const double Yv[3] = {0, 1, 0}, Zv[3] = {0, 0, 1}, Xv[3] = {1, 0, 0};
+    double rot_y[9], rot_z[9], disp[3], t[3];
+    mwo_gen_rot_matrix(Yv, e->agent.dir, rot_y);
+    double cd[3] = {e->cam_fwd_disp, e->cam_height, 0};
+    vec_mat(cd, rot_y, disp);
+    for (int k = 0; k < 3; k++) cam_pos[k] = e->agent.pos[k] + disp[k];
+    mwo_gen_rot_matrix(Zv, e->cam_pitch * M_PI / 180, rot_z);
+    vec_mat(Xv, rot_z, t);
+    vec_mat(t, rot_y, cam_dir);
+}
+
+void mwo_get_state(MwoEnv *e, MwoState *s) {
+    memset(s, 0, sizeof(*s));
+    memcpy(s->agent_pos, e->agent.pos, 24); s->agent_dir = e->agent.dir;
+    memcpy(s->box_pos, e->box.pos, 24); s->box_dir = e->box.dir; memcpy(s->box_color, e->box_color, 24);
+    s->cam_height = e->cam_height; s->cam_fwd_disp = e->cam_fwd_disp; s->cam_pitch = e->cam_pitch; s->cam_fov_y = e->cam_fov_y;
+    memcpy(s->sky_color, e->sky_color, 24); memcpy(s->light_pos, e->light_pos, 24);
+    memcpy(s->light_color, e->light_color, 24); memcpy(s->light_ambient, e->light_ambient, 24);
+    camera(e, s->cam_pos, s->cam_dir);
+    s->step_count = e->step_count; s->max_episode_steps = e->max_episode_steps;
+    s->n_rooms = e->n_rooms; s->n_segs = e->n_segs;
+    int nq = 0; for (int i = 0; i < e->n_rooms; i++) nq += e->rooms[i].n_quads;
+    s->n_quads = nq;
+    s->rng_pos = e->rng.pos; s->rng_key0 = e->rng.key[0]; s->rng_key1 = e->rng.key[1]; s->rng_key623 = e->rng.key[623];
+    uint64_t sum = 0; for (int i = 0; i < 624; i++) sum += e->rng.key[i];
+    s->rng_keysum = (uint32_t)(sum & 0xFFFFFFFFu);
+}
+
+void mwo_set_agent(MwoEnv *e, double x, double z, double dir) { e->agent.pos[0] = x; e->agent.pos[1] = 0; e->agent.pos[2] = z; e->agent.dir = dir; }
+void mwo_set_step_count(MwoEnv *e, int sc) { e->step_count = sc; }
+
+void mwo_get_geometry(MwoEnv *e, double *outline, double *heights, double *portals, int *portal_count, double *segs,
+                      double *room_probs, double *qv, double *qn, float *qt, int *qoff, double *ftex, double *ctex, int *tex_ids) {
+    int q = 0;
+    for (int i = 0; i < e->n_rooms; i++) {
+        Room *r = &e->rooms[i];
+        for (int k = 0; k < 4; k++) { outline[(i * 4 + k) * 2] = r->outline[k][0]; outline[(i * 4 + k) * 2 + 1] = r->outline[k][2]; }
+        heights[i] = r->wall_height;
+        for (int ed = 0; ed < 4; ed++) {
+            portal_count[i * 4 + ed] = r->n_portals[ed];
+            for (int k = 0; k < MWO_MAX_PORTALS; k++) {
+                double *o = portals + ((i * 4 + ed) * MWO_MAX_PORTALS + k) * 4;
+                if (k < r->n_portals[ed]) { o[0] = r->portals[ed][k].start; o[1] = r->portals[ed][k].end; o[2] = r->portals[ed][k].min_y; o[3] = r->portals[ed][k].max_y; }
+                else o[0] = o[1] = o[2] = o[3] = NAN;
+            }
+        }
+        room_probs[i] = e->room_probs[i];
+        qoff[i] = q;
+        for (int k = 0; k < r->n_quads; k++, q++)
+            for (int v = 0; v < 4; v++) {
+                for (int c = 0; c < 3; c++) { qv[(q * 4 + v) * 3 + c] = r->quads[k].verts[v][c]; qn[(q * 4 + v) * 3 + c] = r->quads[k].norm[c]; }
+                qt[(q * 4 + v) * 2] = r->quads[k].texcs[v][0]; qt[(q * 4 + v) * 2 + 1] = r->quads[k].texcs[v][1];
+            }
+        for (int v = 0; v < 4; v++) {
+            ftex[(i * 4 + v) * 2] = r->floor_texcs[v][0]; ftex[(i * 4 + v) * 2 + 1] = r->floor_texcs[v][1];
+            ctex[(i * 4 + v) * 2] = r->ceil_texcs[v][0]; ctex[(i * 4 + v) * 2 + 1] = r->ceil_texcs[v][1];
+        }
+        tex_ids[i * 3] = r->wall_tex; tex_ids[i * 3 + 1] = r->floor_tex; tex_ids[i * 3 + 2] = r->ceil_tex;
+    }
+    qoff[e->n_rooms] = q;
+    for (int s = 0; s < e->n_segs; s++) {
+        segs[s * 4] = e->wall_segs[s][0][0]; segs[s * 4 + 1] = e->wall_segs[s][0][2];
+        segs[s * 4 + 2] = e->wall_segs[s][1][0]; segs[s * 4 + 3] = e->wall_segs[s][1][2];
+    }
+}
+
+/* ===================================================================== render (float32) */
+/* Restates what the reference asks of OpenGL (render_obs miniworld.py:1160-1205,
+ * _render_static 1014-1057, Room._render 390-423, Box.render entity.py:385-408,
+ * drawBox opengl.py:394-444, Texture.load opengl.py:85-103, FrameBuffer.resolve 283-334,
+ * get_depth_map 336-371).  Frozen choices where GL leaves freedom:
+ *   - 8 samples/pixel at the standard 8x pattern; coverage + nearest depth per sample,
+ *     exact (unquantised) depth ordering, ties -> earlier-drawn surface;
+ *   - one shade per (pixel, surface) at the pixel centre, plane extrapolated;
+ *   - LOD from forward differences of the surface's texcoords at the pixel centre,
+ *     trilinear REPEAT filtering over a 2x2-box-filtered RGBA8 mip chain;
+ *   - resolve = mean of the 8 sample colours, unorm8 round-to-nearest;
+ *   - depth resolve takes sample 0, DEPTH16 round-to-nearest.
+ * Visibility uses portal traversal of the axis-aligned rooms (watertight by construction);
+ * tests/ cross-check it against a brute-force z-buffer over the reference's own polygon stream.
+ */
+typedef struct {
+    float lo, hi, min_y, max_y; /* portal extent along the side's axis (world coord) and in y */
+    int nbr;                    /* room behind the portal, -1 none */
+    float u_org, u_sgn;         /* wall texcoord: s = (coord - u_org) * u_sgn * scale */
+} RSide;
+typedef struct {
+    float min_x, max_x, min_z, max_z, height;
+    int wall_tex, floor_tex, ceil_tex;
+    RSide side[4]; /* 0:+x (east) 1:-z (north) 2:-x (west) 3:+z (south) */
+} RRoom;
+
+static const float SAMPLE_X[8] = {1, -1, 5, -3, -5, -7, 3, 7};
+static const float SAMPLE_Y[8] = {-3, 3, 1, -5, 5, -1, 7, -7};
+
+typedef struct {
+    float eye[3], F[3], S[3], U[3], TW, TH;
+    int W, H;
+    float invW, invH;
+} Cam;
+
+static void make_ray(const Cam *c, float wx, float wy, float *d) {
+    float nx = (2.0f * wx - (float)c->W) * c->invW, ny = (2.0f * wy - (float)c->H) * c->invH;
+    float ax = nx * c->TW, ay = ny * c->TH;
+    for (int k = 0; k < 3; k++) d[k] = (c->F[k] + c->S[k] * ax) + c->U[k] * ay;
+}
+
+typedef struct { int kind; /* 0 sky, 1 floor, 2 ceil, 3 wall, 4 box */ int room, side; float t; } Hit;
+
+static int build_rrooms(MwoEnv *e, RRoom *rr) {
+    int n = e->n_rooms;
+    int side_of_edge[MWO_MAX_ROOMS][4];
+    for (int i = 0; i < n; i++) {
+        Room *r = &e->rooms[i]; RRoom *o = &rr[i];
+        o->min_x = (float)r->min_x; o->max_x = (float)r->max_x; o->min_z = (float)r->min_z; o->max_z = (float)r->max_z;
+        o->height = (float)r->wall_height;
+        o->wall_tex = r->wall_tex; o->floor_tex = r->floor_tex; o->ceil_tex = r->ceil_tex;
+        for (int s = 0; s < 4; s++) { o->side[s].nbr = -1; o->side[s].lo = o->side[s].hi = o->side[s].min_y = o->side[s].max_y = 0; }
+        for (int ed = 0; ed < 4; ed++) {
+            const double *nrm = r->edge_norms[ed];
+            int s;
+            if (nrm[0] == -1 && nrm[2] == 0) s = 0; else if (nrm[0] == 0 && nrm[2] == 1) s = 1;
+            else if (nrm[0] == 1 && nrm[2] == 0) s = 2; else if (nrm[0] == 0 && nrm[2] == -1) s = 3;
+            else fail("render: only axis-aligned rectangular rooms are supported");
+            side_of_edge[i][ed] = s;
+            int ax = (s == 0 || s == 2) ? 2 : 0; /* coordinate that runs along this side */
+            double p0c = r->outline[ed][ax], dirc = r->edge_dirs[ed][ax];
+            o->side[s].u_org = (float)p0c; o->side[s].u_sgn = (float)dirc;
+            if (r->n_portals[ed] > 1) fail("render: at most one portal per edge");
+            if (r->n_portals[ed] == 1) {
+                Portal *p = &r->portals[ed][0];
+                double c0 = p0c + dirc * p->start, c1 = p0c + dirc * p->end;
+                o->side[s].lo = (float)(c0 < c1 ? c0 : c1); o->side[s].hi = (float)(c0 < c1 ? c1 : c0);
+                o->side[s].min_y = (float)p->min_y; o->side[s].max_y = (float)p->max_y;
+                o->side[s].nbr = -2; /* resolved below */
+            }
+        }
+    }
+    /* geometric neighbour inference: the room whose opposite side lies on the same plane with a matching portal */
+    for (int i = 0; i < n; i++)
+        for (int s = 0; s < 4; s++) {
+            if (rr[i].side[s].nbr != -2) continue;
+            float plane = s == 0 ? rr[i].max_x : s == 1 ? rr[i].min_z : s == 2 ? rr[i].min_x : rr[i].max_z;
+            int os = (s + 2) % 4, found = -1;
+            for (int j = 0; j < n && found < 0; j++) {
+                if (j == i || rr[j].side[os].nbr == -1) continue;
+                float pj = os == 0 ? rr[j].max_x : os == 1 ? rr[j].min_z : os == 2 ? rr[j].min_x : rr[j].max_z;
+                if (fabsf(pj - plane) < 1e-4f && fabsf(rr[j].side[os].lo - rr[i].side[s].lo) < 1e-4f &&
+                    fabsf(rr[j].side[os].hi - rr[i].side[s].hi) < 1e-4f) found = j;
+            }
+            if (found < 0) fail("render: portal without a neighbour room");
+            rr[i].side[s].nbr = found;
+        }
+    (void)side_of_edge;
+    return n;
+}
+
+static Hit trace_rooms(const RRoom *rr, int n_rooms, int room, const float *o, const float *d) {
+    Hit h = {0, -1, -1, INFINITY};
+    if (room < 0) return h;
+    for (int iter = 0; iter < n_rooms + 1; iter++) {
+        const RRoom *r = &rr[room];
+        float tx = INFINITY, tz = INFINITY; int sx = 0, sz = 1;
+        if (d[0] > 0) { tx = (r->max_x - o[0]) / d[0]; sx = 0; } else if (d[0] < 0) { tx = (r->min_x - o[0]) / d[0]; sx = 2; }
+        if (d[2] > 0) { tz = (r->max_z - o[2]) / d[2]; sz = 3; } else if (d[2] < 0) { tz = (r->min_z - o[2]) / d[2]; sz = 1; }
+        float ts; int s;
+        if (tx <= tz) { ts = tx; s = sx; } else { ts = tz; s = sz; }
+        if (d[1] < 0) { float tf = (0.0f - o[1]) / d[1]; if (tf <= ts) { h.kind = 1; h.room = room; h.t = tf; return h; } }
+        if (d[1] > 0) { float tc = (r->height - o[1]) / d[1]; if (tc <= ts) { h.kind = 2; h.room = room; h.t = tc; return h; } }
+        if (!(ts < INFINITY)) return h;
+        const RSide *sd = &r->side[s];
+        float hc = (s == 0 || s == 2) ? o[2] + ts * d[2] : o[0] + ts * d[0];
+        float y = o[1] + ts * d[1];
+        if (sd->nbr >= 0 && sd->lo < hc && hc < sd->hi && sd->min_y < y && y < sd->max_y) { room = sd->nbr; continue; }
+        h.kind = 3; h.room = room; h.side = s; h.t = ts; return h;
+    }
+    return h;
+}
+
+typedef struct { float pos[3], c, s, half[3], sy; } RBox;
+
+/* returns face index 0..5 (-x,+x,-y,+y,-z,+z in box-local axes) or -1; *t_out = entry t */
+static int trace_box(const RBox *b, const float *o, const float *d, float *t_out) {
+    float ro[3] = {o[0] - b->pos[0], o[1] - b->pos[1], o[2] - b->pos[2]};
+    float lo_[3] = {ro[0] * b->c - ro[2] * b->s, ro[1], ro[0] * b->s + ro[2] * b->c};
+    float ld[3] = {d[0] * b->c - d[2] * b->s, d[1], d[0] * b->s + d[2] * b->c};
+    float lo[3] = {-b->half[0], 0.0f, -b->half[2]}, hi[3] = {b->half[0], b->sy, b->half[2]};
+    float tn = -INFINITY, tf = INFINITY; int face = -1;
+    for (int a = 0; a < 3; a++) {
+        if (ld[a] == 0) { if (lo_[a] < lo[a] || lo_[a] > hi[a]) return -1; continue; }
+        float t1 = (lo[a] - lo_[a]) / ld[a], t2 = (hi[a] - lo_[a]) / ld[a];
+        float tmin = t1 < t2 ? t1 : t2, tmax = t1 < t2 ? t2 : t1;
+        if (tmin > tn) { tn = tmin; face = a * 2 + (ld[a] > 0 ? 0 : 1); }
+        if (tmax < tf) tf = tmax;
+    }
+    if (face < 0 || !(tn <= tf) || !(tn > 0)) return -1;
+    *t_out = tn;
+    return face;
+}
+
+static void fetch_texel(const Tex *t, int l, int i, int j, float *rgb) {
+    const uint8_t *p = t->data + t->level_off[l] + ((size_t)j * t->lw[l] + i) * 4;
+    rgb[0] = p[0]; rgb[1] = p[1]; rgb[2] = p[2];
+}
+
+static int imod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
+
+static void bilinear(const Tex *t, int l, float s, float tt, float *rgb) {
+    int w = t->lw[l], h = t->lh[l];
+    float uu = s * (float)w - 0.5f, vv = tt * (float)h - 0.5f;
+    float fu = floorf(uu), fv = floorf(vv);
+    float a = uu - fu, b = vv - fv;
+    int i0 = imod((int)fu, w), i1 = imod((int)fu + 1, w), j0 = imod((int)fv, h), j1 = imod((int)fv + 1, h);
+    float t00[3], t10[3], t01[3], t11[3];
+    fetch_texel(t, l, i0, j0, t00); fetch_texel(t, l, i1, j0, t10); fetch_texel(t, l, i0, j1, t01); fetch_texel(t, l, i1, j1, t11);
+    for (int k = 0; k < 3; k++) {
+        float top = t00[k] * (1.0f - a) + t10[k] * a, bot = t01[k] * (1.0f - a) + t11[k] * a;
+        rgb[k] = top * (1.0f - b) + bot * b;
+    }
+}
+
+/* s,t: texture coordinates at the pixel centre; (sx,tx),(sy,ty): at the +1 pixel neighbours */
+static void sample_texture(int tex_id, float s, float t, float sx, float tx, float sy, float ty, int valid, float *rgb) {
+    const Tex *T = &g_tex[tex_id];
+    if (!T->data) { rgb[0] = rgb[1] = rgb[2] = 255.0f; return; }
+    float lambda;
+    if (!valid) lambda = (float)(T->n_levels - 1);
+    else {
+        float dsdx = (sx - s) * (float)T->w, dtdx = (tx - t) * (float)T->h;
+        float dsdy = (sy - s) * (float)T->w, dtdy = (ty - t) * (float)T->h;
+        float r1 = dsdx * dsdx + dtdx * dtdx, r2 = dsdy * dsdy + dtdy * dtdy;
+        float rho2 = r1 > r2 ? r1 : r2;
+        if (!(rho2 < INFINITY)) lambda = (float)(T->n_levels - 1);
+        else if (rho2 <= 1.0f) lambda = 0.0f;
+        else lambda = 0.5f * log2f(rho2);
+    }
+    float ws = s - floorf(s), wt = t - floorf(t); /* REPEAT */
+    int maxl = T->n_levels - 1;
+    if (lambda <= 0.0f) { bilinear(T, 0, ws, wt, rgb); return; }
+    float fl = floorf(lambda);
+    int l0 = (int)fl; if (l0 > maxl) l0 = maxl;
+    int l1 = l0 + 1 > maxl ? maxl : l0 + 1;
+    float fr = l0 == maxl ? 0.0f : lambda - fl;
+    float c0[3], c1[3];
+    bilinear(T, l0, ws, wt, c0);
+    if (l1 == l0 || fr == 0.0f) { rgb[0] = c0[0]; rgb[1] = c0[1]; rgb[2] = c0[2]; return; }
+    bilinear(T, l1, ws, wt, c1);
+    for (int k = 0; k < 3; k++) rgb[k] = c0[k] * (1.0f - fr) + c1[k] * fr;
+}
+
+typedef struct {
+    float light_dir[3], amb[3], diff[3], sky[3];
+    float box_color[3];
+} Light;
+
+static void lit_color(const Light *L, const float *n, const float *C, float *out) {
+    float ndl = n[0] * L->light_dir[0] + n[1] * L->light_dir[1] + n[2] * L->light_dir[2];
+    if (ndl < 0) ndl = 0;
+    for (int k = 0; k < 3; k++) {
+        float v = (0.2f * C[k] + L->amb[k] * C[k]) + ndl * L->diff[k] * C[k];
+        out[k] = v > 1.0f ? 1.0f : v;
+    }
+}
+
+/* texture coordinates of the surface `h` where ray (o,d) meets the surface's plane; 0 if behind */
+static int surf_texcoord(const RRoom *rr, const Hit *h, const float *o, const float *d, float *s, float *t) {
+    const RRoom *r = &rr[h->room];
+    float tt;
+    if (h->kind == 1 || h->kind == 2) {
+        float py = h->kind == 1 ? 0.0f : r->height;
+        if (d[1] == 0) return 0;
+        tt = (py - o[1]) / d[1];
+        if (!(tt > 0)) return 0;
+        int tex = h->kind == 1 ? r->floor_tex : r->ceil_tex;
+        float sc_s = (float)(512.0 / tex_width(tex)), sc_t = (float)(512.0 / tex_height(tex));
+        *s = (o[0] + tt * d[0]) * sc_s; *t = (o[2] + tt * d[2]) * sc_t;
+        return 1;
+    }
+    int sd = h->side;
+    float sc_s = (float)(512.0 / tex_width(r->wall_tex)), sc_t = (float)(512.0 / tex_height(r->wall_tex));
+    float plane, od, oo; int along;
+    if (sd == 0 || sd == 2) { plane = sd == 0 ? r->max_x : r->min_x; od = d[0]; oo = o[0]; along = 2; }
+    else { plane = sd == 3 ? r->max_z : r->min_z; od = d[2]; oo = o[2]; along = 0; }
+    if (od == 0) return 0;
+    tt = (plane - oo) / od;
+    if (!(tt > 0)) return 0;
+    float hc = o[along] + tt * d[along], y = o[1] + tt * d[1];
+    *s = ((hc - r->side[sd].u_org) * r->side[sd].u_sgn) * sc_s; *t = y * sc_t;
+    return 1;
+}
+
+void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
+    static RRoom rr[MWO_MAX_ROOMS];
+    int n_rooms = build_rrooms(e, rr);
+    /* camera: gluPerspective(fov_y, W/H, 0.04, 100), gluLookAt(cam_pos, cam_pos+cam_dir, +Y) */
+    double cp[3], cd[3];
+    camera(e, cp, cd);
+    double fl = sqrt(cd[0] * cd[0] + cd[1] * cd[1] + cd[2] * cd[2]);
+    double f[3] = {cd[0] / fl, cd[1] / fl, cd[2] / fl};
+    double sl = sqrt(f[2] * f[2] + f[0] * f[0]);
+    double s[3] = {-f[2] / sl, 0, f[0] / sl};
+    double u[3] = {s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0]};
+    double th = tan(e->cam_fov_y * M_PI / 180 / 2);
+    Cam c;
+    for (int k = 0; k < 3; k++) { c.eye[k] = (float)cp[k]; c.F[k] = (float)f[k]; c.S[k] = (float)s[k]; c.U[k] = (float)u[k]; }
+    c.TH = (float)th; c.TW = (float)(th * ((double)W / (double)H));
+    c.W = W; c.H = H; c.invW = 1.0f / (float)W; c.invH = 1.0f / (float)H;
+    /* light: GL_POSITION = (light_pos + 1, w = 0) -> directional (miniworld.py:1026) */
+    Light L;
+    double lp[3] = {e->light_pos[0] + 1, e->light_pos[1] + 1, e->light_pos[2] + 1};
+    double ll = sqrt(lp[0] * lp[0] + lp[1] * lp[1] + lp[2] * lp[2]);
+    for (int k = 0; k < 3; k++) {
+        L.light_dir[k] = (float)(lp[k] / ll); L.amb[k] = (float)e->light_ambient[k]; L.diff[k] = (float)e->light_color[k];
+        L.sky[k] = (float)e->sky_color[k]; L.box_color[k] = (float)e->box_color[k];
+    }
+    const float white[3] = {1, 1, 1};
+    float lit_floor[3], lit_ceil[3], lit_wall[4][3], lit_box[6][3];
+    { float n[3] = {0, 1, 0}; lit_color(&L, n, white, lit_floor); }
+    { float n[3] = {0, -1, 0}; lit_color(&L, n, white, lit_ceil); }
+    { static const float wn[4][3] = {{-1, 0, 0}, {0, 0, 1}, {1, 0, 0}, {0, 0, -1}};
+      for (int k = 0; k < 4; k++) lit_color(&L, wn[k], white, lit_wall[k]); }
+    RBox bx;
+    for (int k = 0; k < 3; k++) bx.pos[k] = (float)e->box.pos[k];
+    bx.c = (float)cos(e->box.dir); bx.s = (float)sin(e->box.dir);
+    bx.half[0] = (float)(e->box_size[0] / 2); bx.half[2] = (float)(e->box_size[2] / 2); bx.half[1] = 0; bx.sy = (float)e->box_size[1];
+    { /* world normal of local normal n: R_y(dir) n = (nx c + nz s, ny, -nx s + nz c) */
+      static const float ln[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+      for (int k = 0; k < 6; k++) {
+          float n[3] = {ln[k][0] * bx.c + ln[k][2] * bx.s, ln[k][1], -ln[k][0] * bx.s + ln[k][2] * bx.c};
+          lit_color(&L, n, L.box_color, lit_box[k]);
+      } }
+    /* room containing the eye */
+    int cam_room = -1;
+    for (int i = 0; i < n_rooms && cam_room < 0; i++)
+        if (c.eye[0] >= rr[i].min_x && c.eye[0] <= rr[i].max_x && c.eye[2] >= rr[i].min_z && c.eye[2] <= rr[i].max_z) cam_room = i;
+    const float n_ = 0.04f, f_ = 100.0f;
+    const float zA = (f_ + n_) / (f_ - n_), zB = (2.0f * f_ * n_) / (f_ - n_);
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
+            Hit hits[8];
+            for (int k = 0; k < 8; k++) {
+                float d[3];
+                make_ray(&c, cx + SAMPLE_X[k] * 0.0625f, cy + SAMPLE_Y[k] * 0.0625f, d);
+                hits[k] = trace_rooms(rr, n_rooms, cam_room, c.eye, d);
+                float tb; int fc = trace_box(&bx, c.eye, d, &tb);
+                if (fc >= 0 && tb < hits[k].t) { hits[k].kind = 4; hits[k].t = tb; hits[k].room = -1; hits[k].side = fc; }
+            }
+            float dc[3], dx[3], dy[3];
+            make_ray(&c, cx, cy, dc); make_ray(&c, cx + 1.0f, cy, dx); make_ray(&c, cx, cy + 1.0f, dy);
+            float acc[3] = {0, 0, 0};
+            int done_mask = 0;
+            for (int k = 0; k < 8; k++) {
+                if (done_mask & (1 << k)) continue;
+                int cnt = 0;
+                for (int j = k; j < 8; j++)
+                    if (!(done_mask & (1 << j)) && hits[j].kind == hits[k].kind && hits[j].room == hits[k].room && hits[j].side == hits[k].side) { cnt++; done_mask |= 1 << j; }
+                float col[3];
+                const Hit *h = &hits[k];
+                if (h->kind == 0) { col[0] = L.sky[0]; col[1] = L.sky[1]; col[2] = L.sky[2]; }
+                else if (h->kind == 4) { col[0] = lit_box[h->side][0]; col[1] = lit_box[h->side][1]; col[2] = lit_box[h->side][2]; }
+                else {
+                    float s0, t0, s1, t1, s2, t2;
+                    int tex = h->kind == 1 ? rr[h->room].floor_tex : h->kind == 2 ? rr[h->room].ceil_tex : rr[h->room].wall_tex;
+                    const float *lit = h->kind == 1 ? lit_floor : h->kind == 2 ? lit_ceil : lit_wall[h->side];
+                    int okc = surf_texcoord(rr, h, c.eye, dc, &s0, &t0);
+                    int valid = 1;
+                    if (!okc) { /* centre ray misses the plane: shade at the sample's own hit point */
+                        float d[3]; make_ray(&c, cx + SAMPLE_X[k] * 0.0625f, cy + SAMPLE_Y[k] * 0.0625f, d);
+                        surf_texcoord(rr, h, c.eye, d, &s0, &t0); valid = 0; s1 = s2 = s0; t1 = t2 = t0;
+                    } else {
+                        valid = surf_texcoord(rr, h, c.eye, dx, &s1, &t1) && surf_texcoord(rr, h, c.eye, dy, &s2, &t2);
+                    }
+                    float texel[3];
+                    sample_texture(tex, s0, t0, s1, t1, s2, t2, valid, texel);
+                    for (int q = 0; q < 3; q++) col[q] = lit[q] * (texel[q] * (1.0f / 255.0f));
+                }
+                for (int q = 0; q < 3; q++) acc[q] += (float)cnt * col[q];
+            }
+            for (int q = 0; q < 3; q++) {
+                float v = acc[q] * 0.125f;
+                v = v < 0 ? 0 : (v > 1 ? 1 : v);
+                rgb[(py * W + px) * 3 + q] = (uint8_t)(int)floorf(v * 255.0f + 0.5f);
+            }
+            if (depth) {
+                int z16 = 65535;
+                if (hits[0].kind != 0) {
+                    float zn = zA - zB / hits[0].t;
+                    float dd = 0.5f * zn + 0.5f;
+                    int z = (int)floorf(dd * 65535.0f + 0.5f);
+                    z16 = z < 0 ? 0 : (z > 65535 ? 65535 : z);
+                }
+                /* get_depth_map, opengl.py:362-367, float32 arithmetic */
+                float dm = (float)z16 / 65535.0f;
+                float clip_z = (dm - 0.5f) * 2.0f;
+                float wz = (float)(-2.0 * 100.0 * 0.04) / (clip_z * (float)(100.0 - 0.04) - (float)(100.0 + 0.04));
+                depth[py * W + px] = wz;
+            }
+        }
+}
+
+/* ====================================================================== bench helper */
+static uint64_t splitmix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+double mwo_bench_loop(MwoEnv *e, int n_steps, uint64_t action_seed, uint64_t env_index, int W, int H, int want_depth, int constant_action) {
+    uint8_t *rgb = malloc((size_t)W * H * 3);
+    float *dep = want_depth ? malloc(sizeof(float) * W * H) : NULL;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < n_steps; t++) {
+        int a = constant_action >= 0 ? constant_action
+                                     : (int)(splitmix(action_seed ^ splitmix((uint64_t)t * 0x100000001B3ull + env_index)) % 3);
+        double r; int d;
+        mwo_step(e, a, &r, &d);
+        if (d) mwo_reset(e);
+        mwo_render(e, W, H, rgb, dep);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(rgb); free(dep);
+    return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}

@@ -1,0 +1,96 @@
+/* mw_oracle.h - CPU restatement ("oracle") of the gym-miniworld step + render_obs hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is imported, linked or executed by the
+ * product (gym_miniworld_amd/); only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / the timed CPU baseline.
+ *
+ * Parity status:
+ *   - state half (RNG stream, world generation, placement, step, collision, reward/done,
+ *     camera vectors): PINNED bit-exactly against vectors produced by the unmodified
+ *     reference (tests/golden/state_*.npz, math_kat.npz; generator committed beside them).
+ *   - seed -> MT19937 key (un-vendored `gym` <= 0.21, gym/utils/seeding.py, recalled):
+ *     PARITY UNPINNED (no gym in the build container); isolated on the Python side.
+ *   - pixel half (render_obs / render_depth): PARITY UNPINNED against the real OpenGL
+ *     driver - no GL exists in this pipeline.  The renderer below is a frozen written
+ *     specification of the fixed-function pipeline as the reference configures it
+ *     (DESIGN.md "render spec"); its *inputs* (polygons, texcoords, normals, light, camera)
+ *     are pinned against the reference's captured GL call stream (tests/golden/glstream_*.json).
+ */
+#ifndef MW_ORACLE_H
+#define MW_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MWO_HALLWAY = 0, MWO_ONEROOM = 1, MWO_FOURROOMS = 2, MWO_MAZE = 3 };
+
+/* domain parameters, reference params.py:110-123, same order */
+enum {
+    MWO_P_SKY_COLOR = 0, MWO_P_LIGHT_POS, MWO_P_LIGHT_COLOR, MWO_P_LIGHT_AMBIENT, MWO_P_OBJ_COLOR_BIAS,
+    MWO_P_FORWARD_STEP, MWO_P_FORWARD_DRIFT, MWO_P_TURN_STEP, MWO_P_BOT_RADIUS, MWO_P_CAM_PITCH,
+    MWO_P_CAM_FOV_Y, MWO_P_CAM_HEIGHT, MWO_P_CAM_FWD_DISP, MWO_NPARAM
+};
+
+#define MWO_MAX_ROOMS 512
+#define MWO_MAX_PORTALS 2 /* per edge */
+#define MWO_MAX_TEX 16
+#define MWO_MAX_LEVELS 12
+
+typedef struct MwoEnv MwoEnv;
+
+/* textures: global table shared by all envs; data = RGBA8 rows bottom-up (GL convention),
+ * level l at data + level_off[l], dims max(1, w>>l) (floor halving) */
+int mwo_set_texture(int tex_id, int width, int height, int n_levels, const uint8_t *rgba_all_levels);
+
+/* task_args: Hallway {length}, OneRoom {size}, FourRooms {}, Maze {num_rows, num_cols, room_size}.
+ * params: MWO_NPARAM x 9 doubles (default[3], min[3], max[3]); NULL = reference defaults. */
+MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int domain_rand,
+                   const double *params);
+void mwo_destroy(MwoEnv *e);
+
+void mwo_seed_key(MwoEnv *e, const uint32_t *key, int key_len); /* RandomState.seed(list) */
+void mwo_reset(MwoEnv *e);
+void mwo_step(MwoEnv *e, int action, double *reward, int *done); /* no auto-reset */
+
+/* state access */
+typedef struct {
+    double agent_pos[3], agent_dir;
+    double box_pos[3], box_dir, box_color[3];
+    double cam_height, cam_fwd_disp, cam_pitch, cam_fov_y;
+    double sky_color[3], light_pos[3], light_color[3], light_ambient[3];
+    double cam_pos[3], cam_dir[3];
+    int step_count, max_episode_steps, n_rooms, n_segs, n_quads;
+    int rng_pos;
+    uint32_t rng_key0, rng_key1, rng_key623, rng_keysum;
+} MwoState;
+void mwo_get_state(MwoEnv *e, MwoState *out);
+void mwo_set_agent(MwoEnv *e, double x, double z, double dir); /* test hook */
+void mwo_set_step_count(MwoEnv *e, int step_count);
+/* geometry dumps (sizes from MwoState): outline R*4*2, heights R, portals R*4*MAXP*4 (nan pad),
+ * portal_count R*4, segs S*4 (a.x a.z b.x b.z), room_probs R, quad verts Q*4*3, norms Q*4*3,
+ * texcs Q*4*2 (float), quad_offsets R+1, floor_texcs R*4*2, ceil_texcs R*4*2, tex ids R*3 */
+void mwo_get_geometry(MwoEnv *e, double *outline, double *heights, double *portals, int *portal_count,
+                      double *segs, double *room_probs, double *quad_verts, double *quad_norms,
+                      float *quad_texcs, int *quad_offsets, double *floor_texcs, double *ceil_texcs,
+                      int *tex_ids);
+int mwo_intersect(MwoEnv *e, int ent /*0=box,1=agent*/, double x, double z, double radius);
+
+/* render the agent's view (reference render_obs / render_depth); rgb: H*W*3 row 0 = top,
+ * depth: H*W float metres or NULL */
+void mwo_render(MwoEnv *e, int width, int height, uint8_t *rgb, float *depth);
+
+/* stand-alone pieces with reference known-answer vectors */
+int mwo_intersect_circle_segs(const double *pt3, double radius, const double *segs /*n*2*3*/, int n);
+void mwo_gen_rot_matrix(const double *axis3, double angle, double *out9);
+
+/* timed loop for bench.py's cpu_baseline: n_steps of step(+auto reset)+render with the
+ * counter-based action stream; returns wall seconds */
+double mwo_bench_loop(MwoEnv *e, int n_steps, uint64_t action_seed, uint64_t env_index, int width,
+                      int height, int want_depth, int constant_action /* -1 = random */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the UNMODIFIED reference
+(/root/reference, read-only) in the build container.  `gym` and `pyglet` are absent here, so
+they are replaced by the inert stand-ins of _inert_deps.py: every OpenGL entry point records
+its arguments and computes nothing.  Consequently these fixtures pin the reference's *state*
+arithmetic (geometry, RNG draw order, placement, trajectories, rewards, dones, camera vectors)
+and the exact *inputs* it hands to OpenGL (vertex / texcoord / normal / colour / light / camera
+streams).  They do NOT contain reference pixels - none can be produced here.
+
+Run:  python tests/golden/gen_fixtures.py          (only in the container that has /root/reference)
+Outputs: state_<task>.npz, glstream_<task>.json, math_kat.npz  (data only, no reference text).
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _inert_deps as deps  # noqa: E402
+
+deps.install("/root/reference")
+
+import gym_miniworld  # noqa: E402,F401
+from gym_miniworld.envs import FourRooms, Hallway, Maze, OneRoom  # noqa: E402
+from gym_miniworld.opengl import Texture  # noqa: E402
+from gym_miniworld import math as ref_math  # noqa: E402
+
+# name -> (reference class, constructor kwargs).  MazeS3 / OneRoomS6 / Hallway6 exercise the
+# constructor parameters the reference exposes (maze.py:14-21, oneroom.py:14, hallway.py:13).
+TASKS = {
+    "Hallway": (Hallway, {}), "OneRoom": (OneRoom, {}), "FourRooms": (FourRooms, {}), "Maze": (Maze, {}),
+    "MazeS3": (Maze, {"num_rows": 3, "num_cols": 3}),
+    "MazeR2C4": (Maze, {"num_rows": 2, "num_cols": 4, "room_size": 2.5, "max_episode_steps": 200}),
+    "OneRoomS6": (OneRoom, {"size": 6, "max_episode_steps": 100}),
+    "Hallway6": (Hallway, {"length": 6}),
+}
+
+# (seed, domain_rand, policy, n_steps)
+PLAN = {
+    "Hallway": [(0, 0, "random", 600), (1, 0, "greedy", 200), (2, 1, "random", 600), (3, 1, "greedy", 200),
+                (7, 0, "forward", 300)],
+    "OneRoom": [(0, 0, "random", 500), (1, 0, "greedy", 300), (2, 1, "random", 500), (3, 1, "greedy", 300),
+                (7, 0, "forward", 400), (4097, 1, "random", 200)],
+    "FourRooms": [(0, 0, "random", 600), (1, 0, "greedy", 400), (2, 1, "random", 600), (3, 1, "greedy", 400),
+                  (7, 1, "forward", 300)],
+    "Maze": [(0, 0, "random", 1700), (1, 0, "greedy", 300), (2, 1, "random", 400), (3, 1, "forward", 300),
+             (65535, 0, "random", 100)],
+    "MazeS3": [(0, 0, "greedy", 500), (1, 1, "greedy", 500), (2, 0, "forward", 500), (3, 1, "random", 300)],
+    "MazeR2C4": [(0, 0, "greedy", 450), (1, 1, "forward", 450)],
+    "OneRoomS6": [(0, 0, "random", 250), (1, 1, "greedy", 150)],
+    "Hallway6": [(0, 0, "random", 300), (1, 1, "greedy", 100)],
+}
+
+
+def tex_basename(tex):
+    for path, t in Texture.tex_cache.items():
+        if t is tex:
+            return os.path.splitext(os.path.basename(path))[0]
+    raise KeyError
+
+
+def rng_fingerprint(env):
+    st = env.rand.np_random.get_state()
+    key = st[1]
+    return np.array([st[2], int(key[0]), int(key[1]), int(key[623]), int(key.astype(np.uint64).sum() & 0xFFFFFFFF)],
+                    dtype=np.int64)
+
+
+def snapshot_world(env):
+    R = len(env.rooms)
+    outline = np.stack([np.stack([r.outline[:, 0], r.outline[:, 2]], axis=1) for r in env.rooms])  # R,4,2
+    heights = np.array([r.wall_height for r in env.rooms])
+    pmax = max(1, max(len(p) for r in env.rooms for p in r.portals))
+    portals = np.full((R, 4, pmax, 4), np.nan)
+    pcount = np.zeros((R, 4), dtype=np.int32)
+    for i, r in enumerate(env.rooms):
+        for e in range(4):
+            pcount[i, e] = len(r.portals[e])
+            for k, p in enumerate(r.portals[e]):
+                portals[i, e, k] = [p["start_pos"], p["end_pos"], p["min_y"], p["max_y"]]
+    segs = np.asarray(env.wall_segs)
+    d = {
+        "outline": outline, "wall_height": heights, "portals": portals, "portal_count": pcount,
+        "wall_segs": np.concatenate([segs[:, 0, [0, 2]], segs[:, 1, [0, 2]]], axis=1),
+        "segs_y_all_zero": np.array(bool(np.all(segs[:, :, 1] == 0))),
+        "room_probs": np.asarray(env.room_probs),
+        "quad_offsets": np.cumsum([0] + [r.wall_verts.shape[0] // 4 for r in env.rooms]).astype(np.int32),
+        "wall_verts": np.concatenate([r.wall_verts for r in env.rooms]),
+        "wall_norms": np.concatenate([r.wall_norms for r in env.rooms]),
+        "wall_texcs": np.concatenate([r.wall_texcs for r in env.rooms]).astype(np.float32),
+        "floor_texcs": np.stack([r.floor_texcs for r in env.rooms]),
+        "ceil_texcs": np.stack([r.ceil_texcs for r in env.rooms]),
+        "tex_names": np.array([[tex_basename(r.wall_tex), tex_basename(r.floor_tex), tex_basename(r.ceil_tex)]
+                               for r in env.rooms]),
+        "tex_width": np.array([[r.wall_tex.width, r.floor_tex.width, r.ceil_tex.width] for r in env.rooms],
+                              dtype=np.int32),
+    }
+    d.update(snapshot_entities(env))
+    return d
+
+
+def snapshot_entities(env):
+    a = env.agent
+    return {
+        "box_pos": np.array(env.box.pos, dtype=float), "box_dir": np.array(float(env.box.dir)),
+        "box_color": np.array(env.box.color_vec, dtype=float),
+        "agent_pos": np.array(a.pos, dtype=float), "agent_dir": np.array(float(a.dir)),
+        "cam": np.array([a.cam_height, a.cam_fwd_disp, a.cam_pitch, a.cam_fov_y], dtype=float),
+        "sky_color": np.array(env.sky_color, dtype=float), "light_pos": np.array(env.light_pos, dtype=float),
+        "light_color": np.array(env.light_color, dtype=float),
+        "light_ambient": np.array(env.light_ambient, dtype=float),
+        "rng": rng_fingerprint(env),
+    }
+
+
+def choose_action(env, policy, arng):
+    if policy == "random":
+        return int(arng.integers(0, 3))
+    if policy == "forward":
+        return 2 if arng.random() < 0.9 else int(arng.integers(0, 2))
+    # greedy: turn toward the box, then walk
+    a, b = env.agent, env.box
+    want = math.atan2(-(b.pos[2] - a.pos[2]), b.pos[0] - a.pos[0])
+    diff = (want - a.dir + math.pi) % (2 * math.pi) - math.pi
+    if abs(diff) > math.radians(10):
+        return 0 if diff > 0 else 1
+    return 2
+
+
+def run_case(cls, kwargs, seed, dr, policy, n_steps):
+    env = cls(domain_rand=bool(dr), **kwargs)
+    env.seed(seed)
+    env.reset()
+    out = {"reset0/" + k: v for k, v in snapshot_world(env).items()}
+    arng = np.random.default_rng(1000 + seed)
+    actions = np.zeros(n_steps, dtype=np.int32)
+    pos = np.zeros((n_steps, 2))
+    dirs = np.zeros(n_steps)
+    rew = np.zeros(n_steps)
+    done = np.zeros(n_steps, dtype=np.uint8)
+    stepc = np.zeros(n_steps, dtype=np.int32)
+    rngpos = np.zeros((n_steps, 5), dtype=np.int64)
+    campos = np.zeros((n_steps, 3))
+    camdir = np.zeros((n_steps, 3))
+    # state after the worker's auto-reset (subproc_vec_env.py worker: `if done: ob = env.reset()`)
+    post = {k: [] for k in ("step", "agent_pos", "agent_dir", "box_pos", "box_dir", "box_color", "cam",
+                            "sky_color", "light_pos", "light_color", "light_ambient", "rng", "n_rooms",
+                            "segs_sum")}
+    for t in range(n_steps):
+        a = choose_action(env, policy, arng)
+        actions[t] = a
+        _, r, d, _ = env.step(a)
+        pos[t] = env.agent.pos[[0, 2]]
+        dirs[t] = env.agent.dir
+        rew[t] = r
+        done[t] = d
+        stepc[t] = env.step_count
+        rngpos[t] = rng_fingerprint(env)
+        campos[t] = env.agent.cam_pos
+        camdir[t] = env.agent.cam_dir
+        if d:
+            env.reset()
+            s = snapshot_entities(env)
+            post["step"].append(t)
+            for k in s:
+                post[k].append(s[k])
+            post["n_rooms"].append(len(env.rooms))
+            post["segs_sum"].append(float(np.sum(env.wall_segs)))
+    out.update({"traj/actions": actions, "traj/pos": pos, "traj/dir": dirs, "traj/reward": rew,
+                "traj/done": done, "traj/step_count": stepc, "traj/rng": rngpos,
+                "traj/cam_pos": campos, "traj/cam_dir": camdir})
+    for k, v in post.items():
+        out["post/" + k] = np.array(v) if len(v) else np.zeros((0,))
+    out["final/outline"] = snapshot_world(env)["outline"]
+    out["meta/max_episode_steps"] = np.array(env.max_episode_steps)
+    out["meta/max_forward_step"] = np.array(env.max_forward_step)
+    return out
+
+
+def capture_gl(cls, kwargs, seed, dr):
+    """One reset() under the call recorder -> structured polygon list (renderer *input* parity)."""
+    env = cls(domain_rand=bool(dr), **kwargs)
+    env.seed(seed)
+    deps.GL_LOG.clear()
+    deps.GL_LOG_ENABLED[0] = True
+    env.reset()
+    deps.GL_LOG_ENABLED[0] = False
+    log = list(deps.GL_LOG)
+    deps.GL_LOG.clear()
+    polys, lights, misc = [], {}, {}
+    cur = {"color": None, "normal": None, "texc": None, "tex_on": False, "mode": None, "xform": []}
+    poly = None
+    gl = sys.modules["pyglet.gl"]
+    names = {getattr(gl, n): n for n in dir(gl) if n.startswith("GL_")}
+    for name, args in log:
+        if name == "glLightfv":
+            lights[names[args[1]]] = list(args[2])
+        elif name == "glEnable" and names.get(args[0]) == "GL_TEXTURE_2D":
+            cur["tex_on"] = True
+        elif name == "glDisable" and names.get(args[0]) == "GL_TEXTURE_2D":
+            cur["tex_on"] = False
+        elif name == "glColor3f":
+            cur["color"] = [float(x) for x in args]
+        elif name == "glNormal3f":
+            cur["normal"] = [float(x) for x in args]
+        elif name == "glTexCoord2f":
+            cur["texc"] = [float(x) for x in args]
+        elif name == "glTranslatef":
+            cur["xform"].append(["translate"] + [float(x) for x in args])
+        elif name == "glRotatef":
+            cur["xform"].append(["rotate"] + [float(x) for x in args])
+        elif name == "glPushMatrix":
+            cur["xform"] = []
+        elif name == "glPopMatrix":
+            cur["xform"] = []
+        elif name == "glBegin":
+            poly = {"mode": names[args[0]], "color": cur["color"], "tex_on": cur["tex_on"],
+                    "xform": list(cur["xform"]), "verts": [], "texcs": [], "norms": []}
+        elif name == "glVertex3f":
+            poly["verts"].append([float(x) for x in args])
+            poly["texcs"].append(cur["texc"])
+            poly["norms"].append(cur["normal"])
+        elif name == "glEnd":
+            polys.append(poly)
+            poly = None
+        elif name in ("gluPerspective", "gluLookAt", "glClearColor", "glClearDepth"):
+            misc[name] = [float(x) for x in args]
+    ents = snapshot_entities(env)
+    return {
+        "task": cls.__name__, "kwargs": kwargs, "seed": seed, "domain_rand": int(dr),
+        "lights": lights, "misc": misc, "polys": polys,
+        "room_tex": [[tex_basename(r.wall_tex), tex_basename(r.floor_tex), tex_basename(r.ceil_tex)]
+                     for r in env.rooms],
+        "agent_pos": ents["agent_pos"].tolist(), "agent_dir": float(ents["agent_dir"]),
+        "box_pos": ents["box_pos"].tolist(), "box_dir": float(ents["box_dir"]),
+        "box_color": ents["box_color"].tolist(), "cam": ents["cam"].tolist(),
+    }
+
+
+def math_kat():
+    """Known-answer vectors for the two importable numpy-only reference modules (math.py)."""
+    rng = np.random.default_rng(7)
+    n = 256
+    segs = rng.uniform(-5, 5, size=(n, 16, 2, 3))
+    segs[:, :, :, 1] = 0
+    pts = rng.uniform(-5, 5, size=(n, 3))
+    rad = rng.uniform(0.05, 1.5, size=n)
+    hit = np.array([bool(ref_math.intersect_circle_segs(pts[i], rad[i], segs[i])) for i in range(n)])
+    ang = rng.uniform(-7, 7, size=n)
+    axes = np.array([ref_math.Y_VEC, ref_math.Z_VEC, ref_math.X_VEC])
+    rots = np.stack([[ref_math.gen_rot_matrix(ax, a) for ax in axes] for a in ang])
+    return {"segs": segs, "pts": pts, "rad": rad, "hit": hit, "ang": ang, "rots": rots}
+
+
+def main():
+    for task, (cls, kwargs) in TASKS.items():
+        blob = {}
+        for (seed, dr, policy, n) in PLAN[task]:
+            case = run_case(cls, kwargs, seed, dr, policy, n)
+            tag = "s%d_dr%d_%s/" % (seed, dr, policy)
+            for k, v in case.items():
+                blob[tag + k] = v
+            print(task, tag, "dones:", int(case["traj/done"].sum()),
+                  "rewards>0:", int((case["traj/reward"] > 0).sum()))
+        np.savez_compressed(os.path.join(HERE, "state_%s.npz" % task), **blob)
+        for dr in (0, 1):
+            if task.startswith("Maze") and (dr == 1) != (task == "MazeS3"):
+                continue
+            if task in ("MazeR2C4", "OneRoomS6", "Hallway6"):
+                continue
+            g = capture_gl(cls, kwargs, 1, dr)
+            with open(os.path.join(HERE, "glstream_%s_dr%d.json" % (task, dr)), "w") as fh:
+                json.dump(g, fh, separators=(",", ":"))
+    np.savez_compressed(os.path.join(HERE, "math_kat.npz"), **math_kat())
+    # the assumed gym seed hashing, exposed as data so the product/oracle can be checked without gym
+    seeds = [0, 1, 2, 3, 7, 42, 4097, 65535, 2**32 + 5, 2**63 + 11]
+    with open(os.path.join(HERE, "seed_keys.json"), "w") as fh:
+        json.dump({str(s): deps.seed_to_mt_key(s) for s in seeds}, fh)
+
+
+if __name__ == "__main__":
+    main()
