@@ -1,0 +1,92 @@
+"""ctypes binding of the C ABI in include/miniworld_batch.h (libmwbatch.so, built in-tree by
+`python -m gym_miniworld_amd.build` / __graft_entry__.build()).
+
+There is deliberately no fallback: if the HIP library is missing or no GPU is present, loading or
+mwb_create fails loudly.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmwbatch.so")
+
+NPARAM = 13
+ROOM_WORDS = 40
+ABI_VERSION = 1
+
+TASK_IDS = {"Hallway": 0, "OneRoom": 1, "FourRooms": 2, "Maze": 3}
+LAYOUT_HWC, LAYOUT_CWH = 0, 1
+
+
+class MwbConfig(ctypes.Structure):
+    _fields_ = [
+        ("abi_version", ctypes.c_int32), ("task", ctypes.c_int32), ("num_envs", ctypes.c_int32),
+        ("obs_width", ctypes.c_int32), ("obs_height", ctypes.c_int32), ("want_depth", ctypes.c_int32),
+        ("layout", ctypes.c_int32), ("domain_rand", ctypes.c_int32), ("max_episode_steps", ctypes.c_int32),
+        ("device", ctypes.c_int32), ("task_args", ctypes.c_double * 4),
+        ("use_default_params", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("params", (ctypes.c_double * 9) * NPARAM),
+    ]
+
+
+class MwbOutputs(ctypes.Structure):
+    _fields_ = [
+        ("obs", ctypes.c_void_p), ("depth", ctypes.c_void_p), ("reward", ctypes.c_void_p),
+        ("reward64", ctypes.c_void_p), ("done", ctypes.c_void_p), ("ep_steps", ctypes.c_void_p),
+        ("obs_bytes", ctypes.c_size_t), ("depth_bytes", ctypes.c_size_t),
+    ]
+
+
+class MwbState(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "agent_pos", "agent_dir", "box_pos", "box_dir", "box_color", "cam", "sky_color", "light_pos",
+        "light_color", "light_ambient", "step_count", "rng_pos", "rng_keysum", "n_rooms", "n_segs")]
+
+
+EXPORTS = [
+    "mwb_create", "mwb_destroy", "mwb_last_error", "mwb_abi_version", "mwb_set_texture", "mwb_seed", "mwb_reset",
+    "mwb_step", "mwb_render", "mwb_get_outputs", "mwb_get_state", "mwb_set_agent", "mwb_intersect",
+    "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read",
+]
+
+_lib = None
+
+
+class MwbError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmwbatch.so; raises MwbError if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MwbError("HIP extension %s is missing - run `python -m gym_miniworld_amd.build` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32 = ctypes.c_void_p, ctypes.c_int
+    L.mwb_last_error.restype = ctypes.c_char_p
+    L.mwb_create.argtypes = [ctypes.POINTER(MwbConfig), ctypes.POINTER(vp)]
+    L.mwb_destroy.argtypes = [vp]
+    L.mwb_set_texture.argtypes = [vp, i32, i32, i32, vp]
+    L.mwb_seed.argtypes = [vp, vp]
+    L.mwb_reset.argtypes = [vp, vp, vp]
+    L.mwb_step.argtypes = [vp, vp, vp, vp]
+    L.mwb_render.argtypes = [vp, vp]
+    L.mwb_get_outputs.argtypes = [vp, ctypes.POINTER(MwbOutputs)]
+    L.mwb_get_state.argtypes = [vp, i32, i32, ctypes.POINTER(MwbState)]
+    L.mwb_set_agent.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.mwb_intersect.argtypes = [vp, i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(i32)]
+    L.mwb_get_geometry.argtypes = [vp, i32, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.mwb_timing_enable.argtypes = [vp, i32]
+    L.mwb_timing_read.argtypes = [vp] + [ctypes.POINTER(ctypes.c_double)] * 4 + [ctypes.POINTER(i32)]
+    if L.mwb_abi_version() != ABI_VERSION:
+        raise MwbError("libmwbatch.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise MwbError("libmwbatch error %d: %s" % (rc, load().mwb_last_error().decode("utf8", "replace")))

@@ -1,0 +1,238 @@
+"""BatchedMiniWorld: N MiniWorld environments stepped and rendered on one MI355X.
+
+Thin host object over the C ABI (include/miniworld_batch.h).  PyTorch is used only as plumbing:
+device tensors for actions / zero-copy views of the library's output buffers, and the current HIP
+stream.  All simulation and rendering runs in the HIP kernels of csrc/.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from .params import DEFAULT_PARAMS
+
+TEX_FILES = ["floor_tiles_bw_1", "concrete_1", "concrete_2", "concrete_3", "concrete_4", "concrete_tiles_1",
+             "brick_wall_1"]
+TEX_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "textures")
+
+# registered ids of the reference (envs/__init__.py:43-49) that this package covers:
+# id -> (task, task_args, max_episode_steps or 0 for the class default, params override)
+def _fast_params(forward_step=0.7, turn_step=45):   # envs/oneroom.py:52-66, envs/maze.py:123-141
+    p = DEFAULT_PARAMS.no_random()
+    p.set("forward_step", forward_step)
+    p.set("turn_step", turn_step)
+    return p
+
+
+ENV_SPECS = {
+    "MiniWorld-Hallway-v0": ("Hallway", [12], 0, None, None),
+    "MiniWorld-OneRoom-v0": ("OneRoom", [10], 0, None, None),
+    "MiniWorld-OneRoomS6-v0": ("OneRoom", [6], 100, None, None),
+    "MiniWorld-OneRoomS6Fast-v0": ("OneRoom", [6], 50, _fast_params, False),
+    "MiniWorld-FourRooms-v0": ("FourRooms", [], 0, None, None),
+    "MiniWorld-Maze-v0": ("Maze", [8, 8, 3], 0, None, None),
+    "MiniWorld-MazeS2-v0": ("Maze", [2, 2, 3], 0, None, None),
+    "MiniWorld-MazeS3-v0": ("Maze", [3, 3, 3], 0, None, None),
+    "MiniWorld-MazeS3Fast-v0": ("Maze", [3, 3, 3], 300, _fast_params, False),
+}
+
+
+class _DevView:
+    """Exposes a library-owned device buffer through __cuda_array_interface__ (zero-copy)."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner   # keeps the handle alive while views exist
+
+
+class BatchedMiniWorld:
+    """N environments of one task on one GPU.
+
+    reset()/step() mirror VecEnv semantics of the reference's SubprocVecEnv worker
+    (vec_env/subproc_vec_env.py:5-33): env i is seeded `seed + first_env_index + i`
+    (pytorch-a2c-ppo-acktr/envs.py:36), a finished env is reset inside step() and the returned
+    observation is the first one of the new episode while reward/done are the terminal ones.
+    """
+
+    def __init__(self, env_id="MiniWorld-OneRoom-v0", num_envs=1, seed=None, domain_rand=False, obs_width=80,
+                 obs_height=60, want_depth=False, layout="HWC", device=0, max_episode_steps=None, params=None,
+                 task=None, task_args=None, first_env_index=0):
+        import torch
+        self.torch = torch
+        self.L = _lib.load()
+        if task is None:
+            if env_id not in ENV_SPECS:
+                raise KeyError("unknown or out-of-scope env id %r; supported: %s" % (env_id, sorted(ENV_SPECS)))
+            task, spec_args, spec_steps, spec_params, spec_dr = ENV_SPECS[env_id]
+            task_args = spec_args if task_args is None else task_args
+            if max_episode_steps is None:
+                max_episode_steps = spec_steps
+            if params is None and spec_params is not None:
+                params = spec_params()
+            if spec_dr is not None:
+                domain_rand = spec_dr
+        self.env_id, self.task = env_id, task
+        self.num_envs = int(num_envs)
+        self.W, self.H = int(obs_width), int(obs_height)
+        self.want_depth = bool(want_depth)
+        self.layout = layout
+        self.domain_rand = bool(domain_rand)
+        self.params = params if params is not None else DEFAULT_PARAMS
+        self.first_env_index = int(first_env_index)
+        if not torch.cuda.is_available():
+            raise _lib.MwbError("BatchedMiniWorld needs a GPU (torch.cuda.is_available() is False); no CPU path exists")
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+
+        cfg = _lib.MwbConfig()
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.task = _lib.TASK_IDS[task]
+        cfg.num_envs = self.num_envs
+        cfg.obs_width, cfg.obs_height = self.W, self.H
+        cfg.want_depth = int(self.want_depth)
+        cfg.layout = {"HWC": _lib.LAYOUT_HWC, "CWH": _lib.LAYOUT_CWH}[layout]
+        cfg.domain_rand = int(self.domain_rand)
+        cfg.max_episode_steps = int(max_episode_steps or 0)
+        cfg.device = self.device_index
+        ta = list(task_args or []) + [0, 0, 0, 0]
+        for i in range(4):
+            cfg.task_args[i] = float(ta[i])
+        cfg.use_default_params = 0
+        table = self.params.to_table()
+        for i in range(_lib.NPARAM):
+            for j in range(9):
+                cfg.params[i][j] = float(table[i, j])
+        h = ctypes.c_void_p()
+        _lib.check(self.L.mwb_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self.h = h
+        self._load_textures()
+        out = _lib.MwbOutputs()
+        _lib.check(self.L.mwb_get_outputs(self.h, ctypes.byref(out)))
+        N, W, H = self.num_envs, self.W, self.H
+        obs_shape = (N, H, W, 3) if layout == "HWC" else (N, 3, W, H)
+        as_t = lambda ptr, shape, ts: torch.as_tensor(_DevView(ptr, shape, ts, self), device=self.device)  # noqa: E731
+        self.obs = as_t(out.obs, obs_shape, "|u1")
+        self.depth = as_t(out.depth, (N, H, W, 1), "<f4") if self.want_depth else None
+        self.reward = as_t(out.reward, (N,), "<f4")
+        self.reward64 = as_t(out.reward64, (N,), "<f8")
+        self.done = as_t(out.done, (N,), "|u1")
+        self.ep_steps = as_t(out.ep_steps, (N,), "<i4")
+        self.max_episode_steps = self._max_steps(task, ta, max_episode_steps)
+        if seed is not None:
+            self.seed(seed)
+
+    @staticmethod
+    def _max_steps(task, ta, mes):
+        if mes:
+            return int(mes)
+        return {"Hallway": 250, "OneRoom": 180, "FourRooms": 250}.get(task) or int(ta[0] or 8) * int(ta[1] or 8) * 24
+
+    def _load_textures(self):
+        from PIL import Image
+        for tid, name in enumerate(TEX_FILES):
+            with Image.open(os.path.join(TEX_DIR, name + ".png")) as im:
+                img = np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
+            _lib.check(self.L.mwb_set_texture(self.h, tid, img.shape[1], img.shape[0],
+                                              img.ctypes.data_as(ctypes.c_void_p)))
+
+    # -------------------------------------------------------------------------------- lifecycle
+    def close(self):
+        if getattr(self, "h", None):
+            self.torch.cuda.synchronize(self.device)
+            self.L.mwb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------------------- simulation
+    def seed(self, seed):
+        """int -> env i gets seed + first_env_index + i (envs.py:36); or an explicit array of N seeds."""
+        if np.isscalar(seed):
+            seeds = (int(seed) + self.first_env_index + np.arange(self.num_envs, dtype=np.uint64)).astype(np.uint64)
+        else:
+            seeds = np.asarray(seed, dtype=np.uint64)
+            assert seeds.shape == (self.num_envs,)
+        seeds = np.ascontiguousarray(seeds)
+        _lib.check(self.L.mwb_seed(self.h, seeds.ctypes.data_as(ctypes.c_void_p)))
+        return [seed]
+
+    def reset(self, mask=None):
+        m = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=self.torch.uint8).contiguous()
+            m = ctypes.c_void_p(mask.data_ptr())
+        _lib.check(self.L.mwb_reset(self.h, m, self._stream()))
+        return self.obs
+
+    def step(self, actions, skip_mask=None):
+        """actions: int tensor [N] (any int dtype / device); returns views (obs, reward, done) of the
+        library-owned buffers, valid until the next call."""
+        torch = self.torch
+        a = torch.as_tensor(actions).to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+        assert a.numel() == self.num_envs
+        m = None
+        if skip_mask is not None:
+            skip_mask = torch.as_tensor(skip_mask).to(device=self.device, dtype=torch.uint8).contiguous()
+            m = ctypes.c_void_p(skip_mask.data_ptr())
+        _lib.check(self.L.mwb_step(self.h, ctypes.c_void_p(a.data_ptr()), m, self._stream()))
+        self._keep = (a, skip_mask)   # keep inputs alive until the async kernels have consumed them
+        return self.obs, self.reward, self.done
+
+    def render(self):
+        _lib.check(self.L.mwb_render(self.h, self._stream()))
+        return self.obs
+
+    # ---------------------------------------------------------------------------- introspection
+    def get_state(self, first=0, count=None):
+        count = self.num_envs - first if count is None else count
+        shapes = {"agent_pos": (count, 3), "agent_dir": (count,), "box_pos": (count, 3), "box_dir": (count,),
+                  "box_color": (count, 3), "cam": (count, 4), "sky_color": (count, 3), "light_pos": (count, 3),
+                  "light_color": (count, 3), "light_ambient": (count, 3)}
+        out = {k: np.zeros(s, np.float64) for k, s in shapes.items()}
+        out.update({"step_count": np.zeros(count, np.int32), "rng_pos": np.zeros(count, np.int32),
+                    "rng_keysum": np.zeros(count, np.uint32), "n_rooms": np.zeros(count, np.int32),
+                    "n_segs": np.zeros(count, np.int32)})
+        st = _lib.MwbState()
+        for k, v in out.items():
+            setattr(st, k, v.ctypes.data_as(ctypes.c_void_p))
+        _lib.check(self.L.mwb_get_state(self.h, first, count, ctypes.byref(st)))
+        return out
+
+    def set_agent(self, first, pos_xz=None, dir=None, step_count=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, dt) for a, dt in
+                ((pos_xz, np.float64), (dir, np.float64), (step_count, np.int32))]
+        count = next(len(a) if a.ndim else 1 for a in arrs if a is not None)
+        ptrs = [None if a is None else a.ctypes.data_as(ctypes.c_void_p) for a in arrs]
+        _lib.check(self.L.mwb_set_agent(self.h, first, count, *ptrs))
+
+    def intersect(self, env, x, z, radius=0.4):
+        r = ctypes.c_int()
+        _lib.check(self.L.mwb_intersect(self.h, env, float(x), float(z), float(radius), ctypes.byref(r)))
+        return r.value
+
+    def get_geometry(self, env, max_rooms=512, max_segs=2048):
+        rooms = np.zeros((max_rooms, _lib.ROOM_WORDS), np.float32)
+        segs = np.zeros((max_segs, 4), np.float64)
+        nr, ns = ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.L.mwb_get_geometry(self.h, env, rooms.ctypes.data_as(ctypes.c_void_p), max_rooms,
+                                           segs.ctypes.data_as(ctypes.c_void_p), max_segs, ctypes.byref(nr),
+                                           ctypes.byref(ns)))
+        return rooms[:nr.value], segs[:ns.value]
+
+    def timing_enable(self, on=True):
+        _lib.check(self.L.mwb_timing_enable(self.h, int(on)))
+
+    def timing_read(self):
+        v = [ctypes.c_double() for _ in range(4)]
+        n = ctypes.c_int()
+        _lib.check(self.L.mwb_timing_read(self.h, *[ctypes.byref(x) for x in v], ctypes.byref(n)))
+        return {"step": v[0].value, "reset": v[1].value, "prep": v[2].value, "render": v[3].value, "n": n.value}

@@ -1,0 +1,546 @@
+// mwb_api.hip - host side of the C ABI declared in include/miniworld_batch.h.
+//
+// Owns the HBM-resident state of one shard of environments, hashes seeds to MT19937 states,
+// builds the texture mip pyramids, and enqueues the step / reset / prep / render kernels on the
+// caller's stream.  No torch types, no oracle code; fails loudly (negative status + message)
+// rather than falling back to any CPU path.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "mwb_internal.h"
+
+static thread_local std::string g_err;
+static int set_err(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return set_err(MWB_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+
+struct mwb_handle {
+    mwb_config cfg;
+    MwbDev dev;
+    std::vector<void *> allocs;
+    std::vector<std::vector<uint32_t>> tex_levels[MWB_MAX_TEX];   // host mip chains (RGBA8 packed)
+    int tex_w[MWB_MAX_TEX], tex_h[MWB_MAX_TEX];
+    uint32_t *texels_dev;
+    MwbTexDesc *tex_desc_dev;
+    bool seeded, textures_dirty, have_textures;
+    int *scratch_int_dev;
+    // timing
+    // timing: five events per pipeline pass, drawn from a pool and only read back in
+    // mwb_timing_read, so that enabling it adds no host synchronisation to the timed region
+    bool timing;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used;
+    hipEvent_t *ev;   // the current pass' five events
+};
+
+extern "C" const char *mwb_last_error(void) { return g_err.c_str(); }
+extern "C" int mwb_abi_version(void) { return MWB_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------ SHA-512
+// Needed for the seed -> MT19937 key mapping of gym<=0.21 (gym/utils/seeding.py hash_seed, an
+// un-vendored dependency of reference random.py:10): key = little-endian 32-bit limbs of the first
+// 8 bytes of sha512(str(seed)).  "Parity unpinned": gym is not available to check against.
+static const uint64_t K512[80] = {
+    0x428a2f98d728ae22ULL, 0x7137449123ef65cdULL, 0xb5c0fbcfec4d3b2fULL, 0xe9b5dba58189dbbcULL, 0x3956c25bf348b538ULL,
+    0x59f111f1b605d019ULL, 0x923f82a4af194f9bULL, 0xab1c5ed5da6d8118ULL, 0xd807aa98a3030242ULL, 0x12835b0145706fbeULL,
+    0x243185be4ee4b28cULL, 0x550c7dc3d5ffb4e2ULL, 0x72be5d74f27b896fULL, 0x80deb1fe3b1696b1ULL, 0x9bdc06a725c71235ULL,
+    0xc19bf174cf692694ULL, 0xe49b69c19ef14ad2ULL, 0xefbe4786384f25e3ULL, 0x0fc19dc68b8cd5b5ULL, 0x240ca1cc77ac9c65ULL,
+    0x2de92c6f592b0275ULL, 0x4a7484aa6ea6e483ULL, 0x5cb0a9dcbd41fbd4ULL, 0x76f988da831153b5ULL, 0x983e5152ee66dfabULL,
+    0xa831c66d2db43210ULL, 0xb00327c898fb213fULL, 0xbf597fc7beef0ee4ULL, 0xc6e00bf33da88fc2ULL, 0xd5a79147930aa725ULL,
+    0x06ca6351e003826fULL, 0x142929670a0e6e70ULL, 0x27b70a8546d22ffcULL, 0x2e1b21385c26c926ULL, 0x4d2c6dfc5ac42aedULL,
+    0x53380d139d95b3dfULL, 0x650a73548baf63deULL, 0x766a0abb3c77b2a8ULL, 0x81c2c92e47edaee6ULL, 0x92722c851482353bULL,
+    0xa2bfe8a14cf10364ULL, 0xa81a664bbc423001ULL, 0xc24b8b70d0f89791ULL, 0xc76c51a30654be30ULL, 0xd192e819d6ef5218ULL,
+    0xd69906245565a910ULL, 0xf40e35855771202aULL, 0x106aa07032bbd1b8ULL, 0x19a4c116b8d2d0c8ULL, 0x1e376c085141ab53ULL,
+    0x2748774cdf8eeb99ULL, 0x34b0bcb5e19b48a8ULL, 0x391c0cb3c5c95a63ULL, 0x4ed8aa4ae3418acbULL, 0x5b9cca4f7763e373ULL,
+    0x682e6ff3d6b2b8a3ULL, 0x748f82ee5defb2fcULL, 0x78a5636f43172f60ULL, 0x84c87814a1f0ab72ULL, 0x8cc702081a6439ecULL,
+    0x90befffa23631e28ULL, 0xa4506cebde82bde9ULL, 0xbef9a3f7b2c67915ULL, 0xc67178f2e372532bULL, 0xca273eceea26619cULL,
+    0xd186b8c721c0c207ULL, 0xeada7dd6cde0eb1eULL, 0xf57d4f7fee6ed178ULL, 0x06f067aa72176fbaULL, 0x0a637dc5a2c898a6ULL,
+    0x113f9804bef90daeULL, 0x1b710b35131c471bULL, 0x28db77f523047d84ULL, 0x32caab7b40c72493ULL, 0x3c9ebe0a15c9bebcULL,
+    0x431d67c49c100d4cULL, 0x4cc5d4becb3e42b6ULL, 0x597f299cfc657e2aULL, 0x5fcb6fab3ad6faecULL, 0x6c44198c4a475817ULL};
+
+static inline uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+
+static void sha512_short(const uint8_t *msg, size_t len, uint8_t out[64]) {   // len < 112: one block
+    uint8_t blk[128];
+    memset(blk, 0, sizeof(blk));
+    memcpy(blk, msg, len);
+    blk[len] = 0x80;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) blk[127 - i] = (uint8_t)(bits >> (8 * i));
+    uint64_t Hs[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                      0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+    uint64_t w[80];
+    for (int i = 0; i < 16; i++) {
+        w[i] = 0;
+        for (int k = 0; k < 8; k++) w[i] = (w[i] << 8) | blk[i * 8 + k];
+    }
+    for (int i = 16; i < 80; i++) {
+        uint64_t s0 = rotr64(w[i - 15], 1) ^ rotr64(w[i - 15], 8) ^ (w[i - 15] >> 7);
+        uint64_t s1 = rotr64(w[i - 2], 19) ^ rotr64(w[i - 2], 61) ^ (w[i - 2] >> 6);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint64_t a = Hs[0], b = Hs[1], c = Hs[2], d = Hs[3], e = Hs[4], f = Hs[5], g = Hs[6], h = Hs[7];
+    for (int i = 0; i < 80; i++) {
+        uint64_t S1 = rotr64(e, 14) ^ rotr64(e, 18) ^ rotr64(e, 41);
+        uint64_t ch = (e & f) ^ (~e & g);
+        uint64_t t1 = h + S1 + ch + K512[i] + w[i];
+        uint64_t S0 = rotr64(a, 28) ^ rotr64(a, 34) ^ rotr64(a, 39);
+        uint64_t maj = (a & b) ^ (a & c) ^ (b & c);
+        uint64_t t2 = S0 + maj;
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    Hs[0] += a; Hs[1] += b; Hs[2] += c; Hs[3] += d; Hs[4] += e; Hs[5] += f; Hs[6] += g; Hs[7] += h;
+    for (int i = 0; i < 8; i++)
+        for (int k = 0; k < 8; k++) out[i * 8 + k] = (uint8_t)(Hs[i] >> (56 - 8 * k));
+}
+
+// seed (already reduced mod 2^64 by the uint64 type) -> MT19937 init_by_array key
+static int seed_to_key(uint64_t seed, uint32_t key[2]) {
+    char txt[32];
+    int n = snprintf(txt, sizeof(txt), "%llu", (unsigned long long)seed);
+    uint8_t dig[64];
+    sha512_short((const uint8_t *)txt, (size_t)n, dig);
+    uint32_t lo = dig[0] | (dig[1] << 8) | (dig[2] << 16) | ((uint32_t)dig[3] << 24);
+    uint32_t hi = dig[4] | (dig[5] << 8) | (dig[6] << 16) | ((uint32_t)dig[7] << 24);
+    key[0] = lo; key[1] = hi;
+    return hi != 0 ? 2 : 1;   // _int_list_from_bigint drops the high limb when it is zero ([0] for 0)
+}
+
+// numpy RandomState.seed(list) == MT19937 init_by_array
+static void mt_init_by_array(uint32_t *mt, const uint32_t *init_key, int key_length) {
+    mt[0] = 19650218u;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    int i = 1, j = 0;
+    for (int k = (624 > key_length ? 624 : key_length); k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + init_key[j] + (uint32_t)j;
+        i++; j++;
+        if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        if (j >= key_length) j = 0;
+    }
+    for (int k = 623; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        i++;
+        if (i >= 624) { mt[0] = mt[623]; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+    mt[624] = 624;   // position: the first draw regenerates the state
+}
+
+// ------------------------------------------------------------------------------------ helpers
+template <typename T>
+static int dev_alloc(mwb_handle *h, T **p, size_t n) {
+    void *q = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return set_err(MWB_ENOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    e = hipMemset(q, 0, bytes);
+    if (e != hipSuccess) return set_err(MWB_EHIP, std::string("hipMemset failed: ") + hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return MWB_OK;
+}
+
+static void default_params(double p[MWB_NPARAM][9]) {   // params.py:110-123
+    static const double T[MWB_NPARAM][9] = {
+        {0.25, 0.82, 1, 0.1, 0.1, 0.1, 1.0, 1.0, 1.0},       {0, 2.5, 0, -40, 2.5, -40, 40, 5, 40},
+        {0.7, 0.7, 0.7, 0.45, 0.45, 0.45, 0.8, 0.8, 0.8},    {0.45, 0.45, 0.45, 0.35, 0.35, 0.35, 0.55, 0.55, 0.55},
+        {0, 0, 0, -0.2, -0.2, -0.2, 0.2, 0.2, 0.2},          {0.15, 0, 0, 0.12, 0, 0, 0.17, 0, 0},
+        {0, 0, 0, -0.05, 0, 0, 0.05, 0, 0},                  {15, 0, 0, 10, 0, 0, 20, 0, 0},
+        {0.4, 0, 0, 0.38, 0, 0, 0.42, 0, 0},                 {0, 0, 0, -5, 0, 0, 5, 0, 0},
+        {60, 0, 0, 55, 0, 0, 65, 0, 0},                      {1.5, 0, 0, 1.45, 0, 0, 1.55, 0, 0},
+        {0, 0, 0, -0.05, 0, 0, 0.10, 0, 0}};
+    memcpy(p, T, sizeof(T));
+}
+
+extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
+    if (!cfg || !out) return set_err(MWB_EINVAL, "mwb_create: null argument");
+    if (cfg->abi_version != MWB_ABI_VERSION) return set_err(MWB_EINVAL, "mwb_create: abi_version mismatch");
+    if (cfg->num_envs <= 0) return set_err(MWB_EINVAL, "mwb_create: num_envs must be > 0");
+    if (cfg->task < 0 || cfg->task > MWB_TASK_MAZE) return set_err(MWB_EINVAL, "mwb_create: unknown task");
+    if (cfg->obs_width <= 0 || cfg->obs_height <= 0 || cfg->obs_width > 1024 || cfg->obs_height > 1024)
+        return set_err(MWB_EINVAL, "mwb_create: bad observation size");
+    if (cfg->layout != MWB_LAYOUT_HWC && cfg->layout != MWB_LAYOUT_CWH) return set_err(MWB_EINVAL, "mwb_create: bad layout");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_err(MWB_EHIP, "mwb_create: no HIP device available (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return set_err(MWB_EINVAL, "mwb_create: bad device ordinal");
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    mwb_handle *h = new mwb_handle();
+    h->cfg = *cfg;
+    MwbDev &d = h->dev;
+    memset(&d, 0, sizeof(d));
+    d.N = cfg->num_envs; d.task = cfg->task; d.W = cfg->obs_width; d.H = cfg->obs_height;
+    d.want_depth = cfg->want_depth ? 1 : 0; d.layout = cfg->layout; d.domain_rand = cfg->domain_rand ? 1 : 0;
+    static const double dflt[4][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}};
+    for (int i = 0; i < 4; i++) d.task_args[i] = cfg->task_args[i] != 0 ? cfg->task_args[i] : dflt[cfg->task][i];
+    int mes = cfg->max_episode_steps;
+    if (mes <= 0) {   // hallway.py:18, oneroom.py:14, fourrooms.py:15, maze.py:27
+        if (d.task == MWB_TASK_HALLWAY) mes = 250;
+        else if (d.task == MWB_TASK_ONEROOM) mes = 180;
+        else if (d.task == MWB_TASK_FOURROOMS) mes = 250;
+        else mes = (int)d.task_args[0] * (int)d.task_args[1] * 24;
+    }
+    d.max_episode_steps = mes;
+    double P[MWB_NPARAM][9];
+    if (cfg->use_default_params) default_params(P); else memcpy(P, cfg->params, sizeof(P));
+    for (int i = 0; i < MWB_NPARAM; i++)
+        for (int k = 0; k < 3; k++) { d.params[i].def[k] = P[i][k]; d.params[i].lo[k] = P[i][3 + k]; d.params[i].hi[k] = P[i][6 + k]; }
+    if (d.task == MWB_TASK_HALLWAY) { if (!(d.task_args[0] >= 2)) { delete h; return set_err(MWB_EINVAL, "Hallway: length >= 2"); } d.R_max = 1; d.S_max = 4; }
+    else if (d.task == MWB_TASK_ONEROOM) { if (!(d.task_args[0] >= 2)) { delete h; return set_err(MWB_EINVAL, "OneRoom: size >= 2"); } d.R_max = 1; d.S_max = 4; }
+    else if (d.task == MWB_TASK_FOURROOMS) { d.R_max = 8; d.S_max = 32; }
+    else {
+        int rows = (int)d.task_args[0], cols = (int)d.task_args[1];
+        if (rows < 1 || cols < 1 || rows * cols > 160) { delete h; return set_err(MWB_EINVAL, "Maze: 1 <= rows*cols <= 160"); }
+        d.R_max = 2 * rows * cols - 1; d.S_max = 4 * rows * cols;
+        if (d.S_max < 8) d.S_max = 8;
+    }
+    size_t N = (size_t)d.N;
+    int rc = MWB_OK;
+#define A(ptr, n) if (rc == MWB_OK) rc = dev_alloc(h, &(ptr), (n))
+    A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N); A(d.box_z, N); A(d.box_dir, N);
+    A(d.box_color, N * 3); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
+    A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.need_reset, N);
+    A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * MWB_ROOM_WORDS); A(d.segs, N * d.S_max * 4); A(d.frame, N * MWB_FRAME_WORDS);
+    A(d.obs, N * d.W * d.H * 3);
+    if (d.want_depth) { A(d.depth, N * d.W * d.H); }
+    A(d.reward, N); A(d.reward64, N); A(d.done, N); A(d.ep_steps, N);
+    A(h->tex_desc_dev, (size_t)MWB_MAX_TEX);
+    A(h->scratch_int_dev, (size_t)4);
+#undef A
+    if (rc != MWB_OK) { mwb_destroy(h); return rc; }
+    d.tex_desc = h->tex_desc_dev;
+    h->texels_dev = nullptr; d.texels = nullptr;
+    h->seeded = false; h->textures_dirty = false; h->have_textures = false;
+    h->timing = false; h->ev_used = 0; h->ev = nullptr;
+    for (int i = 0; i < MWB_MAX_TEX; i++) { h->tex_w[i] = 0; h->tex_h[i] = 0; }
+    if (mwb_reset_lds_bytes(d) > 64 * 1024 || mwb_render_lds_bytes(d) > 64 * 1024) {
+        mwb_destroy(h);
+        return set_err(MWB_EINVAL, "mwb_create: world too large for the LDS staging buffers");
+    }
+    *out = h;
+    return MWB_OK;
+}
+
+extern "C" int mwb_destroy(mwb_handle *h) {
+    if (!h) return MWB_OK;
+    hipSetDevice(h->cfg.device);
+    hipDeviceSynchronize();
+    for (void *p : h->allocs) hipFree(p);
+    if (h->texels_dev) hipFree(h->texels_dev);
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    delete h;
+    return MWB_OK;
+}
+
+// ------------------------------------------------------------------------------------ textures
+// Mip chain: level k+1 has dims max(1, n/2); each texel is the equal-weight mean (round half up) of
+// the source texels it covers - 2x2 for even sizes (DESIGN.md render spec; restates
+// glGenerateMipmap of opengl.py:98-99, whose filter GL leaves to the driver).
+static void build_mips(const uint8_t *rgb, int w, int h, std::vector<std::vector<uint32_t>> &levels) {
+    levels.clear();
+    std::vector<uint32_t> cur((size_t)w * h);
+    for (int y = 0; y < h; y++)   // flip: texture row 0 = bottom image row (pyglet upload order, opengl.py:85-96)
+        for (int x = 0; x < w; x++) {
+            const uint8_t *p = rgb + ((size_t)(h - 1 - y) * w + x) * 3;
+            cur[(size_t)y * w + x] = p[0] | (p[1] << 8) | (p[2] << 16) | 0xFF000000u;
+        }
+    levels.push_back(cur);
+    int sw = w, sh = h;
+    while (sw > 1 || sh > 1) {
+        int dw = sw > 1 ? sw / 2 : 1, dh = sh > 1 ? sh / 2 : 1;
+        std::vector<uint32_t> nxt((size_t)dw * dh);
+        const std::vector<uint32_t> &src = levels.back();
+        for (int j = 0; j < dh; j++) {
+            int j0 = (int)(((long long)j * sh) / dh), j1 = (int)((((long long)(j + 1) * sh) + dh - 1) / dh);
+            for (int i = 0; i < dw; i++) {
+                int i0 = (int)(((long long)i * sw) / dw), i1 = (int)((((long long)(i + 1) * sw) + dw - 1) / dw);
+                uint32_t sum[4] = {0, 0, 0, 0};
+                for (int y = j0; y < j1; y++)
+                    for (int x = i0; x < i1; x++) {
+                        uint32_t t = src[(size_t)y * sw + x];
+                        sum[0] += t & 255u; sum[1] += (t >> 8) & 255u; sum[2] += (t >> 16) & 255u; sum[3] += t >> 24;
+                    }
+                uint32_t cnt = (uint32_t)((j1 - j0) * (i1 - i0));
+                uint32_t o = 0;
+                for (int c = 0; c < 4; c++) o |= ((sum[c] + cnt / 2) / cnt) << (8 * c);
+                nxt[(size_t)j * dw + i] = o;
+            }
+        }
+        levels.push_back(nxt);
+        sw = dw; sh = dh;
+    }
+}
+
+extern "C" int mwb_set_texture(mwb_handle *h, int tex_id, int width, int height, const uint8_t *rgb) {
+    if (!h || !rgb) return set_err(MWB_EINVAL, "mwb_set_texture: null argument");
+    if (tex_id < 0 || tex_id >= MWB_MAX_TEX || width <= 0 || height <= 0 || width > 4096 || height > 4096)
+        return set_err(MWB_EINVAL, "mwb_set_texture: bad texture id or size");
+    build_mips(rgb, width, height, h->tex_levels[tex_id]);
+    if ((int)h->tex_levels[tex_id].size() > MWB_MAX_LEVELS) return set_err(MWB_EINVAL, "mwb_set_texture: too many mip levels");
+    h->tex_w[tex_id] = width; h->tex_h[tex_id] = height;
+    h->textures_dirty = true;
+    return MWB_OK;
+}
+
+static int upload_textures(mwb_handle *h) {
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    for (int i = 0; i < MWB_MAX_TEX; i++)
+        if (h->tex_w[i] == 0) return set_err(MWB_ESTATE, "render requested before all 7 textures were set (mwb_set_texture)");
+    std::vector<uint32_t> all;
+    MwbTexDesc desc[MWB_MAX_TEX];
+    memset(desc, 0, sizeof(desc));
+    for (int i = 0; i < MWB_MAX_TEX; i++) {
+        desc[i].w = h->tex_w[i]; desc[i].h = h->tex_h[i]; desc[i].n_levels = (int)h->tex_levels[i].size();
+        desc[i].sc_s = (float)(512.0 / h->tex_w[i]); desc[i].sc_t = (float)(512.0 / h->tex_h[i]);
+        for (size_t l = 0; l < h->tex_levels[i].size(); l++) {
+            desc[i].level_off[l] = (uint32_t)all.size();
+            all.insert(all.end(), h->tex_levels[i][l].begin(), h->tex_levels[i][l].end());
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->texels_dev) { hipFree(h->texels_dev); h->texels_dev = nullptr; }
+    HIP_TRY(hipMalloc((void **)&h->texels_dev, all.size() * 4));
+    HIP_TRY(hipMemcpy(h->texels_dev, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->tex_desc_dev, desc, sizeof(desc), hipMemcpyHostToDevice));
+    h->dev.texels = h->texels_dev;
+    h->textures_dirty = false; h->have_textures = true;
+    return MWB_OK;
+}
+
+// ---------------------------------------------------------------------------------- simulation
+extern "C" int mwb_seed(mwb_handle *h, const uint64_t *seeds) {
+    if (!h || !seeds) return set_err(MWB_EINVAL, "mwb_seed: null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    std::vector<uint32_t> st((size_t)h->dev.N * MWB_MT_WORDS);
+    for (int e = 0; e < h->dev.N; e++) {
+        uint32_t key[2];
+        int n = seed_to_key(seeds[e], key);
+        mt_init_by_array(&st[(size_t)e * MWB_MT_WORDS], key, n);
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h->dev.rng, st.data(), st.size() * 4, hipMemcpyHostToDevice));
+    h->seeded = true;
+    return MWB_OK;
+}
+
+static int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(MWB_EHIP, std::string(what) + " launch failed: " + hipGetErrorString(e));
+    return MWB_OK;
+}
+
+static int timing_begin(mwb_handle *h, hipStream_t s) {
+    if (!h->timing) return MWB_OK;
+    if (h->ev_used + 5 > h->ev_pool.size()) {
+        size_t old = h->ev_pool.size();
+        h->ev_pool.resize(old + 5 * 256);
+        for (size_t i = old; i < h->ev_pool.size(); i++) HIP_TRY(hipEventCreate(&h->ev_pool[i]));
+    }
+    h->ev = &h->ev_pool[h->ev_used];
+    h->ev_used += 5;
+    HIP_TRY(hipEventRecord(h->ev[0], s));
+    return MWB_OK;
+}
+#define TMARK(i) do { if (h->timing) HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
+
+static int render_tail(mwb_handle *h, hipStream_t s) {
+    mwb_launch_prep(h->dev, s);
+    int rc = check_launch("prep_kernel"); if (rc) return rc;
+    TMARK(3);
+    mwb_launch_render(h->dev, s);
+    rc = check_launch("render_kernel"); if (rc) return rc;
+    TMARK(4);
+    return MWB_OK;
+}
+
+static int ensure_ready(mwb_handle *h) {
+    if (!h) return set_err(MWB_EINVAL, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (!h->seeded) return set_err(MWB_ESTATE, "mwb_seed must be called before reset/step (the reference seeds from entropy; this library refuses to)");
+    if (h->textures_dirty || !h->have_textures) { int rc = upload_textures(h); if (rc) return rc; }
+    return MWB_OK;
+}
+
+extern "C" int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream) {
+    int rc = ensure_ready(h); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    rc = timing_begin(h, s); if (rc) return rc;
+    mwb_launch_mark_reset(h->dev, mask_dev, s);
+    rc = check_launch("mark_reset_kernel"); if (rc) return rc;
+    TMARK(1);
+    mwb_launch_reset(h->dev, s);
+    rc = check_launch("reset_kernel"); if (rc) return rc;
+    TMARK(2);
+    return render_tail(h, s);
+}
+
+extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask_dev, void *stream) {
+    int rc = ensure_ready(h); if (rc) return rc;
+    if (!actions_dev) return set_err(MWB_EINVAL, "mwb_step: null actions");
+    hipStream_t s = (hipStream_t)stream;
+    rc = timing_begin(h, s); if (rc) return rc;
+    mwb_launch_step(h->dev, actions_dev, skip_mask_dev, s);
+    rc = check_launch("step_kernel"); if (rc) return rc;
+    TMARK(1);
+    mwb_launch_reset(h->dev, s);
+    rc = check_launch("reset_kernel"); if (rc) return rc;
+    TMARK(2);
+    return render_tail(h, s);
+}
+
+extern "C" int mwb_render(mwb_handle *h, void *stream) {
+    int rc = ensure_ready(h); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    rc = timing_begin(h, s); if (rc) return rc;
+    TMARK(1); TMARK(2);
+    return render_tail(h, s);
+}
+
+extern "C" int mwb_get_outputs(mwb_handle *h, mwb_outputs *out) {
+    if (!h || !out) return set_err(MWB_EINVAL, "mwb_get_outputs: null argument");
+    const MwbDev &d = h->dev;
+    out->obs = d.obs; out->depth = d.depth; out->reward = d.reward; out->reward64 = d.reward64; out->done = d.done;
+    out->ep_steps = d.ep_steps;
+    out->obs_bytes = (size_t)d.N * d.W * d.H * 3;
+    out->depth_bytes = d.want_depth ? (size_t)d.N * d.W * d.H * 4 : 0;
+    return MWB_OK;
+}
+
+// -------------------------------------------------------------------------------- introspection
+template <typename T>
+static int fetch(T *dst, const T *src_dev, size_t first, size_t count, size_t stride) {
+    if (!dst) return MWB_OK;
+    HIP_TRY(hipMemcpy(dst, src_dev + first * stride, count * stride * sizeof(T), hipMemcpyDeviceToHost));
+    return MWB_OK;
+}
+
+extern "C" int mwb_get_state(mwb_handle *h, int first, int count, mwb_state *o) {
+    if (!h || !o) return set_err(MWB_EINVAL, "mwb_get_state: null argument");
+    const MwbDev &d = h->dev;
+    if (first < 0 || count < 0 || first + count > d.N) return set_err(MWB_EINVAL, "mwb_get_state: env range out of bounds");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<double> a(count), b(count);
+    int rc;
+    if (o->agent_pos) {
+        if ((rc = fetch(a.data(), d.agent_x, first, count, 1))) return rc;
+        if ((rc = fetch(b.data(), d.agent_z, first, count, 1))) return rc;
+        for (int i = 0; i < count; i++) { o->agent_pos[i * 3] = a[i]; o->agent_pos[i * 3 + 1] = 0.0; o->agent_pos[i * 3 + 2] = b[i]; }
+    }
+    if (o->box_pos) {
+        if ((rc = fetch(a.data(), d.box_x, first, count, 1))) return rc;
+        if ((rc = fetch(b.data(), d.box_z, first, count, 1))) return rc;
+        for (int i = 0; i < count; i++) { o->box_pos[i * 3] = a[i]; o->box_pos[i * 3 + 1] = 0.0; o->box_pos[i * 3 + 2] = b[i]; }
+    }
+    if ((rc = fetch(o->agent_dir, d.agent_dir, first, count, 1))) return rc;
+    if ((rc = fetch(o->box_dir, d.box_dir, first, count, 1))) return rc;
+    if ((rc = fetch(o->box_color, d.box_color, first, count, 3))) return rc;
+    if ((rc = fetch(o->cam, d.cam, first, count, 4))) return rc;
+    if ((rc = fetch(o->sky_color, d.sky_color, first, count, 3))) return rc;
+    if ((rc = fetch(o->light_pos, d.light_pos, first, count, 3))) return rc;
+    if ((rc = fetch(o->light_color, d.light_color, first, count, 3))) return rc;
+    if ((rc = fetch(o->light_ambient, d.light_ambient, first, count, 3))) return rc;
+    if ((rc = fetch(o->step_count, d.step_count, first, count, 1))) return rc;
+    if ((rc = fetch(o->n_rooms, d.n_rooms, first, count, 1))) return rc;
+    if ((rc = fetch(o->n_segs, d.n_segs, first, count, 1))) return rc;
+    if (o->rng_pos || o->rng_keysum) {
+        std::vector<uint32_t> st((size_t)count * MWB_MT_WORDS);
+        if ((rc = fetch(st.data(), d.rng, first, count, MWB_MT_WORDS))) return rc;
+        for (int i = 0; i < count; i++) {
+            uint64_t sum = 0;
+            for (int k = 0; k < 624; k++) sum += st[(size_t)i * MWB_MT_WORDS + k];
+            if (o->rng_keysum) o->rng_keysum[i] = (uint32_t)(sum & 0xFFFFFFFFu);
+            if (o->rng_pos) o->rng_pos[i] = (int32_t)st[(size_t)i * MWB_MT_WORDS + 624];
+        }
+    }
+    return MWB_OK;
+}
+
+extern "C" int mwb_set_agent(mwb_handle *h, int first, int count, const double *pos_xz, const double *dir, const int32_t *step_count) {
+    if (!h) return set_err(MWB_EINVAL, "mwb_set_agent: null handle");
+    const MwbDev &d = h->dev;
+    if (first < 0 || count < 0 || first + count > d.N) return set_err(MWB_EINVAL, "mwb_set_agent: env range out of bounds");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (pos_xz) {
+        std::vector<double> a(count), b(count);
+        for (int i = 0; i < count; i++) { a[i] = pos_xz[i * 2]; b[i] = pos_xz[i * 2 + 1]; }
+        HIP_TRY(hipMemcpy(d.agent_x + first, a.data(), count * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d.agent_z + first, b.data(), count * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (dir) HIP_TRY(hipMemcpy(d.agent_dir + first, dir, count * sizeof(double), hipMemcpyHostToDevice));
+    if (step_count) HIP_TRY(hipMemcpy(d.step_count + first, step_count, count * sizeof(int32_t), hipMemcpyHostToDevice));
+    return MWB_OK;
+}
+
+extern "C" int mwb_intersect(mwb_handle *h, int env, double x, double z, double radius, int *result) {
+    if (!h || !result) return set_err(MWB_EINVAL, "mwb_intersect: null argument");
+    if (env < 0 || env >= h->dev.N) return set_err(MWB_EINVAL, "mwb_intersect: env out of range");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    mwb_launch_intersect(h->dev, env, x, z, radius, h->scratch_int_dev, 0);
+    int rc = check_launch("intersect_kernel"); if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(result, h->scratch_int_dev, sizeof(int), hipMemcpyDeviceToHost));
+    return MWB_OK;
+}
+
+extern "C" int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_rooms, double *segs, int max_segs, int *n_rooms, int *n_segs) {
+    if (!h || !n_rooms || !n_segs) return set_err(MWB_EINVAL, "mwb_get_geometry: null argument");
+    const MwbDev &d = h->dev;
+    if (env < 0 || env >= d.N) return set_err(MWB_EINVAL, "mwb_get_geometry: env out of range");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(n_rooms, d.n_rooms + env, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(n_segs, d.n_segs + env, sizeof(int), hipMemcpyDeviceToHost));
+    if (rooms) {
+        int n = *n_rooms < max_rooms ? *n_rooms : max_rooms;
+        if (n > 0) HIP_TRY(hipMemcpy(rooms, d.rooms + (size_t)env * d.R_max * MWB_ROOM_WORDS, (size_t)n * MWB_ROOM_WORDS * 4, hipMemcpyDeviceToHost));
+    }
+    if (segs) {
+        int n = *n_segs < max_segs ? *n_segs : max_segs;
+        if (n > 0) HIP_TRY(hipMemcpy(segs, d.segs + (size_t)env * d.S_max * 4, (size_t)n * 4 * 8, hipMemcpyDeviceToHost));
+    }
+    return MWB_OK;
+}
+
+// -------------------------------------------------------------------------------------- timing
+extern "C" int mwb_timing_enable(mwb_handle *h, int enable) {
+    if (!h) return set_err(MWB_EINVAL, "mwb_timing_enable: null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    h->timing = enable != 0;
+    h->ev_used = 0;
+    return MWB_OK;
+}
+
+extern "C" int mwb_timing_read(mwb_handle *h, double *ms_step, double *ms_reset, double *ms_prep, double *ms_render, int *n) {
+    if (!h) return set_err(MWB_EINVAL, "mwb_timing_read: null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    double acc[4] = {0, 0, 0, 0};
+    int passes = (int)(h->ev_used / 5);
+    for (int p = 0; p < passes; p++)
+        for (int i = 0; i < 4; i++) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[p * 5 + i], h->ev_pool[p * 5 + i + 1]));
+            acc[i] += ms;
+        }
+    int cnt = passes > 0 ? passes : 1;
+    if (ms_step) *ms_step = acc[0] / cnt;
+    if (ms_reset) *ms_reset = acc[1] / cnt;
+    if (ms_prep) *ms_prep = acc[2] / cnt;
+    if (ms_render) *ms_render = acc[3] / cnt;
+    if (n) *n = passes;
+    h->ev_used = 0;
+    return MWB_OK;
+}

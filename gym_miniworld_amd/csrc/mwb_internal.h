@@ -1,0 +1,105 @@
+// mwb_internal.h - data layout shared by the host API (mwb_api.hip) and the kernels (mwb_kernels.hip).
+//
+// HBM layout (one handle = one GPU's shard of N environments), structure-of-arrays:
+//   sim  : per-env f64 pose / episode parameters (arrays of N), i32 counters, u8 flags
+//   rng  : per-env MT19937 state, N x 625 u32 (624 key words + position), env-major
+//   rooms: per-env room table, N x R_max x MWB_ROOM_WORDS f32 words (render kernel stages it in LDS)
+//   segs : per-env collision segments, N x S_max x 4 f64 (a.x a.z b.x b.z), reference order
+//   frame: per-env render constants (camera basis, lit colours, box frame), N x FRAME_WORDS f32
+//   tex  : RGBA8 mip pyramids of the 7 textures, shared by all envs (L2 / Infinity Cache resident)
+//   out  : obs u8 [N,H,W,3] or [N,3,W,H], depth f32 [N,H,W], reward f32/f64 [N], done u8 [N]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/miniworld_batch.h"
+
+#define MWB_MT_WORDS 625   // 624 key words + pos
+#define MWB_MAX_TEX 7
+#define MWB_MAX_LEVELS 12
+#define MWB_FRAME_WORDS 80
+
+// room table word offsets (f32 words; ints stored as bit patterns)
+#define RW_MINX 0
+#define RW_MAXX 1
+#define RW_MINZ 2
+#define RW_MAXZ 3
+#define RW_HEIGHT 4
+#define RW_TEX 5     // wall | floor << 8 | ceil << 16
+#define RW_SIDE0 8   // 8 words per side: lo hi min_y max_y | nbr u_org u_sgn pad
+#define RS_LO 0
+#define RS_HI 1
+#define RS_MINY 2
+#define RS_MAXY 3
+#define RS_NBR 4
+#define RS_UORG 5
+#define RS_USGN 6
+
+// frame-constant word offsets
+#define FC_EYE 0
+#define FC_F 3
+#define FC_S 6
+#define FC_U 9
+#define FC_TW 12
+#define FC_TH 13
+#define FC_SKY 14
+#define FC_LIT_FLOOR 17
+#define FC_LIT_CEIL 20
+#define FC_LIT_WALL 23   // 4 x 3
+#define FC_LIT_BOX 35    // 6 x 3
+#define FC_BOX_POS 53
+#define FC_BOX_C 56
+#define FC_BOX_S 57
+#define FC_BOX_HX 58
+#define FC_BOX_HZ 59
+#define FC_BOX_SY 60
+#define FC_BOX_LO 61     // ray origin in box-local axes (3)
+#define FC_CULL_OC 64    // box bounding-sphere centre minus eye (3)
+#define FC_CULL_CC 67    // |oc|^2 - R^2
+
+struct MwbTexDesc {
+    int w, h, n_levels;
+    float sc_s, sc_t;                     // TEX_DENSITY / size (miniworld.py:17,30-31,58-63) as f32
+    int pad[3];
+    uint32_t level_off[MWB_MAX_LEVELS];   // texel (u32) offsets into the shared texel buffer
+};
+
+struct MwbParam { double def[3], lo[3], hi[3]; };
+
+// everything a kernel needs, passed by value
+struct MwbDev {
+    int N, task, W, H, want_depth, layout, domain_rand, max_episode_steps;
+    int R_max, S_max;
+    double task_args[4];
+    MwbParam params[MWB_NPARAM];
+    // sim state (f64 SoA)
+    double *agent_x, *agent_z, *agent_dir;
+    double *box_x, *box_z, *box_dir;
+    double *box_color;      // [N][3]
+    double *cam;            // [N][4] height, fwd_disp, pitch, fov_y
+    double *sky_color, *light_pos, *light_color, *light_ambient;   // [N][3]
+    int32_t *step_count, *n_rooms, *n_segs;
+    uint8_t *need_reset;
+    uint32_t *rng;          // [N][625]
+    float *rooms;           // [N][R_max][MWB_ROOM_WORDS]
+    double *segs;           // [N][S_max][4]
+    float *frame;           // [N][MWB_FRAME_WORDS]
+    const uint32_t *texels;
+    const MwbTexDesc *tex_desc;   // [MWB_MAX_TEX] in device memory
+    // outputs
+    uint8_t *obs;
+    float *depth, *reward;
+    double *reward64;
+    uint8_t *done;
+    int32_t *ep_steps;
+};
+
+// launch wrappers implemented in mwb_kernels.hip
+void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *skip_mask, hipStream_t s);
+void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s);
+void mwb_launch_reset(const MwbDev &d, hipStream_t s);
+void mwb_launch_prep(const MwbDev &d, hipStream_t s);
+void mwb_launch_render(const MwbDev &d, hipStream_t s);
+void mwb_launch_intersect(const MwbDev &d, int env, double x, double z, double radius, int *result_dev, hipStream_t s);
+size_t mwb_reset_lds_bytes(const MwbDev &d);
+size_t mwb_render_lds_bytes(const MwbDev &d);

@@ -1,0 +1,1059 @@
+// mwb_kernels.hip - HIP kernels of the batched MiniWorld stepper + renderer (gfx950 / MI355X).
+//
+// Pipeline of one mwb_step():
+//   step_kernel   1 thread / env   f64   MiniWorldEnv.step (miniworld.py:658-716) + task rule
+//   reset_kernel  1 wave   / env   f64   MiniWorldEnv.reset (miniworld.py:532-592), only envs that ended
+//   prep_kernel   1 thread / env   f64->f32  camera basis, per-face lighting, box frame
+//   render_kernel 1 workgroup / env f32  render_obs/_render_world (miniworld.py:1059-1085,1160-1220):
+//                 room table staged in LDS, one wave per 16x4 pixel tile, 8 coverage rays per pixel
+//                 through the portal graph, per-surface shading, framebuffer assembled in LDS and
+//                 written with 16-byte coalesced stores.
+// No MFMA: there is no dense contraction on this path; the work is rays x rooms (VALU + LDS).
+//
+// Compiled with -ffp-contract=off: world generation and the step must reproduce the reference's
+// float64 results bit for bit, and the visibility arithmetic of the renderer is specified with
+// explicit fmaf() ("render spec").
+#include "mwb_internal.h"
+
+#define WAVE 64
+
+// =========================================================================== MT19937 (numpy legacy)
+// numpy.random.RandomState draw recipes used through reference random.py:4-65.
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// single-thread generator over a state in global memory (step kernel, domain randomisation draws)
+struct MtSerial {
+    uint32_t *key;
+    int pos;
+    __device__ void load(uint32_t *st) { key = st; pos = (int)st[624]; }
+    __device__ void store() { key[624] = (uint32_t)pos; }
+    __device__ uint32_t next32() {
+        if (pos == 624) {
+            for (int i = 0; i < 624; i++) key[i] = mt_mix(key[i], key[(i + 1) % 624], key[(i + 397) % 624]);
+            pos = 0;
+        }
+        return mt_temper(key[pos++]);
+    }
+    __device__ double next_double() {
+        uint32_t a = next32() >> 5, b = next32() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    __device__ double uniform(double lo, double hi) { double sc = hi - lo; return lo + sc * next_double(); }
+};
+
+// wave-cooperative generator over a state staged in LDS (reset kernel): every lane carries the same
+// position and computes the same draw; the twist is done by all 64 lanes.
+struct MtWave {
+    uint32_t *key;   // LDS, 624 words
+    int pos, lane;
+    __device__ void twist() {
+        for (int base = 0; base < 624; base += WAVE) {
+            int i = base + lane;
+            uint32_t v = 0;
+            if (i < 624) v = mt_mix(key[i], key[(i + 1) % 624], key[(i + 397) % 624]);
+            __syncthreads();
+            if (i < 624) key[i] = v;
+            __syncthreads();
+        }
+        pos = 0;
+    }
+    __device__ uint32_t next32() {
+        if (pos == 624) twist();
+        return mt_temper(key[pos++]);
+    }
+    __device__ double next_double() {
+        uint32_t a = next32() >> 5, b = next32() >> 6;
+        return (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    __device__ double uniform(double lo, double hi) { double sc = hi - lo; return lo + sc * next_double(); }
+    // RandomState.randint(lo, hi): masked rejection on 32-bit words, no draw when the range is 1
+    __device__ int randint(int lo, int hi) {
+        uint32_t rng = (uint32_t)(hi - 1 - lo);
+        if (rng == 0) return lo;
+        uint32_t mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t v;
+        do { v = next32() & mask; } while (v > rng);
+        return lo + (int)v;
+    }
+};
+
+// ================================================================================== step kernel
+// circle vs wall segments, reference math.py:25-57 (strict <, y flattened)
+__device__ __forceinline__ bool seg_hit(const double *sg, double px, double pz, double radius) {
+    double ax = sg[0], az = sg[1], bx = sg[2], bz = sg[3];
+    double abx = bx - ax, abz = bz - az;
+    double apx = px - ax, apz = pz - az;
+    double dotAPAB = (apx * abx + 0.0) + apz * abz;
+    double dotABAB = (abx * abx + 0.0) + abz * abz;
+    double proj = dotAPAB / dotABAB;
+    proj = proj < 0 ? 0 : (proj > 1 ? 1 : proj);
+    double cx = ax + proj * abx, cz = az + proj * abz;
+    double ddx = cx - px, ddz = cz - pz;
+    double dist = sqrt((ddx * ddx + 0.0) + ddz * ddz);
+    return dist < radius;
+}
+
+#define AGENT_RADIUS 0.4   /* entity.py:451 */
+
+__device__ __forceinline__ double box_radius() {
+    double sx = 0.8, sz = 0.8;   // entity.py:367-378, Box(size=0.8)
+    return sqrt(sx * sx + sz * sz) / 2;
+}
+
+__global__ void __launch_bounds__(256) step_kernel(MwbDev d, const int32_t *__restrict__ actions,
+                                                   const uint8_t *__restrict__ skip) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= d.N) return;
+    if (skip && skip[e]) {   // the fork's 'dummy' command, vec_env/subproc_vec_env.py:26-31
+        d.reward[e] = -99.0f; d.reward64[e] = -99.0; d.done[e] = 0; d.ep_steps[e] = d.step_count[e];
+        d.need_reset[e] = 0;
+        return;
+    }
+    int sc = d.step_count[e] + 1;   // miniworld.py:663
+    d.step_count[e] = sc;
+    double fwd_step = d.params[MWB_P_FORWARD_STEP].def[0];
+    double fwd_drift = d.params[MWB_P_FORWARD_DRIFT].def[0];
+    double turn_step = d.params[MWB_P_TURN_STEP].def[0];
+    if (d.domain_rand) {   // miniworld.py:665-668: three draws every step, whatever the action
+        MtSerial g;
+        g.load(d.rng + (size_t)e * MWB_MT_WORDS);
+        fwd_step = g.uniform(d.params[MWB_P_FORWARD_STEP].lo[0], d.params[MWB_P_FORWARD_STEP].hi[0]);
+        fwd_drift = g.uniform(d.params[MWB_P_FORWARD_DRIFT].lo[0], d.params[MWB_P_FORWARD_DRIFT].hi[0]);
+        turn_step = g.uniform(d.params[MWB_P_TURN_STEP].lo[0], d.params[MWB_P_TURN_STEP].hi[0]);
+        g.store();
+    }
+    int a = actions[e];
+    double ax = d.agent_x[e], az = d.agent_z[e], adir = d.agent_dir[e];
+    double bx = d.box_x[e], bz = d.box_z[e];
+    double brad = box_radius();
+    if (a == 2 || a == 3) {   // move_agent, miniworld.py:608-633
+        double fd = (a == 2) ? fwd_step : -fwd_step;
+        double c = cos(adir), s = sin(adir);
+        // pos + dir_vec*fwd + right_vec*drift with dir_vec=(cos,0,-sin), right_vec=(sin,0,cos)
+        double nx = (ax + c * fd) + s * fwd_drift;
+        double nz = (az + (-s) * fd) + c * fwd_drift;
+        const double *sg = d.segs + (size_t)e * d.S_max * 4;
+        int ns = d.n_segs[e];
+        bool hit = false;
+        for (int i = 0; i < ns && !hit; i++) hit = seg_hit(sg + i * 4, nx, nz, AGENT_RADIUS);
+        if (!hit) {   // entity test, miniworld.py:946-957 (the box is the only other entity)
+            double ddx = bx - nx, ddz = bz - nz;
+            double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
+            hit = dist < AGENT_RADIUS + brad;
+        }
+        if (!hit) { ax = nx; az = nz; d.agent_x[e] = ax; d.agent_z[e] = az; }
+    } else if (a == 0 || a == 1) {   // turn_agent, miniworld.py:635-656
+        double ta = (a == 0) ? turn_step : -turn_step;
+        ta *= (3.141592653589793 / 180);
+        adir += ta;
+        d.agent_dir[e] = adir;
+    }
+    double r = 0.0;
+    int done = 0;
+    if (sc >= d.max_episode_steps) { done = 1; r = 0.0; }   // miniworld.py:708-711
+    {   // near(box), miniworld.py:961-971, then the task rule (e.g. envs/maze.py:106-113)
+        double ddx = bx - ax, ddz = bz - az;
+        double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
+        double max_forward_step = d.params[MWB_P_FORWARD_STEP].hi[0];   // miniworld.py:569
+        if (dist < brad + AGENT_RADIUS + 1.1 * max_forward_step) {
+            r += 1.0 - 0.2 * ((double)sc / d.max_episode_steps);   // _reward, miniworld.py:1012
+            done = 1;
+        }
+    }
+    d.reward64[e] = r; d.reward[e] = (float)r; d.done[e] = (uint8_t)done; d.ep_steps[e] = sc;
+    d.need_reset[e] = (uint8_t)done;   // worker auto-reset, vec_env/subproc_vec_env.py:10-13
+}
+
+__global__ void mark_reset_kernel(MwbDev d, const uint8_t *__restrict__ mask) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= d.N) return;
+    d.need_reset[e] = mask ? (mask[e] ? 1 : 0) : 1;
+}
+
+// ================================================================================= reset kernel
+// World generation.  One wave per environment; all 64 lanes run the same sequential logic on
+// identical values (the RNG stream is inherently serial) and split the wide parts: the MT19937
+// twist, the circle-vs-segments tests of the placement loop and the emission of the room / segment
+// tables.  The float64 room store lives in LDS.
+struct WRoom {
+    double ox[4], oz[4];            // outline, reference order (miniworld.py:732-741, 826)
+    double height;
+    double p_start[4], p_end[4], p_maxy[4];   // at most one portal per edge in the four tasks
+    double min_x, max_x, min_z, max_z, area;
+    int n_port[4], nbr[4];
+    int tex_fam[3], tex_id[3];      // wall, floor, ceil
+};
+
+enum { TEXF_FLOOR_TILES_BW = 0, TEXF_CONCRETE, TEXF_CONCRETE_TILES, TEXF_BRICK_WALL };
+__constant__ int c_texf_first[4] = {0, 1, 5, 6};
+__constant__ int c_texf_count[4] = {1, 4, 1, 1};   // <name>_<i>.png variants, opengl.py:50-58
+
+struct WorldGen {
+    WRoom *rooms;
+    int n_rooms;
+    double *cdf;
+    double *segs;     // LDS copy, S_max x 4
+    int n_segs;
+    int *seg_off;
+    MtWave rng;
+    int lane;
+    bool fail;
+
+    // Room.__init__, miniworld.py:75-138
+    __device__ int add_room(const double *ox, const double *oz, double height, int wall_fam, int floor_fam, int ceil_fam) {
+        WRoom &r = rooms[n_rooms];
+        double mnx = ox[0], mxx = ox[0], mnz = oz[0], mxz = oz[0];
+        for (int i = 0; i < 4; i++) {
+            r.ox[i] = ox[i]; r.oz[i] = oz[i];
+            mnx = fmin(mnx, ox[i]); mxx = fmax(mxx, ox[i]); mnz = fmin(mnz, oz[i]); mxz = fmax(mxz, oz[i]);
+            r.n_port[i] = 0; r.nbr[i] = -1;
+        }
+        r.min_x = mnx; r.max_x = mxx; r.min_z = mnz; r.max_z = mxz;
+        r.area = (mxx - mnx) * (mxz - mnz);
+        r.height = height;
+        r.tex_fam[0] = wall_fam; r.tex_fam[1] = floor_fam; r.tex_fam[2] = ceil_fam;
+        return n_rooms++;
+    }
+    // add_rect_room, miniworld.py:718-743
+    __device__ int add_rect_room(double min_x, double max_x, double min_z, double max_z, int wall_fam) {
+        double ox[4] = {max_x, max_x, min_x, min_x}, oz[4] = {max_z, min_z, min_z, max_z};
+        return add_room(ox, oz, 2.74, wall_fam, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES);
+    }
+    // edge direction as Room.__init__ / add_portal compute it: (p1 - p0) / norm
+    __device__ void edge(const WRoom &r, int e, double &dx, double &dz, double &len) const {
+        double ex = r.ox[(e + 1) & 3] - r.ox[e], ez = r.oz[(e + 1) & 3] - r.oz[e];
+        len = sqrt((ex * ex + 0.0) + ez * ez);
+        dx = ex / len; dz = ez / len;
+    }
+    // Room.add_portal, miniworld.py:140-218; mode 0 start/end, 1 min_x/max_x, 2 min_z/max_z
+    __device__ void add_portal(int ri, int e, int mode, double a, double b, bool has_max_y, double max_y_in,
+                               double &start, double &end) {
+        WRoom &r = rooms[ri];
+        double dx, dz, len;
+        edge(r, e, dx, dz, len);
+        if (mode == 1) {
+            double m0 = (a - r.ox[e]) / dx, m1 = (b - r.ox[e]) / dx;
+            if (m1 < m0) { double t = m0; m0 = m1; m1 = t; }
+            start = m0; end = m1;
+        } else if (mode == 2) {
+            double m0 = (a - r.oz[e]) / dz, m1 = (b - r.oz[e]) / dz;
+            if (m1 < m0) { double t = m0; m0 = m1; m1 = t; }
+            start = m0; end = m1;
+        } else { start = a; end = b; }
+        if (!(end > start) || !(start >= 0) || !(end <= len) || r.n_port[e] != 0) fail = true;
+        r.p_start[e] = start; r.p_end[e] = end;
+        r.p_maxy[e] = has_max_y ? max_y_in : r.height;
+        r.n_port[e] = 1;
+    }
+    // connect_rooms, miniworld.py:757-843
+    __device__ void connect_rooms(int ia, int ib, int mode, double lo, double hi, bool has_max_y, double max_y) {
+        int idx_a = -1, idx_b = -1;
+        for (int i = 0; i < 4 && idx_a < 0; i++)
+            for (int j = 0; j < 4; j++) {
+                double adx, adz, bdx, bdz, l;
+                edge(rooms[ia], i, adx, adz, l);
+                edge(rooms[ib], j, bdx, bdz, l);
+                // edge_norms = -cross(edge_dir, Y) = (dz, 0, -dx) (unit for axis-aligned edges)
+                double nax = adz, naz = -adx, nbx = bdz, nbz = -bdx;
+                double dotn = (nax * nbx + 0.0) + naz * nbz;
+                if (dotn > -0.9) continue;
+                double ddx = rooms[ib].ox[j] - rooms[ia].ox[i], ddz = rooms[ib].oz[j] - rooms[ia].oz[i];
+                double dd = (nax * ddx + 0.0) + naz * ddz;
+                if (dd > 0.05) continue;
+                idx_a = i; idx_b = j;
+                break;
+            }
+        if (idx_a < 0) { fail = true; return; }
+        double sa, ea, sb, eb;
+        add_portal(ia, idx_a, mode, lo, hi, has_max_y, max_y, sa, ea);
+        add_portal(ib, idx_b, mode, lo, hi, has_max_y, max_y, sb, eb);
+        double adx, adz, bdx, bdz, l;
+        edge(rooms[ia], idx_a, adx, adz, l);
+        edge(rooms[ib], idx_b, bdx, bdz, l);
+        const WRoom &A = rooms[ia], &B = rooms[ib];
+        double a_x = A.ox[idx_a] + adx * sa, a_z = A.oz[idx_a] + adz * sa;
+        double b_x = A.ox[idx_a] + adx * ea, b_z = A.oz[idx_a] + adz * ea;
+        double c_x = B.ox[idx_b] + bdx * sb, c_z = B.oz[idx_b] + bdz * sb;
+        double d_x = B.ox[idx_b] + bdx * eb, d_z = B.oz[idx_b] + bdz * eb;
+        double adx_ = a_x - d_x, adz_ = a_z - d_z;
+        if (sqrt(adx_ * adx_ + 0.0 + adz_ * adz_) < 0.001) {   // portals directly connected
+            rooms[ia].nbr[idx_a] = ib; rooms[ib].nbr[idx_b] = ia;
+            return;
+        }
+        double len_a = sqrt((b_x - a_x) * (b_x - a_x) + 0.0 + (b_z - a_z) * (b_z - a_z));
+        double len_b = sqrt((d_x - c_x) * (d_x - c_x) + 0.0 + (d_z - c_z) * (d_z - c_z));
+        double ox[4] = {c_x, b_x, a_x, d_x}, oz[4] = {c_z, b_z, a_z, d_z};
+        double my = has_max_y ? max_y : A.height;
+        int wf = A.tex_fam[0], ff = A.tex_fam[1], cf = A.tex_fam[2];
+        int ic = add_room(ox, oz, my, wf, ff, cf);
+        double s0, e0;
+        add_portal(ic, 1, 0, 0.0, len_a, false, 0.0, s0, e0);
+        add_portal(ic, 3, 0, 0.0, len_b, false, 0.0, s0, e0);
+        rooms[ia].nbr[idx_a] = ic; rooms[ib].nbr[idx_b] = ic;
+        rooms[ic].nbr[1] = ia; rooms[ic].nbr[3] = ib;
+    }
+    // numpy add.reduce pairwise summation (np.sum at miniworld.py:998)
+    __device__ double pairwise_area_sum(int first, int n) const {
+        if (n < 8) {
+            double res = 0.;
+            for (int i = 0; i < n; i++) res += rooms[first + i].area;
+            return res;
+        } else if (n <= 128) {
+            double r[8];
+            for (int k = 0; k < 8; k++) r[k] = rooms[first + k].area;
+            int i;
+            for (i = 8; i < n - (n % 8); i += 8)
+                for (int k = 0; k < 8; k++) r[k] += rooms[first + i + k].area;
+            double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (; i < n; i++) res += rooms[first + i].area;
+            return res;
+        } else {
+            int n2 = n / 2;
+            n2 -= n2 % 8;
+            return pairwise_area_sum(first, n2) + pairwise_area_sum(first + n2, n - n2);
+        }
+    }
+    // number of collidable segments edge e of room r produces (gen_seg_poly calls, miniworld.py:312-375)
+    __device__ int edge_segs(const WRoom &r, int e, double *out /* may be null */) const {
+        double dx, dz, len;
+        edge(r, e, dx, dz, len);
+        int n = 0;
+        double st[2], en[2];
+        if (r.n_port[e] == 0) { st[0] = 0; en[0] = len; n = 1; }
+        else {
+            st[0] = 0; en[0] = r.p_start[e];
+            st[1] = r.p_end[e]; en[1] = len;
+            n = 2;
+        }
+        int cnt = 0;
+        for (int k = 0; k < n; k++) {
+            if (en[k] == st[k]) continue;   // gen_seg_poly: seg_end == seg_start
+            if (out) {
+                // wall_segs.append([s_p1, s_p0]), s_p = edge_p0 + seg * side_vec (miniworld.py:281-286)
+                double p0x = r.ox[e] + st[k] * dx, p0z = r.oz[e] + st[k] * dz;
+                double p1x = r.ox[e] + en[k] * dx, p1z = r.oz[e] + en[k] * dz;
+                out[cnt * 4 + 0] = p1x; out[cnt * 4 + 1] = p1z; out[cnt * 4 + 2] = p0x; out[cnt * 4 + 3] = p0z;
+            }
+            cnt++;
+        }
+        return cnt;
+    }
+    // MiniWorldEnv._gen_static_data, miniworld.py:981-998 (+ Room._gen_static_data 243-245, 311-375)
+    __device__ void gen_static_data(bool use_rng, int S_max) {
+        for (int i = 0; i < n_rooms; i++)
+            for (int k = 0; k < 3; k++) {   // Texture.get, opengl.py:40-69
+                int fam = rooms[i].tex_fam[k];
+                int idx = use_rng ? rng.randint(0, c_texf_count[fam]) : 0;
+                rooms[i].tex_id[k] = c_texf_first[fam] + idx;
+            }
+        __syncthreads();
+        int off = 0;
+        for (int i = 0; i < n_rooms; i++) {
+            seg_off[i] = off;
+            for (int e = 0; e < 4; e++) off += edge_segs(rooms[i], e, nullptr);
+        }
+        n_segs = off;
+        if (n_segs > S_max) { fail = true; n_segs = S_max; }
+        __syncthreads();
+        for (int i = lane; i < n_rooms && !fail; i += WAVE) {
+            int o = seg_off[i];
+            for (int e = 0; e < 4; e++) o += edge_segs(rooms[i], e, segs + o * 4);
+        }
+        __syncthreads();
+        double sum = pairwise_area_sum(0, n_rooms);
+        // RandomState.choice(p): cdf = p.cumsum(); cdf /= cdf[-1]
+        double acc = 0;
+        for (int i = 0; i < n_rooms; i++) {
+            double p = rooms[i].area / sum;
+            acc = (i == 0) ? p : acc + p;
+            cdf[i] = acc;
+        }
+        __syncthreads();
+        double last = cdf[n_rooms - 1];
+        __syncthreads();
+        for (int i = 0; i < n_rooms; i++) cdf[i] = cdf[i] / last;
+        __syncthreads();
+    }
+    // MiniWorldEnv.intersect walls part, all lanes
+    __device__ bool walls_hit(double px, double pz, double radius) const {
+        bool h = false;
+        for (int i = lane; i < n_segs; i += WAVE) h = h || seg_hit(segs + i * 4, px, pz, radius);
+        return __any(h);
+    }
+    // place_entity, miniworld.py:845-907 (pos=None, room=None path)
+    __device__ void place_entity(double radius, bool has_other, double other_x, double other_z, double other_radius,
+                                 bool has_dir, double dir_in, bool has_min_x, double min_x, bool has_max_x, double max_x,
+                                 double &out_x, double &out_z, double &out_dir) {
+        for (int attempt = 0; attempt < 100000; attempt++) {
+            double u = rng.next_double();   // choice(rooms, p=room_probs): searchsorted(cdf, u, 'right')
+            int lo = 0, hi = n_rooms;
+            while (lo < hi) { int mid = (lo + hi) / 2; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+            const WRoom &r = rooms[lo < n_rooms ? lo : n_rooms - 1];
+            double lx = has_min_x ? min_x : r.min_x, hx = has_max_x ? max_x : r.max_x;
+            double lz = r.min_z, hz = r.max_z;
+            double px = rng.uniform(lx + radius, hx - radius);
+            (void)rng.uniform(0.0, 0.0);   // the y component draws too
+            double pz = rng.uniform(lz + radius, hz - radius);
+            // Room.point_inside, miniworld.py:220-232
+            bool inside = true;
+            for (int e = 0; e < 4; e++) {
+                double dx, dz, len;
+                edge(r, e, dx, dz, len);
+                double nx = dz, nz = -dx;
+                double dot = (nx * (px - r.ox[e]) + 0.0) + nz * (pz - r.oz[e]);
+                if (!(dot > 0)) inside = false;
+            }
+            if (!inside) continue;
+            if (walls_hit(px, pz, radius)) continue;
+            if (has_other) {
+                double ddx = other_x - px, ddz = other_z - pz;
+                double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
+                if (dist < radius + other_radius) continue;
+            }
+            out_dir = has_dir ? dir_in : rng.uniform(-3.141592653589793, 3.141592653589793);
+            out_x = px; out_z = pz;
+            return;
+        }
+        fail = true;
+    }
+};
+
+__device__ __forceinline__ void sample_param(MtWave &g, const MwbParam &p, int n, bool use_rng, double *out) {
+    for (int k = 0; k < n; k++) out[k] = use_rng ? g.uniform(p.lo[k], p.hi[k]) : p.def[k];   // params.py:81-99
+}
+
+__global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
+    int e = blockIdx.x;
+    if (!d.need_reset[e]) return;
+    int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WRoom *rooms = (WRoom *)smem;
+    size_t off = (size_t)d.R_max * sizeof(WRoom);
+    double *segs = (double *)(smem + off); off += (size_t)d.S_max * 4 * sizeof(double);
+    double *cdf = (double *)(smem + off); off += (size_t)d.R_max * sizeof(double);
+    int *seg_off = (int *)(smem + off); off += (size_t)((d.R_max + 3) & ~3) * sizeof(int);
+    uint32_t *key = (uint32_t *)(smem + off);
+
+    uint32_t *st = d.rng + (size_t)e * MWB_MT_WORDS;
+    for (int i = lane; i < 624; i += WAVE) key[i] = st[i];
+    __syncthreads();
+
+    WorldGen w;
+    w.rooms = rooms; w.n_rooms = 0; w.cdf = cdf; w.segs = segs; w.n_segs = 0; w.seg_off = seg_off;
+    w.rng.key = key; w.rng.pos = (int)st[624]; w.rng.lane = lane; w.lane = lane; w.fail = false;
+    bool dr = d.domain_rand != 0;
+
+    double box_x = 0, box_z = 0, box_dir = 0, ag_x = 0, ag_z = 0, ag_dir = 0;
+    double brad = box_radius();
+    if (d.task == MWB_TASK_HALLWAY) {   // envs/hallway.py:25-42
+        double length = d.task_args[0];
+        int r = w.add_rect_room(-1, -1 + length, -2, 2, TEXF_CONCRETE);
+        double rmax = rooms[r].max_x;
+        w.gen_static_data(dr, d.S_max);
+        w.place_entity(brad, false, 0, 0, 0, false, 0, true, rmax - 2, false, 0, box_x, box_z, box_dir);
+        double adir = w.rng.uniform(-3.141592653589793 / 4, 3.141592653589793 / 4);
+        w.place_entity(AGENT_RADIUS, true, box_x, box_z, brad, true, adir, false, 0, true, rmax - 2, ag_x, ag_z, ag_dir);
+    } else if (d.task == MWB_TASK_ONEROOM) {   // envs/oneroom.py:26-35
+        double size = d.task_args[0];
+        w.add_rect_room(0, size, 0, size, TEXF_CONCRETE);
+        w.gen_static_data(dr, d.S_max);
+        w.place_entity(brad, false, 0, 0, 0, false, 0, false, 0, false, 0, box_x, box_z, box_dir);
+        w.place_entity(AGENT_RADIUS, true, box_x, box_z, brad, false, 0, false, 0, false, 0, ag_x, ag_z, ag_dir);
+    } else if (d.task == MWB_TASK_FOURROOMS) {   // envs/fourrooms.py:22-52
+        w.add_rect_room(-7, -1, 1, 7, TEXF_CONCRETE);
+        w.add_rect_room(1, 7, 1, 7, TEXF_CONCRETE);
+        w.add_rect_room(1, 7, -7, -1, TEXF_CONCRETE);
+        w.add_rect_room(-7, -1, -7, -1, TEXF_CONCRETE);
+        w.connect_rooms(0, 1, 2, 3, 5, true, 2.2);
+        w.connect_rooms(1, 2, 1, 3, 5, true, 2.2);
+        w.connect_rooms(2, 3, 2, -5, -3, true, 2.2);
+        w.connect_rooms(3, 0, 1, -5, -3, true, 2.2);
+        w.gen_static_data(dr, d.S_max);
+        w.place_entity(brad, false, 0, 0, 0, false, 0, false, 0, false, 0, box_x, box_z, box_dir);
+        w.place_entity(AGENT_RADIUS, true, box_x, box_z, brad, false, 0, false, 0, false, 0, ag_x, ag_z, ag_dir);
+    } else {   // envs/maze.py:34-104, recursive backtracker with an explicit stack
+        int num_rows = (int)d.task_args[0], num_cols = (int)d.task_args[1];
+        double room_size = d.task_args[2], gap = 0.25;
+        for (int j = 0; j < num_rows; j++)
+            for (int i = 0; i < num_cols; i++) {
+                double min_x = i * (room_size + gap), max_x = min_x + room_size;
+                double min_z = j * (room_size + gap), max_z = min_z + room_size;
+                w.add_rect_room(min_x, max_x, min_z, max_z, TEXF_BRICK_WALL);
+            }
+        // DFS frames live in the (not yet used) segment buffer: cell, packed neighbour order, next index
+        int *stack = (int *)segs;
+        uint8_t *visited = (uint8_t *)(stack + 3 * (num_rows * num_cols + 1));
+        for (int i = 0; i < num_rows * num_cols; i++) visited[i] = 0;
+        __syncthreads();
+        int sp = 0;
+        auto push = [&](int ci, int cj) {
+            visited[cj * num_cols + ci] = 1;
+            // RandGen.subset(list, 4): choice + remove, random.py:50-65; entries are (dj, di)
+            int lst[4] = {0, 1, 2, 3}, n = 4, packed = 0;
+            for (int q = 0; q < 4; q++) {
+                int idx = w.rng.randint(0, n);
+                int v = idx == 0 ? lst[0] : idx == 1 ? lst[1] : idx == 2 ? lst[2] : lst[3];
+                packed |= v << (2 * q);
+                if (idx <= 0) lst[0] = lst[1];
+                if (idx <= 1) lst[1] = lst[2];
+                if (idx <= 2) lst[2] = lst[3];
+                n--;
+            }
+            stack[sp * 3 + 0] = cj * num_cols + ci; stack[sp * 3 + 1] = packed; stack[sp * 3 + 2] = 0;
+            sp++;
+        };
+        push(0, 0);
+        while (sp > 0 && !w.fail) {
+            int cell = stack[(sp - 1) * 3], packed = stack[(sp - 1) * 3 + 1], next = stack[(sp - 1) * 3 + 2];
+            if (next >= 4) { sp--; continue; }
+            stack[(sp - 1) * 3 + 2] = next + 1;
+            int v = (packed >> (2 * next)) & 3;   // (0,1),(0,-1),(-1,0),(1,0) as (dj, di)
+            int dj = v == 0 ? 0 : v == 1 ? 0 : v == 2 ? -1 : 1;
+            int di = v == 0 ? 1 : v == 1 ? -1 : 0;
+            int ci = cell % num_cols, cj = cell / num_cols;
+            int ni = ci + di, nj = cj + dj;
+            if (nj < 0 || nj >= num_rows || ni < 0 || ni >= num_cols) continue;
+            if (visited[nj * num_cols + ni]) continue;
+            int rb = nj * num_cols + ni;
+            if (di == 0) w.connect_rooms(cell, rb, 1, rooms[cell].min_x, rooms[cell].max_x, false, 0);
+            else w.connect_rooms(cell, rb, 2, rooms[cell].min_z, rooms[cell].max_z, false, 0);
+            push(ni, nj);
+        }
+        __syncthreads();
+        w.gen_static_data(dr, d.S_max);
+        w.place_entity(brad, false, 0, 0, 0, false, 0, false, 0, false, 0, box_x, box_z, box_dir);
+        w.place_entity(AGENT_RADIUS, true, box_x, box_z, brad, false, 0, false, 0, false, 0, ag_x, ag_z, ag_dir);
+    }
+    // miniworld.py:561-573: sky / light, then entity.randomize in list order (box, agent)
+    double sky[3], lpos[3], lcol[3], lamb[3], bias[3], cam[4];
+    sample_param(w.rng, d.params[MWB_P_SKY_COLOR], 3, dr, sky);
+    sample_param(w.rng, d.params[MWB_P_LIGHT_POS], 3, dr, lpos);
+    sample_param(w.rng, d.params[MWB_P_LIGHT_COLOR], 3, dr, lcol);
+    sample_param(w.rng, d.params[MWB_P_LIGHT_AMBIENT], 3, dr, lamb);
+    sample_param(w.rng, d.params[MWB_P_OBJ_COLOR_BIAS], 3, dr, bias);
+    sample_param(w.rng, d.params[MWB_P_CAM_HEIGHT], 1, dr, &cam[0]);
+    sample_param(w.rng, d.params[MWB_P_CAM_FWD_DISP], 1, dr, &cam[1]);
+    sample_param(w.rng, d.params[MWB_P_CAM_PITCH], 1, dr, &cam[2]);
+    sample_param(w.rng, d.params[MWB_P_CAM_FOV_Y], 1, dr, &cam[3]);
+    __syncthreads();
+
+    // ---- emit: RNG state, scalars (lane 0), room + segment tables (all lanes)
+    for (int i = lane; i < 624; i += WAVE) st[i] = key[i];
+    if (lane == 0) {
+        st[624] = (uint32_t)w.rng.pos;
+        d.agent_x[e] = ag_x; d.agent_z[e] = ag_z; d.agent_dir[e] = ag_dir;
+        d.box_x[e] = box_x; d.box_z[e] = box_z; d.box_dir[e] = box_dir;
+        const double red[3] = {1.0, 0.0, 0.0};   // COLORS['red'] + bias, clipped (entity.py:381-383)
+        for (int k = 0; k < 3; k++) {
+            double v = red[k] + bias[k];
+            d.box_color[e * 3 + k] = v < 0 ? 0 : (v > 1 ? 1 : v);
+            d.sky_color[e * 3 + k] = sky[k]; d.light_pos[e * 3 + k] = lpos[k];
+            d.light_color[e * 3 + k] = lcol[k]; d.light_ambient[e * 3 + k] = lamb[k];
+        }
+        for (int k = 0; k < 4; k++) d.cam[e * 4 + k] = cam[k];
+        d.step_count[e] = 0;
+        d.n_rooms[e] = w.fail ? -1 : w.n_rooms;
+        d.n_segs[e] = w.n_segs;
+        d.need_reset[e] = 0;
+    }
+    double *gsegs = d.segs + (size_t)e * d.S_max * 4;
+    for (int i = lane; i < w.n_segs * 4; i += WAVE) gsegs[i] = segs[i];
+    float *grooms = d.rooms + (size_t)e * d.R_max * MWB_ROOM_WORDS;
+    for (int ri = lane; ri < w.n_rooms; ri += WAVE) {
+        const WRoom &r = rooms[ri];
+        float *o = grooms + (size_t)ri * MWB_ROOM_WORDS;
+        o[RW_MINX] = (float)r.min_x; o[RW_MAXX] = (float)r.max_x; o[RW_MINZ] = (float)r.min_z; o[RW_MAXZ] = (float)r.max_z;
+        o[RW_HEIGHT] = (float)r.height;
+        o[RW_TEX] = __int_as_float(r.tex_id[0] | (r.tex_id[1] << 8) | (r.tex_id[2] << 16));
+        o[6] = 0; o[7] = 0;
+        for (int s = 0; s < 4; s++) {
+            float *sd = o + RW_SIDE0 + 8 * s;
+            sd[RS_LO] = 0; sd[RS_HI] = 0; sd[RS_MINY] = 0; sd[RS_MAXY] = 0; sd[RS_NBR] = __int_as_float(-1);
+            sd[RS_UORG] = 0; sd[RS_USGN] = 0; sd[7] = 0;
+        }
+        for (int ed = 0; ed < 4; ed++) {
+            double dx, dz, len;
+            w.edge(r, ed, dx, dz, len);
+            double nx = dz, nz = -dx;   // inward normal
+            int s = (nx == -1 && nz == 0) ? 0 : (nx == 0 && nz == 1) ? 1 : (nx == 1 && nz == 0) ? 2 : 3;
+            bool along_z = (s == 0 || s == 2);
+            double p0c = along_z ? r.oz[ed] : r.ox[ed], dirc = along_z ? dz : dx;
+            float *sd = o + RW_SIDE0 + 8 * s;
+            sd[RS_UORG] = (float)p0c; sd[RS_USGN] = (float)dirc;
+            if (r.n_port[ed]) {
+                double c0 = p0c + dirc * r.p_start[ed], c1 = p0c + dirc * r.p_end[ed];
+                sd[RS_LO] = (float)(c0 < c1 ? c0 : c1); sd[RS_HI] = (float)(c0 < c1 ? c1 : c0);
+                sd[RS_MINY] = 0.0f; sd[RS_MAXY] = (float)r.p_maxy[ed];
+                sd[RS_NBR] = __int_as_float(r.nbr[ed]);
+            }
+        }
+    }
+}
+
+// ================================================================================== prep kernel
+// Camera basis (Agent.cam_pos / cam_dir, entity.py:457-484 via gen_rot_matrix math.py:9-23), the
+// gluPerspective / gluLookAt set-up of render_obs (miniworld.py:1183-1200), fixed-function lighting
+// per flat face (miniworld.py:1026-1045) and the box frame (entity.py:385-408), once per env-step.
+__device__ __forceinline__ void rot_matrix(double axx, double axy, double axz, double angle, double *m) {
+    double n = sqrt(axx * axx + axy * axy + axz * axz);
+    axx /= n; axy /= n; axz /= n;
+    double a = cos(angle / 2.0), s = sin(angle / 2.0);
+    double b = -axx * s, c = -axy * s, dd = -axz * s;
+    m[0] = a * a + b * b - c * c - dd * dd; m[1] = 2 * (b * c - a * dd); m[2] = 2 * (b * dd + a * c);
+    m[3] = 2 * (b * c + a * dd); m[4] = a * a + c * c - b * b - dd * dd; m[5] = 2 * (c * dd - a * b);
+    m[6] = 2 * (b * dd - a * c); m[7] = 2 * (c * dd + a * b); m[8] = a * a + dd * dd - b * b - c * c;
+}
+__device__ __forceinline__ void vec_mat(const double *v, const double *m, double *o) {
+    for (int j = 0; j < 3; j++) o[j] = (v[0] * m[j] + v[1] * m[3 + j]) + v[2] * m[6 + j];
+}
+__device__ __forceinline__ void lit_color(const float *L, const float *amb, const float *dif, float nx, float ny, float nz,
+                                          const float *C, float *out) {
+    float ndl = nx * L[0] + ny * L[1] + nz * L[2];
+    if (ndl < 0) ndl = 0;
+    for (int k = 0; k < 3; k++) {
+        float v = (0.2f * C[k] + amb[k] * C[k]) + ndl * dif[k] * C[k];   // 0.2 = GL default global ambient
+        out[k] = v > 1.0f ? 1.0f : v;
+    }
+}
+
+__global__ void __launch_bounds__(256) prep_kernel(MwbDev d) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= d.N) return;
+    float *fc = d.frame + (size_t)e * MWB_FRAME_WORDS;
+    double adir = d.agent_dir[e];
+    double cam_h = d.cam[e * 4 + 0], cam_fd = d.cam[e * 4 + 1], cam_pitch = d.cam[e * 4 + 2], fov = d.cam[e * 4 + 3];
+    double rot_y[9], rot_z[9], disp[3], t[3], cd[3];
+    rot_matrix(0, 1, 0, adir, rot_y);
+    double v0[3] = {cam_fd, cam_h, 0};
+    vec_mat(v0, rot_y, disp);
+    double cp[3] = {d.agent_x[e] + disp[0], 0.0 + disp[1], d.agent_z[e] + disp[2]};
+    rot_matrix(0, 0, 1, cam_pitch * 3.141592653589793 / 180, rot_z);
+    double xv[3] = {1, 0, 0};
+    vec_mat(xv, rot_z, t);
+    vec_mat(t, rot_y, cd);
+    double fl = sqrt(cd[0] * cd[0] + cd[1] * cd[1] + cd[2] * cd[2]);
+    double f[3] = {cd[0] / fl, cd[1] / fl, cd[2] / fl};
+    double sl = sqrt(f[2] * f[2] + f[0] * f[0]);
+    double s[3] = {-f[2] / sl, 0, f[0] / sl};
+    double u[3] = {s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0]};
+    double th = tan(fov * 3.141592653589793 / 180 / 2);
+    float eye[3];
+    for (int k = 0; k < 3; k++) {
+        eye[k] = (float)cp[k];
+        fc[FC_EYE + k] = eye[k]; fc[FC_F + k] = (float)f[k]; fc[FC_S + k] = (float)s[k]; fc[FC_U + k] = (float)u[k];
+    }
+    fc[FC_TH] = (float)th;
+    fc[FC_TW] = (float)(th * ((double)d.W / (double)d.H));
+    // light: GL_POSITION = (light_pos + 1, w = 0) -> directional
+    double lp[3] = {d.light_pos[e * 3] + 1, d.light_pos[e * 3 + 1] + 1, d.light_pos[e * 3 + 2] + 1};
+    double ll = sqrt(lp[0] * lp[0] + lp[1] * lp[1] + lp[2] * lp[2]);
+    float L[3], amb[3], dif[3], bcol[3];
+    for (int k = 0; k < 3; k++) {
+        L[k] = (float)(lp[k] / ll); amb[k] = (float)d.light_ambient[e * 3 + k]; dif[k] = (float)d.light_color[e * 3 + k];
+        bcol[k] = (float)d.box_color[e * 3 + k];
+        fc[FC_SKY + k] = (float)d.sky_color[e * 3 + k];
+    }
+    const float white[3] = {1, 1, 1};
+    lit_color(L, amb, dif, 0, 1, 0, white, fc + FC_LIT_FLOOR);
+    lit_color(L, amb, dif, 0, -1, 0, white, fc + FC_LIT_CEIL);
+    lit_color(L, amb, dif, -1, 0, 0, white, fc + FC_LIT_WALL + 0);
+    lit_color(L, amb, dif, 0, 0, 1, white, fc + FC_LIT_WALL + 3);
+    lit_color(L, amb, dif, 1, 0, 0, white, fc + FC_LIT_WALL + 6);
+    lit_color(L, amb, dif, 0, 0, -1, white, fc + FC_LIT_WALL + 9);
+    double bdir = d.box_dir[e];
+    float bc = (float)cos(bdir), bs = (float)sin(bdir);
+    const float ln[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+    for (int k = 0; k < 6; k++)   // world normal = R_y(dir) n_local (glRotatef about +Y)
+        lit_color(L, amb, dif, ln[k][0] * bc + ln[k][2] * bs, ln[k][1], -ln[k][0] * bs + ln[k][2] * bc, bcol, fc + FC_LIT_BOX + 3 * k);
+    float bpos[3] = {(float)d.box_x[e], 0.0f, (float)d.box_z[e]};
+    float hx = (float)(0.8 / 2), hz = (float)(0.8 / 2), sy = (float)0.8;
+    fc[FC_BOX_POS] = bpos[0]; fc[FC_BOX_POS + 1] = bpos[1]; fc[FC_BOX_POS + 2] = bpos[2];
+    fc[FC_BOX_C] = bc; fc[FC_BOX_S] = bs; fc[FC_BOX_HX] = hx; fc[FC_BOX_HZ] = hz; fc[FC_BOX_SY] = sy;
+    float ro[3] = {eye[0] - bpos[0], eye[1] - bpos[1], eye[2] - bpos[2]};
+    fc[FC_BOX_LO] = ro[0] * bc - ro[2] * bs; fc[FC_BOX_LO + 1] = ro[1]; fc[FC_BOX_LO + 2] = ro[0] * bs + ro[2] * bc;
+    // conservative bounding sphere of the box for ray culling (radius inflated 2 %)
+    float oc[3] = {bpos[0] - eye[0], 0.5f * sy - eye[1], bpos[2] - eye[2]};
+    float R = 1.02f * sqrtf(hx * hx + 0.25f * sy * sy + hz * hz);
+    fc[FC_CULL_OC] = oc[0]; fc[FC_CULL_OC + 1] = oc[1]; fc[FC_CULL_OC + 2] = oc[2];
+    fc[FC_CULL_CC] = (oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2]) - R * R;
+}
+
+// ================================================================================ render kernel
+__constant__ float c_sample_x[8] = {1 * 0.0625f, -1 * 0.0625f, 5 * 0.0625f, -3 * 0.0625f, -5 * 0.0625f, -7 * 0.0625f, 3 * 0.0625f, 7 * 0.0625f};
+__constant__ float c_sample_y[8] = {-3 * 0.0625f, 3 * 0.0625f, 1 * 0.0625f, -5 * 0.0625f, 5 * 0.0625f, -1 * 0.0625f, 7 * 0.0625f, -7 * 0.0625f};
+
+#define KIND_SKY 0u
+#define KIND_FLOOR 1u
+#define KIND_CEIL 2u
+#define KIND_WALL 3u
+#define KIND_BOX 4u
+#define MAKE_KEY(kind, side, room) ((uint32_t)(kind) | ((uint32_t)(side) << 3) | ((uint32_t)(room) << 6))
+
+struct Cam {
+    float eye[3], F[3], S[3], U[3], TW, TH, invW, invH, Wf, Hf;
+};
+
+__device__ __forceinline__ void make_ray(const Cam &c, float wx, float wy, float *dv) {
+    float nx = (2.0f * wx - c.Wf) * c.invW, ny = (2.0f * wy - c.Hf) * c.invH;
+    float ax = nx * c.TW, ay = ny * c.TH;
+#pragma unroll
+    for (int k = 0; k < 3; k++) dv[k] = fmaf(c.U[k], ay, fmaf(c.S[k], ax, c.F[k]));
+}
+
+// portal traversal of the LDS room table: nearest opaque surface along (eye, d)
+__device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms, int n_rooms, int room, const float *o,
+                                                const float *dv, float &t_hit) {
+    t_hit = INFINITY;
+    if (room < 0) return MAKE_KEY(KIND_SKY, 0, 0);
+    float ix = dv[0] != 0 ? 1.0f / dv[0] : 0.0f, iy = dv[1] != 0 ? 1.0f / dv[1] : 0.0f, iz = dv[2] != 0 ? 1.0f / dv[2] : 0.0f;
+    for (int iter = 0; iter <= n_rooms; iter++) {
+        const float *r = rooms + room * MWB_ROOM_WORDS;
+        float4 rect = *(const float4 *)(r + RW_MINX);   // min_x max_x min_z max_z
+        float height = r[RW_HEIGHT];
+        float tx = INFINITY, tz = INFINITY;
+        int sx = 0, sz = 1;
+        if (dv[0] > 0) { tx = (rect.y - o[0]) * ix; sx = 0; } else if (dv[0] < 0) { tx = (rect.x - o[0]) * ix; sx = 2; }
+        if (dv[2] > 0) { tz = (rect.w - o[2]) * iz; sz = 3; } else if (dv[2] < 0) { tz = (rect.z - o[2]) * iz; sz = 1; }
+        float ts; int s;
+        if (tx <= tz) { ts = tx; s = sx; } else { ts = tz; s = sz; }
+        if (dv[1] < 0) { float tf = (0.0f - o[1]) * iy; if (tf <= ts) { t_hit = tf; return MAKE_KEY(KIND_FLOOR, 0, room); } }
+        if (dv[1] > 0) { float tc = (height - o[1]) * iy; if (tc <= ts) { t_hit = tc; return MAKE_KEY(KIND_CEIL, 0, room); } }
+        if (!(ts < INFINITY)) return MAKE_KEY(KIND_SKY, 0, 0);
+        const float *sd = r + RW_SIDE0 + 8 * s;
+        float4 port = *(const float4 *)(sd);   // lo hi min_y max_y
+        int nbr = __float_as_int(sd[RS_NBR]);
+        float hc = (s == 0 || s == 2) ? fmaf(ts, dv[2], o[2]) : fmaf(ts, dv[0], o[0]);
+        float y = fmaf(ts, dv[1], o[1]);
+        if (nbr >= 0 && port.x < hc && hc < port.y && port.z < y && y < port.w) { room = nbr; continue; }
+        t_hit = ts;
+        return MAKE_KEY(KIND_WALL, s, room);
+    }
+    return MAKE_KEY(KIND_SKY, 0, 0);
+}
+
+// slab test in box-local axes; returns face 0..5 (-x,+x,-y,+y,-z,+z) or -1
+__device__ __forceinline__ int trace_box(const float *fc, const float *dv, float &t_out) {
+    float c = fc[FC_BOX_C], s = fc[FC_BOX_S];
+    float ld[3] = {fmaf(dv[0], c, -(dv[2] * s)), dv[1], fmaf(dv[0], s, dv[2] * c)};
+    float lo_[3] = {fc[FC_BOX_LO], fc[FC_BOX_LO + 1], fc[FC_BOX_LO + 2]};
+    float lo[3] = {-fc[FC_BOX_HX], 0.0f, -fc[FC_BOX_HZ]}, hi[3] = {fc[FC_BOX_HX], fc[FC_BOX_SY], fc[FC_BOX_HZ]};
+    float tn = -INFINITY, tf = INFINITY;
+    int face = -1;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        if (ld[a] == 0) { if (lo_[a] < lo[a] || lo_[a] > hi[a]) return -1; continue; }
+        float inv = 1.0f / ld[a];
+        float t1 = (lo[a] - lo_[a]) * inv, t2 = (hi[a] - lo_[a]) * inv;
+        float tmin = t1 < t2 ? t1 : t2, tmax = t1 < t2 ? t2 : t1;
+        if (tmin > tn) { tn = tmin; face = a * 2 + (ld[a] > 0 ? 0 : 1); }
+        if (tmax < tf) tf = tmax;
+    }
+    if (face < 0 || !(tn <= tf) || !(tn > 0)) return -1;
+    t_out = tn;
+    return face;
+}
+
+struct TexLds { int w, h, n_levels; float sc_s, sc_t; int pad[3]; uint32_t off[MWB_MAX_LEVELS]; };
+static_assert(sizeof(TexLds) == sizeof(MwbTexDesc), "TexLds mirrors MwbTexDesc");
+
+__device__ __forceinline__ int imod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
+
+__device__ __forceinline__ void bilinear(const uint32_t *__restrict__ texels, uint32_t off, int w, int h, float s, float t, float *rgb) {
+    float uu = s * (float)w - 0.5f, vv = t * (float)h - 0.5f;
+    float fu = floorf(uu), fv = floorf(vv);
+    float a = uu - fu, b = vv - fv;
+    int i0 = (int)fu, j0 = (int)fv;
+    // s,t in [0,1): i0 in [-1, w-1]; wrap with compares instead of integer division
+    int i1 = i0 + 1; if (i1 >= w) i1 -= w; if (i0 < 0) i0 += w;
+    int j1 = j0 + 1; if (j1 >= h) j1 -= h; if (j0 < 0) j0 += h;
+    uint32_t t00 = texels[off + j0 * w + i0], t10 = texels[off + j0 * w + i1];
+    uint32_t t01 = texels[off + j1 * w + i0], t11 = texels[off + j1 * w + i1];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float c00 = (float)((t00 >> (8 * k)) & 255u), c10 = (float)((t10 >> (8 * k)) & 255u);
+        float c01 = (float)((t01 >> (8 * k)) & 255u), c11 = (float)((t11 >> (8 * k)) & 255u);
+        float top = c00 * (1.0f - a) + c10 * a, bot = c01 * (1.0f - a) + c11 * a;
+        rgb[k] = top * (1.0f - b) + bot * b;
+    }
+}
+
+__device__ __forceinline__ void sample_texture(const uint32_t *__restrict__ texels, const TexLds &T, float s, float t, float sx,
+                                               float tx, float sy, float ty, bool valid, float *rgb) {
+    int maxl = T.n_levels - 1;
+    float lambda;
+    if (!valid) lambda = (float)maxl;
+    else {
+        float dsdx = (sx - s) * (float)T.w, dtdx = (tx - t) * (float)T.h;
+        float dsdy = (sy - s) * (float)T.w, dtdy = (ty - t) * (float)T.h;
+        float r1 = dsdx * dsdx + dtdx * dtdx, r2 = dsdy * dsdy + dtdy * dtdy;
+        float rho2 = r1 > r2 ? r1 : r2;
+        if (!(rho2 < INFINITY)) lambda = (float)maxl;
+        else if (rho2 <= 1.0f) lambda = 0.0f;
+        else lambda = 0.5f * log2f(rho2);
+    }
+    float ws = s - floorf(s), wt = t - floorf(t);   // GL_REPEAT
+    if (lambda <= 0.0f) { bilinear(texels, T.off[0], T.w, T.h, ws, wt, rgb); return; }
+    float fl = floorf(lambda);
+    int l0 = (int)fl; if (l0 > maxl) l0 = maxl;
+    int l1 = l0 + 1 > maxl ? maxl : l0 + 1;
+    float fr = l0 == maxl ? 0.0f : lambda - fl;
+    float c0[3], c1[3];
+    int w0 = T.w >> l0; if (w0 < 1) w0 = 1;
+    int h0 = T.h >> l0; if (h0 < 1) h0 = 1;
+    bilinear(texels, T.off[l0], w0, h0, ws, wt, c0);
+    if (l1 == l0 || fr == 0.0f) { rgb[0] = c0[0]; rgb[1] = c0[1]; rgb[2] = c0[2]; return; }
+    int w1 = T.w >> l1; if (w1 < 1) w1 = 1;
+    int h1 = T.h >> l1; if (h1 < 1) h1 = 1;
+    bilinear(texels, T.off[l1], w1, h1, ws, wt, c1);
+#pragma unroll
+    for (int k = 0; k < 3; k++) rgb[k] = c0[k] * (1.0f - fr) + c1[k] * fr;
+}
+
+// texture coordinates where ray (eye, dv) meets the plane of surface `key`; false if behind
+__device__ __forceinline__ bool surf_texcoord(const float *__restrict__ rooms, uint32_t key, const float *o, const float *dv,
+                                              float sc_s, float sc_t, float &s, float &t) {
+    uint32_t kind = key & 7u, side = (key >> 3) & 7u;
+    const float *r = rooms + (key >> 6) * MWB_ROOM_WORDS;
+    if (kind == KIND_FLOOR || kind == KIND_CEIL) {
+        float py = kind == KIND_FLOOR ? 0.0f : r[RW_HEIGHT];
+        if (dv[1] == 0) return false;
+        float tt = (py - o[1]) / dv[1];
+        if (!(tt > 0)) return false;
+        s = (o[0] + tt * dv[0]) * sc_s; t = (o[2] + tt * dv[2]) * sc_t;
+        return true;
+    }
+    float plane, od, oo;
+    int along;
+    if (side == 0 || side == 2) { plane = side == 0 ? r[RW_MAXX] : r[RW_MINX]; od = dv[0]; oo = o[0]; along = 2; }
+    else { plane = side == 3 ? r[RW_MAXZ] : r[RW_MINZ]; od = dv[2]; oo = o[2]; along = 0; }
+    if (od == 0) return false;
+    float tt = (plane - oo) / od;
+    if (!(tt > 0)) return false;
+    float hc = (along == 2 ? o[2] + tt * dv[2] : o[0] + tt * dv[0]), y = o[1] + tt * dv[1];
+    const float *sd = r + RW_SIDE0 + 8 * side;
+    s = ((hc - sd[RS_UORG]) * sd[RS_USGN]) * sc_s; t = y * sc_t;
+    return true;
+}
+
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) render_kernel(MwbDev d) {
+    const int e = blockIdx.x;
+    const int tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = d.W, H = d.H;
+    int n_rooms = d.n_rooms[e];
+    if (n_rooms < 0) n_rooms = 0;
+    float *rooms = (float *)smem;
+    size_t off = ((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15;
+    float *fc = (float *)(smem + off); off += MWB_FRAME_WORDS * 4;
+    TexLds *tex = (TexLds *)(smem + off); off += sizeof(TexLds) * MWB_MAX_TEX;
+    int *cam_room_s = (int *)(smem + off); off += 16;
+    uint8_t *fb = smem + off;
+
+    {   // stage the room table, the frame constants and the texture descriptors
+        const float4 *src = (const float4 *)(d.rooms + (size_t)e * d.R_max * MWB_ROOM_WORDS);
+        float4 *dst = (float4 *)rooms;
+        for (int i = tid; i < n_rooms * (MWB_ROOM_WORDS / 4); i += THREADS) dst[i] = src[i];
+        const float *fsrc = d.frame + (size_t)e * MWB_FRAME_WORDS;
+        for (int i = tid; i < MWB_FRAME_WORDS; i += THREADS) fc[i] = fsrc[i];
+        const uint32_t *tsrc = (const uint32_t *)d.tex_desc;
+        uint32_t *tdst = (uint32_t *)tex;
+        for (int i = tid; i < (int)(sizeof(TexLds) * MWB_MAX_TEX / 4); i += THREADS) tdst[i] = tsrc[i];
+        if (tid == 0) *cam_room_s = 0x7fffffff;
+    }
+    __syncthreads();
+    Cam cam;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { cam.eye[k] = fc[FC_EYE + k]; cam.F[k] = fc[FC_F + k]; cam.S[k] = fc[FC_S + k]; cam.U[k] = fc[FC_U + k]; }
+    cam.TW = fc[FC_TW]; cam.TH = fc[FC_TH];
+    cam.Wf = (float)W; cam.Hf = (float)H; cam.invW = 1.0f / (float)W; cam.invH = 1.0f / (float)H;
+    // room containing the eye: first (lowest index) rectangle that holds it, bounds inclusive
+    for (int i = tid; i < n_rooms; i += THREADS) {
+        const float *r = rooms + i * MWB_ROOM_WORDS;
+        if (cam.eye[0] >= r[RW_MINX] && cam.eye[0] <= r[RW_MAXX] && cam.eye[2] >= r[RW_MINZ] && cam.eye[2] <= r[RW_MAXZ])
+            atomicMin(cam_room_s, i);
+    }
+    __syncthreads();
+    int cam_room = *cam_room_s;
+    if (cam_room == 0x7fffffff) cam_room = -1;
+
+    const float zn = 0.04f, zf = 100.0f;   // gluPerspective near / far, miniworld.py:1186-1187
+    const float zA = (zf + zn) / (zf - zn), zB = (2.0f * zf * zn) / (zf - zn);
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 3) / 4;
+    const int n_tiles = tiles_x * tiles_y;
+    const int wave = tid / WAVE, lane = tid % WAVE, n_waves = THREADS / WAVE;
+    const float cull_cc = fc[FC_CULL_CC];
+
+    for (int tile = wave; tile < n_tiles; tile += n_waves) {
+        int px = (tile % tiles_x) * 16 + (lane & 15), py = (tile / tiles_x) * 4 + (lane >> 4);
+        bool active = px < W && py < H;
+        if (!active) continue;
+        float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
+        uint32_t keys[8];
+        float t0 = INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            float dv[3], th;
+            make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
+            uint32_t key = trace_rooms(rooms, n_rooms, cam_room, cam.eye, dv, th);
+            // conservative sphere cull, then the exact slab test
+            float b = dv[0] * fc[FC_CULL_OC] + dv[1] * fc[FC_CULL_OC + 1] + dv[2] * fc[FC_CULL_OC + 2];
+            float dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+            if (cull_cc <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc)) {
+                float tb;
+                int face = trace_box(fc, dv, tb);
+                if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, 0); th = tb; }
+            }
+            keys[k] = key;
+            if (k == 0) t0 = th;
+        }
+        float dc[3], dx[3], dy[3];
+        make_ray(cam, cx, cy, dc);
+        make_ray(cam, cx + 1.0f, cy, dx);
+        make_ray(cam, cx, cy + 1.0f, dy);
+        float acc[3] = {0, 0, 0};
+        uint32_t rem = 0xFFu;
+        while (rem) {
+            int k = __ffs(rem) - 1;
+            uint32_t key = keys[0];
+#pragma unroll
+            for (int j = 1; j < 8; j++) key = (k == j) ? keys[j] : key;
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) m |= (keys[j] == key ? 1u : 0u) << j;
+            m &= rem;
+            rem &= ~m;
+            float cnt = (float)__popc(m);
+            float col[3];
+            uint32_t kind = key & 7u;
+            if (kind == KIND_SKY) { col[0] = fc[FC_SKY]; col[1] = fc[FC_SKY + 1]; col[2] = fc[FC_SKY + 2]; }
+            else if (kind == KIND_BOX) {
+                const float *lb = fc + FC_LIT_BOX + 3 * ((key >> 3) & 7u);
+                col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2];
+            } else {
+                const float *r = rooms + (key >> 6) * MWB_ROOM_WORDS;
+                uint32_t texw = (uint32_t)__float_as_int(r[RW_TEX]);
+                int tex_id = kind == KIND_FLOOR ? (texw >> 8) & 255u : kind == KIND_CEIL ? (texw >> 16) & 255u : texw & 255u;
+                const TexLds &T = tex[tex_id];
+                const float *lit = kind == KIND_FLOOR ? fc + FC_LIT_FLOOR : kind == KIND_CEIL ? fc + FC_LIT_CEIL
+                                                                                               : fc + FC_LIT_WALL + 3 * ((key >> 3) & 7u);
+                float sc_s = T.sc_s, sc_t = T.sc_t;   // TEX_DENSITY / texture size, miniworld.py:17,30-31
+                float s0, t0_, s1, t1, s2, t2;
+                bool valid;
+                if (!surf_texcoord(rooms, key, cam.eye, dc, sc_s, sc_t, s0, t0_)) {
+                    float dv[3];   // centre ray misses the plane: shade at the sample's own hit point
+                    make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
+                    surf_texcoord(rooms, key, cam.eye, dv, sc_s, sc_t, s0, t0_);
+                    valid = false; s1 = s2 = s0; t1 = t2 = t0_;
+                } else {
+                    bool v1 = surf_texcoord(rooms, key, cam.eye, dx, sc_s, sc_t, s1, t1);
+                    bool v2 = surf_texcoord(rooms, key, cam.eye, dy, sc_s, sc_t, s2, t2);
+                    valid = v1 && v2;
+                }
+                float texel[3];
+                sample_texture(d.texels, T, s0, t0_, s1, t1, s2, t2, valid, texel);
+#pragma unroll
+                for (int q = 0; q < 3; q++) col[q] = lit[q] * (texel[q] * (1.0f / 255.0f));
+            }
+#pragma unroll
+            for (int q = 0; q < 3; q++) acc[q] += cnt * col[q];
+        }
+        uint8_t out[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            float v = acc[q] * 0.125f;
+            v = v < 0 ? 0 : (v > 1 ? 1 : v);
+            out[q] = (uint8_t)(int)floorf(v * 255.0f + 0.5f);   // RGBA32F -> unorm8 resolve
+        }
+        if (d.layout == MWB_LAYOUT_HWC) {
+            uint8_t *p = fb + (py * W + px) * 3;
+            p[0] = out[0]; p[1] = out[1]; p[2] = out[2];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; q++) fb[(q * W + px) * H + py] = out[q];
+        }
+        if (d.want_depth) {
+            int z16 = 65535;   // DEPTH_COMPONENT16 of sample 0; cleared to 1.0 where nothing was drawn
+            if ((keys[0] & 7u) != KIND_SKY) {
+                float zndc = zA - zB / t0;
+                float dd = 0.5f * zndc + 0.5f;
+                int z = (int)floorf(dd * 65535.0f + 0.5f);
+                z16 = z < 0 ? 0 : (z > 65535 ? 65535 : z);
+            }
+            // get_depth_map, opengl.py:362-367 in float32
+            float dm = (float)z16 / 65535.0f;
+            float clip_z = (dm - 0.5f) * 2.0f;
+            float wz = (float)(-2.0 * 100.0 * 0.04) / (clip_z * (float)(100.0 - 0.04) - (float)(100.0 + 0.04));
+            d.depth[(size_t)e * W * H + py * W + px] = wz;
+        }
+    }
+    __syncthreads();
+    {   // framebuffer LDS -> HBM, 16 bytes per lane
+        const int nbytes = W * H * 3;
+        uint8_t *dst = d.obs + (size_t)e * nbytes;
+        if ((nbytes & 15) == 0) {
+            const uint4 *s4 = (const uint4 *)fb;
+            uint4 *d4 = (uint4 *)dst;
+            for (int i = tid; i < nbytes / 16; i += THREADS) d4[i] = s4[i];
+        } else {
+            for (int i = tid; i < nbytes; i += THREADS) dst[i] = fb[i];
+        }
+    }
+}
+
+// ============================================================================== small utilities
+__global__ void intersect_kernel(MwbDev d, int e, double x, double z, double radius, int *result) {
+    // MiniWorldEnv.intersect(agent, pos, radius), miniworld.py:933-959
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double *sg = d.segs + (size_t)e * d.S_max * 4;
+    int ns = d.n_segs[e], res = 0;
+    for (int i = 0; i < ns && !res; i++) if (seg_hit(sg + i * 4, x, z, radius)) res = 1;
+    if (!res) {
+        double ddx = d.box_x[e] - x, ddz = d.box_z[e] - z;
+        if (sqrt(ddx * ddx + 0.0 + ddz * ddz) < radius + box_radius()) res = 2;
+    }
+    *result = res;
+}
+
+// ====================================================================================== launch
+size_t mwb_reset_lds_bytes(const MwbDev &d) {
+    size_t b = (size_t)d.R_max * sizeof(WRoom) + (size_t)d.S_max * 4 * sizeof(double) + (size_t)d.R_max * sizeof(double) +
+               (size_t)((d.R_max + 3) & ~3) * sizeof(int) + 624 * sizeof(uint32_t);
+    return (b + 15) & ~(size_t)15;
+}
+size_t mwb_render_lds_bytes(const MwbDev &d) {
+    size_t b = (((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15) + MWB_FRAME_WORDS * 4 + sizeof(TexLds) * MWB_MAX_TEX + 16 +
+               (size_t)d.W * d.H * 3;
+    return (b + 15) & ~(size_t)15;
+}
+
+void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *skip, hipStream_t s) {
+    hipLaunchKernelGGL(step_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d, actions, skip);
+}
+void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s) {
+    hipLaunchKernelGGL(mark_reset_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d, mask);
+}
+void mwb_launch_reset(const MwbDev &d, hipStream_t s) {
+    hipLaunchKernelGGL(reset_kernel, dim3(d.N), dim3(WAVE), mwb_reset_lds_bytes(d), s, d);
+}
+void mwb_launch_prep(const MwbDev &d, hipStream_t s) {
+    hipLaunchKernelGGL(prep_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d);
+}
+void mwb_launch_render(const MwbDev &d, hipStream_t s) {
+    render_kernel<256><<<dim3(d.N), dim3(256), mwb_render_lds_bytes(d), s>>>(d);
+}
+void mwb_launch_intersect(const MwbDev &d, int env, double x, double z, double radius, int *result_dev, hipStream_t s) {
+    hipLaunchKernelGGL(intersect_kernel, dim3(1), dim3(64), 0, s, d, env, x, z, radius, result_dev);
+}

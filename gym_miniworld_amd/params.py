@@ -1,0 +1,75 @@
+"""Domain-randomisation parameter table with the interface of the reference's
+gym_miniworld/params.py:10-123 (DomainParams.set / get_max / no_random / copy, DEFAULT_PARAMS),
+so code that customises `params=` for a reference env (e.g. envs/oneroom.py:52-66) keeps working.
+The table is handed to the HIP library as 13 x (default[3], min[3], max[3]) doubles; sampling
+itself happens on the GPU from each env's MT19937 stream.
+"""
+from collections import namedtuple
+from copy import deepcopy
+
+import numpy as np
+
+DomainParam = namedtuple("DomainParam", ["default", "min", "max", "type"])
+
+# order of the C ABI table (include/miniworld_batch.h MWB_P_*), same as params.py:110-123
+PARAM_ORDER = ["sky_color", "light_pos", "light_color", "light_ambient", "obj_color_bias", "forward_step",
+               "forward_drift", "turn_step", "bot_radius", "cam_pitch", "cam_fov_y", "cam_height", "cam_fwd_disp"]
+
+
+class DomainParams:
+    def __init__(self):
+        self.params = {}
+
+    def copy(self):
+        return deepcopy(self)
+
+    def no_random(self):
+        c = self.copy()
+        for name, p in c.params.items():
+            c.params[name] = DomainParam(p.default, p.default, p.default, p.type)
+        return c
+
+    def set(self, name, default, min=None, max=None, type="float"):
+        conv = lambda v: np.array(v, dtype=float) if isinstance(v, (list, tuple, np.ndarray)) else v  # noqa: E731
+        default, min, max = conv(default), conv(min), conv(max)
+        if min is None:
+            min = default
+        if max is None:
+            max = default
+        assert np.all(np.greater_equal(max, default)) and np.all(np.greater_equal(default, min))
+        if name in self.params:
+            assert type == self.params[name].type
+            assert np.shape(default) == np.shape(self.params[name].default)
+        self.params[name] = DomainParam(default, min, max, type)
+
+    def get_max(self, name):
+        assert name in self.params, name
+        return self.params[name].max
+
+    def to_table(self):
+        """-> float64 [13, 9] (default[3], min[3], max[3]) for mwb_config.params"""
+        t = np.zeros((len(PARAM_ORDER), 9))
+        for i, name in enumerate(PARAM_ORDER):
+            p = self.params[name]
+            if p.type != "float":
+                raise NotImplementedError("only float parameters exist in the reference table")
+            for j, v in enumerate((p.default, p.min, p.max)):
+                v = np.atleast_1d(np.asarray(v, dtype=float))
+                t[i, j * 3:j * 3 + len(v)] = v
+        return t
+
+
+DEFAULT_PARAMS = DomainParams()
+DEFAULT_PARAMS.set("sky_color", [0.25, 0.82, 1], [0.1, 0.1, 0.1], [1.0, 1.0, 1.0])
+DEFAULT_PARAMS.set("light_pos", [0, 2.5, 0], [-40, 2.5, -40], [40, 5, 40])
+DEFAULT_PARAMS.set("light_color", [0.7, 0.7, 0.7], [0.45, 0.45, 0.45], [0.8, 0.8, 0.8])
+DEFAULT_PARAMS.set("light_ambient", [0.45, 0.45, 0.45], [0.35, 0.35, 0.35], [0.55, 0.55, 0.55])
+DEFAULT_PARAMS.set("obj_color_bias", [0, 0, 0], [-0.2, -0.2, -0.2], [0.2, 0.2, 0.2])
+DEFAULT_PARAMS.set("forward_step", 0.15, 0.12, 0.17)
+DEFAULT_PARAMS.set("forward_drift", 0, -0.05, 0.05)
+DEFAULT_PARAMS.set("turn_step", 15, 10, 20)
+DEFAULT_PARAMS.set("bot_radius", 0.4, 0.38, 0.42)
+DEFAULT_PARAMS.set("cam_pitch", 0, -5, 5)
+DEFAULT_PARAMS.set("cam_fov_y", 60, 55, 65)
+DEFAULT_PARAMS.set("cam_height", 1.5, 1.45, 1.55)
+DEFAULT_PARAMS.set("cam_fwd_disp", 0, -0.05, 0.10)

@@ -1,0 +1,147 @@
+/* miniworld_batch.h - C ABI of the MI355X-native batched MiniWorld stepper + renderer.
+ *
+ * The reference (mjsargent/gym-miniworld) is pure Python and has no FFI for this path; its
+ * boundary is two Python protocols.  Each entry point below names the reference
+ * interface it replaces (file:line under the reference root); the Python binding a maintainer
+ * would add is shown in INTEGRATION.md and implemented in gym_miniworld_amd/batch.py.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * MWB_E* code, with a message retrievable through mwb_last_error(); no exception crosses the
+ * ABI.  One handle owns the state of `num_envs` environments on one GPU; a handle is not
+ * thread-safe.  Device work is enqueued on the caller's HIP stream (void* = hipStream_t) and is
+ * asynchronous unless stated; outputs are library-owned device buffers that stay valid and are
+ * overwritten by the next mwb_step / mwb_reset / mwb_render on the same handle.
+ */
+#ifndef MINIWORLD_BATCH_H
+#define MINIWORLD_BATCH_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MWB_ABI_VERSION 1
+
+enum { MWB_OK = 0, MWB_EINVAL = -1, MWB_EHIP = -2, MWB_ENOMEM = -3, MWB_ESTATE = -4 };
+
+/* tasks: the reference env classes registered as MiniWorld-<Class>-v0 (envs/__init__.py:43-49) */
+enum { MWB_TASK_HALLWAY = 0,   /* envs/hallway.py   task_args = {length}                    */
+       MWB_TASK_ONEROOM = 1,   /* envs/oneroom.py   task_args = {size}                      */
+       MWB_TASK_FOURROOMS = 2, /* envs/fourrooms.py task_args = {}                          */
+       MWB_TASK_MAZE = 3 };    /* envs/maze.py      task_args = {num_rows,num_cols,room_size} */
+
+/* observation layouts */
+enum { MWB_LAYOUT_HWC = 0,  /* [N,H,W,3]  MiniWorldEnv.observation_space, miniworld.py:473-478 */
+       MWB_LAYOUT_CWH = 1 }; /* [N,3,W,H]  after TransposeImage, pytorch-a2c-ppo-acktr/envs.py:96-107 */
+
+/* domain parameters in the order of the reference table params.py:110-123 */
+enum { MWB_P_SKY_COLOR = 0, MWB_P_LIGHT_POS, MWB_P_LIGHT_COLOR, MWB_P_LIGHT_AMBIENT, MWB_P_OBJ_COLOR_BIAS,
+       MWB_P_FORWARD_STEP, MWB_P_FORWARD_DRIFT, MWB_P_TURN_STEP, MWB_P_BOT_RADIUS, MWB_P_CAM_PITCH,
+       MWB_P_CAM_FOV_Y, MWB_P_CAM_HEIGHT, MWB_P_CAM_FWD_DISP, MWB_NPARAM };
+
+/* Constructor arguments: MiniWorldEnv.__init__ kwargs (miniworld.py:456-465) + the task class'
+ * own kwargs + batch size / device. */
+typedef struct mwb_config {
+    int32_t abi_version;       /* MWB_ABI_VERSION */
+    int32_t task;              /* MWB_TASK_* */
+    int32_t num_envs;          /* environments owned by this handle (this GPU's shard) */
+    int32_t obs_width;         /* 80  (miniworld.py:459) */
+    int32_t obs_height;        /* 60  (miniworld.py:460) */
+    int32_t want_depth;        /* also produce render_depth() maps (miniworld.py:1207-1220) */
+    int32_t layout;            /* MWB_LAYOUT_* of the observation batch */
+    int32_t domain_rand;       /* miniworld.py:464 */
+    int32_t max_episode_steps; /* <= 0: the task's default (hallway.py:18, oneroom.py:14, ...) */
+    int32_t device;            /* HIP device ordinal */
+    double task_args[4];       /* see MWB_TASK_*; 0 = the class default */
+    int32_t use_default_params; /* 1: params.py:110-123 DEFAULT_PARAMS; 0: `params` below */
+    int32_t reserved;
+    double params[MWB_NPARAM][9]; /* default[3], min[3], max[3] per parameter (DomainParams.set) */
+} mwb_config;
+
+typedef struct mwb_handle mwb_handle;
+
+/* library-owned device buffers produced by mwb_reset / mwb_step / mwb_render */
+typedef struct mwb_outputs {
+    uint8_t *obs;       /* u8, layout per config: [N,H,W,3] or [N,3,W,H]                         */
+    float *depth;       /* f32 [N,H,W] metres (get_depth_map, opengl.py:336-371) or NULL         */
+    float *reward;      /* f32 [N]  (VecPyTorch.step_wait casts to float32, envs.py:129)          */
+    double *reward64;   /* f64 [N]  the reference's Python float, for bit-exact checks            */
+    uint8_t *done;      /* u8  [N]                                                                */
+    int32_t *ep_steps;  /* i32 [N]  step_count of the transition just taken (before auto-reset)   */
+    size_t obs_bytes, depth_bytes;
+} mwb_outputs;
+
+/* host-side snapshot of the simulator state of a contiguous env range, for tests / debugging;
+ * every pointer may be NULL to skip that field. Arrays are [count] or [count][3]. */
+typedef struct mwb_state {
+    double *agent_pos;  /* [count][3] Entity.pos (entity.py:22-24), y = 0 */
+    double *agent_dir;  /* [count]    Entity.dir                          */
+    double *box_pos;    /* [count][3] */
+    double *box_dir;    /* [count]    */
+    double *box_color;  /* [count][3] Box.color_vec (entity.py:381-383)   */
+    double *cam;        /* [count][4] cam_height, cam_fwd_disp, cam_pitch, cam_fov_y (entity.py:486-492) */
+    double *sky_color, *light_pos, *light_color, *light_ambient; /* [count][3] (miniworld.py:561-566) */
+    int32_t *step_count;    /* [count] miniworld.py:539,663 */
+    int32_t *rng_pos;       /* [count] MT19937 position (RandomState.get_state()[2]) */
+    uint32_t *rng_keysum;   /* [count] sum of the 624 key words mod 2^32 */
+    int32_t *n_rooms;       /* [count] */
+    int32_t *n_segs;        /* [count] */
+} mwb_state;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+/* replaces: gym.make('MiniWorld-<Class>-v0') x N + SubprocVecEnv.__init__
+ * (envs/__init__.py:43-49, pytorch-a2c-ppo-acktr/envs.py:57-63, vec_env/subproc_vec_env.py:36-56) */
+int mwb_create(const mwb_config *cfg, mwb_handle **out);
+/* replaces: SubprocVecEnv.close (vec_env/subproc_vec_env.py:87-97) */
+int mwb_destroy(mwb_handle *h);
+const char *mwb_last_error(void);
+int mwb_abi_version(void);
+
+/* ---- assets ------------------------------------------------------------------------------ */
+/* replaces: Texture.load (opengl.py:71-108): upload RGB8 pixels (row 0 = TOP of the image, tightly
+ * packed) for texture slot `tex_id` (0 floor_tiles_bw_1, 1-4 concrete_1..4, 5 concrete_tiles_1,
+ * 6 brick_wall_1); the library builds the mip chain.  Must precede the first render. Synchronous. */
+int mwb_set_texture(mwb_handle *h, int tex_id, int width, int height, const uint8_t *rgb);
+
+/* ---- simulation -------------------------------------------------------------------------- */
+/* replaces: env.seed(seed + rank) per worker (envs.py:35-36, miniworld.py:528-530, random.py:9-10).
+ * seeds: host array [num_envs]. Synchronous (host-side key hashing + upload). */
+int mwb_seed(mwb_handle *h, const uint64_t *seeds);
+/* replaces: VecEnv.reset (vec_env/subproc_vec_env.py:77-80 -> MiniWorldEnv.reset miniworld.py:532-592)
+ * mask: device u8[num_envs] or NULL; NULL or mask[i]!=0 resets env i. Renders the first observation. */
+int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream);
+/* replaces: VecEnv.step_async+step_wait (vec_env/subproc_vec_env.py:58-75, worker 5-14,26-31 ->
+ * MiniWorldEnv.step miniworld.py:658-716 + task rule e.g. envs/maze.py:106-113), including the
+ * worker's auto-reset and the fork's `mask` ('dummy') semantics.
+ * actions: device i32[num_envs]; skip_mask: device u8[num_envs] or NULL (mask[i]!=0 -> env i is not
+ * stepped, reward -99, done 0, observation re-rendered). */
+int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask_dev, void *stream);
+/* replaces: MiniWorldEnv.render_obs / render_depth (miniworld.py:1160-1220) for the whole batch */
+int mwb_render(mwb_handle *h, void *stream);
+int mwb_get_outputs(mwb_handle *h, mwb_outputs *out);
+
+/* ---- introspection (tests, Gym single-env view) ------------------------------------------- */
+int mwb_get_state(mwb_handle *h, int first_env, int count, mwb_state *out);          /* synchronous */
+/* overwrite pose / step counter of env range (NULL = leave); used to inject oracle states */
+int mwb_set_agent(mwb_handle *h, int first_env, int count, const double *pos_xz, const double *dir,
+                  const int32_t *step_count);
+/* replaces: MiniWorldEnv.intersect(agent, pos, radius) (miniworld.py:933-959) for one env; result
+ * 0 none, 1 wall, 2 box. Synchronous. */
+int mwb_intersect(mwb_handle *h, int env, double x, double z, double radius, int *result);
+/* geometry of one env as the kernels see it: n_rooms x MWB_ROOM_WORDS f32 words and n_segs x 4 f64 */
+#define MWB_ROOM_WORDS 40
+int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_rooms, double *segs, int max_segs,
+                     int *n_rooms, int *n_segs);
+
+/* ---- timing hooks used by bench.py -------------------------------------------------------- */
+/* average device time (ms) of each kernel of the step pipeline since the last call (HIP events
+ * recorded on the stream the kernels were launched on); names: "step","reset","prep","render". */
+int mwb_timing_enable(mwb_handle *h, int enable);
+int mwb_timing_read(mwb_handle *h, double *ms_step, double *ms_reset, double *ms_prep, double *ms_render,
+                    int *n_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

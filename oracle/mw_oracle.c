@@ -842,7 +842,7 @@ typedef struct {
 static void make_ray(const Cam *c, float wx, float wy, float *d) {
     float nx = (2.0f * wx - (float)c->W) * c->invW, ny = (2.0f * wy - (float)c->H) * c->invH;
     float ax = nx * c->TW, ay = ny * c->TH;
-    for (int k = 0; k < 3; k++) d[k] = (c->F[k] + c->S[k] * ax) + c->U[k] * ay;
+    for (int k = 0; k < 3; k++) d[k] = fmaf(c->U[k], ay, fmaf(c->S[k], ax, c->F[k]));
 }
 
 typedef struct { int kind; /* 0 sky, 1 floor, 2 ceil, 3 wall, 4 box */ int room, side; float t; } Hit;
@@ -898,19 +898,21 @@ static int build_rrooms(MwoEnv *e, RRoom *rr) {
 static Hit trace_rooms(const RRoom *rr, int n_rooms, int room, const float *o, const float *d) {
     Hit h = {0, -1, -1, INFINITY};
     if (room < 0) return h;
+    /* per-ray reciprocals (one correctly rounded division each); plane distances are (c - o) * inv */
+    float ix = d[0] != 0 ? 1.0f / d[0] : 0.0f, iy = d[1] != 0 ? 1.0f / d[1] : 0.0f, iz = d[2] != 0 ? 1.0f / d[2] : 0.0f;
     for (int iter = 0; iter < n_rooms + 1; iter++) {
         const RRoom *r = &rr[room];
         float tx = INFINITY, tz = INFINITY; int sx = 0, sz = 1;
-        if (d[0] > 0) { tx = (r->max_x - o[0]) / d[0]; sx = 0; } else if (d[0] < 0) { tx = (r->min_x - o[0]) / d[0]; sx = 2; }
-        if (d[2] > 0) { tz = (r->max_z - o[2]) / d[2]; sz = 3; } else if (d[2] < 0) { tz = (r->min_z - o[2]) / d[2]; sz = 1; }
+        if (d[0] > 0) { tx = (r->max_x - o[0]) * ix; sx = 0; } else if (d[0] < 0) { tx = (r->min_x - o[0]) * ix; sx = 2; }
+        if (d[2] > 0) { tz = (r->max_z - o[2]) * iz; sz = 3; } else if (d[2] < 0) { tz = (r->min_z - o[2]) * iz; sz = 1; }
         float ts; int s;
         if (tx <= tz) { ts = tx; s = sx; } else { ts = tz; s = sz; }
-        if (d[1] < 0) { float tf = (0.0f - o[1]) / d[1]; if (tf <= ts) { h.kind = 1; h.room = room; h.t = tf; return h; } }
-        if (d[1] > 0) { float tc = (r->height - o[1]) / d[1]; if (tc <= ts) { h.kind = 2; h.room = room; h.t = tc; return h; } }
+        if (d[1] < 0) { float tf = (0.0f - o[1]) * iy; if (tf <= ts) { h.kind = 1; h.room = room; h.t = tf; return h; } }
+        if (d[1] > 0) { float tc = (r->height - o[1]) * iy; if (tc <= ts) { h.kind = 2; h.room = room; h.t = tc; return h; } }
         if (!(ts < INFINITY)) return h;
         const RSide *sd = &r->side[s];
-        float hc = (s == 0 || s == 2) ? o[2] + ts * d[2] : o[0] + ts * d[0];
-        float y = o[1] + ts * d[1];
+        float hc = (s == 0 || s == 2) ? fmaf(ts, d[2], o[2]) : fmaf(ts, d[0], o[0]);
+        float y = fmaf(ts, d[1], o[1]);
         if (sd->nbr >= 0 && sd->lo < hc && hc < sd->hi && sd->min_y < y && y < sd->max_y) { room = sd->nbr; continue; }
         h.kind = 3; h.room = room; h.side = s; h.t = ts; return h;
     }
@@ -923,12 +925,13 @@ typedef struct { float pos[3], c, s, half[3], sy; } RBox;
 static int trace_box(const RBox *b, const float *o, const float *d, float *t_out) {
     float ro[3] = {o[0] - b->pos[0], o[1] - b->pos[1], o[2] - b->pos[2]};
     float lo_[3] = {ro[0] * b->c - ro[2] * b->s, ro[1], ro[0] * b->s + ro[2] * b->c};
-    float ld[3] = {d[0] * b->c - d[2] * b->s, d[1], d[0] * b->s + d[2] * b->c};
+    float ld[3] = {fmaf(d[0], b->c, -(d[2] * b->s)), d[1], fmaf(d[0], b->s, d[2] * b->c)};
     float lo[3] = {-b->half[0], 0.0f, -b->half[2]}, hi[3] = {b->half[0], b->sy, b->half[2]};
     float tn = -INFINITY, tf = INFINITY; int face = -1;
     for (int a = 0; a < 3; a++) {
         if (ld[a] == 0) { if (lo_[a] < lo[a] || lo_[a] > hi[a]) return -1; continue; }
-        float t1 = (lo[a] - lo_[a]) / ld[a], t2 = (hi[a] - lo_[a]) / ld[a];
+        float inv = 1.0f / ld[a];
+        float t1 = (lo[a] - lo_[a]) * inv, t2 = (hi[a] - lo_[a]) * inv;
         float tmin = t1 < t2 ? t1 : t2, tmax = t1 < t2 ? t2 : t1;
         if (tmin > tn) { tn = tmin; face = a * 2 + (ld[a] > 0 ? 0 : 1); }
         if (tmax < tf) tf = tmax;

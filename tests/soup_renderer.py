@@ -1,0 +1,163 @@
+"""Brute-force software rendition of a captured reference GL call stream (tests/golden/glstream_*.json).
+
+Independent cross-check of the oracle's renderer (float64, numpy, no portal traversal, no
+knowledge of rooms): every polygon the reference handed to OpenGL is intersected with every
+sample ray, back faces are culled by WINDING (as GL_CULL_FACE does), the nearest hit wins
+(GL_LESS depth test), each covered polygon is shaded once per pixel at the pixel centre with
+fixed-function lighting from the captured glLightfv arguments and trilinear REPEAT texturing
+from the captured texcoords, and the 8 samples are averaged.  It shares only the written render
+spec (sample pattern, mip chain, LOD rule) with oracle/mw_oracle.c - none of its code.
+"""
+import numpy as np
+
+SAMPLE_X = np.array([1, -1, 5, -3, -5, -7, 3, 7]) / 16.0
+SAMPLE_Y = np.array([-3, 3, 1, -5, 5, -1, 7, -7]) / 16.0
+
+
+def _norm(v):
+    return v / np.linalg.norm(v)
+
+
+def _roty(deg):
+    a = np.radians(deg)
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def polygons_from_stream(g):
+    """-> list of dicts: verts (n,3) world, texcs (n,2) or None, normal (3,), color (3,), tex (name or None)"""
+    out = []
+    room_i, slot = 0, 0  # per room the reference draws floor, ceiling, walls (miniworld.py:390-423)
+    for p in g["polys"]:
+        verts = np.array(p["verts"], float)
+        texcs = np.array(p["texcs"], float)
+        norms = np.array(p["norms"], float)
+        R, T = np.eye(3), np.zeros(3)
+        for op in p["xform"]:  # glTranslatef then glRotatef (entity.py:395-397): v_world = T + R v
+            if op[0] == "translate":
+                T = T + R @ np.array(op[1:4])
+            else:
+                assert op[2:5] == [0.0, 1.0, 0.0]
+                R = R @ _roty(op[1])
+        verts = verts @ R.T + T
+        norms = norms @ R.T
+        if p["tex_on"]:
+            tex = g["room_tex"][room_i][{0: 1, 1: 2, 2: 0}[slot]]
+            slot += 1
+            if slot == 3:
+                slot, room_i = 0, room_i + 1
+        else:
+            tex = None
+        n_per = {"GL_QUADS": 4, "GL_POLYGON": len(verts)}[p["mode"]]
+        for k in range(0, len(verts), n_per):
+            out.append({"verts": verts[k:k + n_per], "texcs": texcs[k:k + n_per] if tex else None,
+                        "normal": norms[k], "color": np.array(p["color"], float), "tex": tex})
+    return out
+
+
+def _bilinear(level, s, t):
+    h, w = level.shape[:2]
+    uu, vv = s * w - 0.5, t * h - 0.5
+    i0, j0 = np.floor(uu).astype(int), np.floor(vv).astype(int)
+    a, b = (uu - i0)[:, None], (vv - j0)[:, None]
+    i1, j1 = (i0 + 1) % w, (j0 + 1) % h
+    i0, j0 = i0 % w, j0 % h
+    L = level[..., :3].astype(float)
+    return (L[j0, i0] * (1 - a) + L[j0, i1] * a) * (1 - b) + (L[j1, i0] * (1 - a) + L[j1, i1] * a) * b
+
+
+def _trilinear(levels, s, t, rho2):
+    nl = len(levels)
+    lam = np.where(np.isfinite(rho2), 0.5 * np.log2(np.maximum(rho2, 1e-300)), nl - 1.0)
+    lam = np.clip(lam, 0, nl - 1)
+    l0 = np.minimum(np.floor(lam).astype(int), nl - 1)
+    l1 = np.minimum(l0 + 1, nl - 1)
+    fr = (lam - np.floor(lam))[:, None]
+    s, t = s - np.floor(s), t - np.floor(t)
+    out = np.zeros((len(s), 3))
+    for l in np.unique(np.concatenate([l0, l1])):
+        c = _bilinear(levels[l], s, t)
+        out += np.where((l0 == l)[:, None], (1 - fr) * c, 0) + np.where((l1 == l)[:, None] & (l1 != l0)[:, None], fr * c, 0)
+    return out
+
+
+def render_stream(g, textures, W=80, H=60):
+    """textures: name -> list of mip levels (H,W,4) uint8 with row 0 = bottom.  Returns (H,W,3) uint8."""
+    polys = polygons_from_stream(g)
+    fovy, aspect, _, _ = g["misc"]["gluPerspective"]
+    la = g["misc"]["gluLookAt"]
+    eye, center, up = np.array(la[0:3]), np.array(la[3:6]), np.array(la[6:9])
+    f = _norm(center - eye)
+    s_ = _norm(np.cross(f, up))
+    u_ = np.cross(s_, f)
+    th = np.tan(np.radians(fovy) / 2)
+    tw = th * aspect
+    sky = np.array(g["misc"]["glClearColor"][:3])
+    Lp = np.array(g["lights"]["GL_POSITION"])
+    assert Lp[3] == 0.0  # directional (miniworld.py:1026)
+    Ldir = _norm(Lp[:3])
+    amb, dif = np.array(g["lights"]["GL_AMBIENT"][:3]), np.array(g["lights"]["GL_DIFFUSE"][:3])
+
+    def rays(wx, wy):
+        nx, ny = 2 * wx / W - 1, 2 * wy / H - 1
+        return f[None] + s_[None] * (nx * tw)[:, None] + u_[None] * (ny * th)[:, None]
+
+    py, px = np.mgrid[0:H, 0:W]
+    cx, cy = (px + 0.5).ravel(), (H - 1 - py + 0.5).ravel()
+    npx = W * H
+    best_t = np.full((8, npx), np.inf)
+    best_p = np.full((8, npx), -1)
+    planes = []
+    for pi, p in enumerate(polys):
+        v = p["verts"]
+        ng = _norm(np.cross(v[1] - v[0], v[2] - v[0]))  # CCW winding -> front side
+        planes.append(ng)
+        for k in range(8):
+            d = rays(cx + SAMPLE_X[k], cy + SAMPLE_Y[k])
+            den = d @ ng
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = ((v[0] - eye) @ ng) / den
+            ok = (den < 0) & (t > 0) & (t < best_t[k])
+            P = eye[None] + t[:, None] * d
+            for e in range(len(v)):
+                a, b = v[e], v[(e + 1) % len(v)]
+                ok &= (np.cross(b - a, P - a) @ ng) >= -1e-9
+            best_t[k] = np.where(ok, t, best_t[k])
+            best_p[k] = np.where(ok, pi, best_p[k])
+    acc = np.zeros((npx, 3))
+    dc, dx, dy = rays(cx, cy), rays(cx + 1, cy), rays(cx, cy + 1)
+    acc += (best_p == -1).sum(axis=0)[:, None] * sky[None]
+    for pi in np.unique(best_p[best_p >= 0]):
+        p = polys[pi]
+        cnt = (best_p == pi).sum(axis=0)
+        idx = np.nonzero(cnt)[0]
+        C = p["color"]
+        lit = np.minimum(1.0, 0.2 * C + amb * C + max(float(p["normal"] @ Ldir), 0.0) * dif * C)
+        if p["tex"] is None:
+            col = np.broadcast_to(lit, (len(idx), 3))
+        else:
+            v, tc, ng = p["verts"], p["texcs"], planes[pi]
+            # affine texcoord map on the polygon's plane from its first three vertices
+            e1, e2 = v[1] - v[0], v[-1] - v[0]
+            M = np.array([[e1 @ e1, e1 @ e2], [e1 @ e2, e2 @ e2]])
+
+            def texc(d):
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    t = ((v[0] - eye) @ ng) / (d @ ng)
+                P = eye[None] + t[:, None] * d - v[0][None]
+                ab = np.linalg.solve(M, np.stack([P @ e1, P @ e2]))
+                st = tc[0][None] + ab[0][:, None] * (tc[1] - tc[0])[None] + ab[1][:, None] * (tc[-1] - tc[0])[None]
+                return st, t > 0
+            levels = textures[p["tex"]]
+            h0, w0 = levels[0].shape[:2]
+            st0, ok0 = texc(dc[idx])
+            stx, okx = texc(dx[idx])
+            sty, oky = texc(dy[idx])
+            r1 = ((stx[:, 0] - st0[:, 0]) * w0) ** 2 + ((stx[:, 1] - st0[:, 1]) * h0) ** 2
+            r2 = ((sty[:, 0] - st0[:, 0]) * w0) ** 2 + ((sty[:, 1] - st0[:, 1]) * h0) ** 2
+            rho2 = np.where(ok0 & okx & oky, np.maximum(r1, r2), np.inf)
+            texel = _trilinear(levels, st0[:, 0], st0[:, 1], rho2)
+            col = lit[None] * texel / 255.0
+        acc[idx] += cnt[idx][:, None] * col
+    img = np.clip(acc / 8.0, 0, 1)
+    return np.floor(img * 255 + 0.5).astype(np.uint8).reshape(H, W, 3)

@@ -1,0 +1,213 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical seeds.
+
+Bars (BASELINE.json north_star): rewards / dones / step counters / RNG stream bit-exact; world
+geometry and placement bit-exact (float64); observations within +-1/255 per channel; depth within
+1e-4 m.  Poses after steps are compared within a few ulp because the device's float64 sin/cos
+(OCML) and the host's (glibc) may differ in the last bit ("numerics").
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("MiniWorld-Hallway-v0", "Hallway", None, 0),
+    ("MiniWorld-OneRoom-v0", "OneRoom", None, 0),
+    ("MiniWorld-FourRooms-v0", "FourRooms", None, 0),
+    ("MiniWorld-Maze-v0", "Maze", None, 0),
+    ("MiniWorld-MazeS3-v0", "Maze", [3, 3, 3], 0),
+    ("MiniWorld-OneRoomS6-v0", "OneRoom", [6], 100),
+]
+
+
+def make_pair(O, env_id, task, args, mes, n, seed, dr, depth=False, layout="HWC"):
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    b = BatchedMiniWorld(env_id, num_envs=n, seed=seed, domain_rand=dr, want_depth=depth, layout=layout)
+    envs = [O.OracleEnv(task, seed=seed + i, domain_rand=dr, task_args=args, max_episode_steps=mes) for i in range(n)]
+    return b, envs
+
+
+def oracle_states(envs):
+    return [e.state() for e in envs]
+
+
+def assert_state_equal(st, os_, exact_pose=True, tag=""):
+    n = len(os_)
+    f = lambda name: np.array([list(getattr(s, name)) if hasattr(getattr(s, name), "__len__") else getattr(s, name) for s in os_])  # noqa: E731
+    for k in ("box_pos", "box_dir", "box_color", "sky_color", "light_pos", "light_color", "light_ambient"):
+        assert np.array_equal(st[k], f(k)), (tag, k)
+    cam = np.array([[s.cam_height, s.cam_fwd_disp, s.cam_pitch, s.cam_fov_y] for s in os_])
+    assert np.array_equal(st["cam"], cam), (tag, "cam")
+    assert np.array_equal(st["step_count"], f("step_count")), (tag, "step_count")
+    assert np.array_equal(st["rng_pos"], f("rng_pos")), (tag, "rng_pos")
+    assert np.array_equal(st["rng_keysum"], f("rng_keysum").astype(np.uint32)), (tag, "rng_keysum")
+    assert np.array_equal(st["n_rooms"], f("n_rooms")), (tag, "n_rooms")
+    assert np.array_equal(st["n_segs"], f("n_segs")), (tag, "n_segs")
+    if exact_pose:
+        assert np.array_equal(st["agent_pos"], f("agent_pos")), (tag, "agent_pos")
+        assert np.array_equal(st["agent_dir"], f("agent_dir")), (tag, "agent_dir")
+    else:
+        assert np.allclose(st["agent_pos"], f("agent_pos"), rtol=0, atol=1e-11), (tag, "agent_pos")
+        assert np.allclose(st["agent_dir"], f("agent_dir"), rtol=0, atol=1e-11), (tag, "agent_dir")
+    assert n == len(st["agent_dir"])
+
+
+@pytest.mark.parametrize("env_id,task,args,mes", CASES)
+@pytest.mark.parametrize("dr", [0, 1])
+def test_reset_state_and_geometry_bit_exact(oracle_mod, env_id, task, args, mes, dr):
+    O = oracle_mod
+    n = 24
+    b, envs = make_pair(O, env_id, task, args, mes, n, seed=100, dr=dr)
+    b.reset()
+    for e in envs:
+        e.reset(render=False)
+    assert_state_equal(b.get_state(), oracle_states(envs), tag=env_id)
+    for i in (0, 5, n - 1):
+        rooms, segs = b.get_geometry(i)
+        g = envs[i].geometry()
+        assert np.array_equal(segs, g["wall_segs"]), (env_id, i, "segs")
+        tex = rooms[:, 5].view(np.int32)
+        got = np.stack([tex & 255, (tex >> 8) & 255, (tex >> 16) & 255], axis=1)
+        assert np.array_equal(got, g["tex_ids"]), (env_id, i, "tex ids")
+        o = g["outline"]
+        rect = np.stack([o[:, :, 0].min(1), o[:, :, 0].max(1), o[:, :, 1].min(1), o[:, :, 1].max(1)], axis=1)
+        assert np.array_equal(rooms[:, 0:4], rect.astype(np.float32)), (env_id, i, "rects")
+        assert np.array_equal(rooms[:, 4], g["wall_height"].astype(np.float32))
+    # a second reset continues every env's RNG stream exactly
+    b.reset()
+    for e in envs:
+        e.reset(render=False)
+    assert_state_equal(b.get_state(), oracle_states(envs), tag=env_id + " 2nd reset")
+    b.close()
+
+
+def obs_diff(a, b):
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    return d
+
+
+@pytest.mark.parametrize("env_id,task,args,mes", CASES)
+@pytest.mark.parametrize("dr", [0, 1])
+def test_render_after_reset_matches_oracle(oracle_mod, env_id, task, args, mes, dr):
+    O = oracle_mod
+    n = 16
+    b, envs = make_pair(O, env_id, task, args, mes, n, seed=7, dr=dr, depth=True)
+    obs = b.reset().cpu().numpy()
+    dep = b.depth.cpu().numpy()[..., 0]
+    for i, e in enumerate(envs):
+        e.reset(render=False)
+        ref, refd = e.render_obs(depth=True)
+        d = obs_diff(obs[i], ref)
+        assert d.max() <= 1, (env_id, dr, i, int(d.max()), int((d > 1).sum()))
+        assert np.abs(dep[i] - refd).max() <= 1e-4, (env_id, dr, i, float(np.abs(dep[i] - refd).max()))
+    assert 0 < obs.mean() < 255   # run_tests.py:21-22 sanity
+    b.close()
+
+
+@pytest.mark.parametrize("env_id,task,args,mes,steps", [
+    ("MiniWorld-Hallway-v0", "Hallway", None, 0, 300),
+    ("MiniWorld-OneRoom-v0", "OneRoom", None, 0, 400),
+    ("MiniWorld-FourRooms-v0", "FourRooms", None, 0, 300),
+    ("MiniWorld-MazeS3-v0", "Maze", [3, 3, 3], 0, 300),
+    ("MiniWorld-Maze-v0", "Maze", None, 0, 120),
+])
+@pytest.mark.parametrize("dr", [0, 1])
+def test_rollout_rewards_dones_exact_and_obs_close(oracle_mod, env_id, task, args, mes, steps, dr):
+    """Random-action rollout with auto-reset: reward / done / step_count / RNG exact every step;
+    observation checked every 25 steps after injecting the oracle's pose (isolates the renderer
+    from last-ulp trig differences)."""
+    import torch
+    O = oracle_mod
+    n = 16
+    b, envs = make_pair(O, env_id, task, args, mes, n, seed=2024, dr=dr)
+    b.reset()
+    for e in envs:
+        e.reset(render=False)
+    rng = np.random.default_rng(5)
+    n_done = 0
+    for t in range(steps):
+        # bias towards moving forward so that walls, the box and resets are actually reached
+        a = rng.choice(3, size=n, p=[0.2, 0.2, 0.6]).astype(np.int32)
+        b.step(torch.from_numpy(a))
+        rew = b.reward64.cpu().numpy()
+        done = b.done.cpu().numpy()
+        eps = b.ep_steps.cpu().numpy()
+        for i, e in enumerate(envs):
+            _, r, d, _ = e.step(int(a[i]))
+            assert r == rew[i] and d == bool(done[i]) and e.state().step_count == eps[i], (env_id, dr, t, i, r, rew[i], d, done[i])
+            if d:
+                e.reset(render=False)
+                n_done += 1
+        if t % 25 == 24 or t == steps - 1:
+            os_ = oracle_states(envs)
+            assert_state_equal(b.get_state(), os_, exact_pose=False, tag="%s t=%d" % (env_id, t))
+            b.set_agent(0, pos_xz=np.array([[s.agent_pos[0], s.agent_pos[2]] for s in os_]),
+                        dir=np.array([s.agent_dir for s in os_]))
+            obs = b.render().cpu().numpy()
+            for i, e in enumerate(envs):
+                d = obs_diff(obs[i], e.render_obs())
+                assert d.max() <= 1, (env_id, dr, t, i, int(d.max()), int((d > 1).sum()))
+    assert n_done > 0 or steps < 200
+    b.close()
+
+
+def test_cwh_layout_is_transpose_of_hwc(oracle_mod):
+    """TransposeImage (pytorch-a2c-ppo-acktr/envs.py:106-107): obs.transpose(2, 1, 0)."""
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    a = BatchedMiniWorld("MiniWorld-FourRooms-v0", num_envs=8, seed=3, layout="HWC")
+    c = BatchedMiniWorld("MiniWorld-FourRooms-v0", num_envs=8, seed=3, layout="CWH")
+    oa = a.reset().cpu().numpy()
+    oc = c.reset().cpu().numpy()
+    assert oc.shape == (8, 3, 80, 60)
+    assert np.array_equal(oc, oa.transpose(0, 3, 2, 1))
+    a.close(); c.close()
+
+
+def test_skip_mask_dummy_semantics(oracle_mod):
+    """vec_env/subproc_vec_env.py:26-31,58-67: mask[i] != 0 -> no step, reward -99, done False."""
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    b = BatchedMiniWorld("MiniWorld-OneRoom-v0", num_envs=8, seed=11)
+    b.reset()
+    before = b.get_state()
+    obs0 = b.obs.cpu().numpy().copy()
+    mask = torch.tensor([1, 0, 1, 0, 1, 0, 1, 0], dtype=torch.uint8)
+    b.step(torch.full((8,), 2, dtype=torch.int32), skip_mask=mask)
+    after = b.get_state()
+    rew = b.reward.cpu().numpy()
+    assert np.all(rew[0::2] == -99) and np.all(b.done.cpu().numpy()[0::2] == 0)
+    assert np.array_equal(after["step_count"][0::2], before["step_count"][0::2])
+    assert np.array_equal(after["step_count"][1::2], before["step_count"][1::2] + 1)
+    assert np.array_equal(after["agent_pos"][0::2], before["agent_pos"][0::2])
+    assert np.array_equal(b.obs.cpu().numpy()[0::2], obs0[0::2])
+    b.close()
+
+
+def test_large_batch_properties():
+    """BASELINE sizes (4096 OneRoom envs): size-independent properties - run_tests.py:51-59 (agent
+    never leaves the room), run_tests.py:69-72 (spawn never intersects), shape/dtype, brightness."""
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    n = 4096
+    b = BatchedMiniWorld("MiniWorld-OneRoom-v0", num_envs=n, seed=1)
+    obs = b.reset()
+    assert obs.shape == (n, 60, 80, 3) and obs.dtype == torch.uint8
+    st = b.get_state()
+    for i in range(0, n, 257):
+        assert b.intersect(i, st["agent_pos"][i, 0], st["agent_pos"][i, 2]) == 0
+    g = torch.Generator().manual_seed(0)
+    for _ in range(60):
+        b.step(torch.randint(0, 3, (n,), generator=g, dtype=torch.int32))
+    st = b.get_state()
+    assert np.all(st["agent_pos"][:, [0, 2]] >= 0) and np.all(st["agent_pos"][:, [0, 2]] <= 10)
+    m = b.obs.float().mean().item()
+    assert 20 < m < 235
+    # envs are independent: the first 16 envs of the big batch equal a 16-env batch with the same seeds
+    small = BatchedMiniWorld("MiniWorld-OneRoom-v0", num_envs=16, seed=1)
+    small.reset()
+    g = torch.Generator().manual_seed(0)
+    for _ in range(60):
+        a = torch.randint(0, 3, (n,), generator=g, dtype=torch.int32)
+        small.step(a[:16])
+    assert torch.equal(small.obs, b.obs[:16])
+    b.close(); small.close()
