@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py - env-steps/s of the batched MiniWorld hot path on N MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (MiniWorldEnv.step + auto-reset + render_obs for every env of
+the rank's shard) on synthetic uniformly random actions that are resident in HBM before the timed
+region.  For N > 1 every rank owns a contiguous env range (weak scaling: envs per GPU fixed) and
+each step's observation shard is all-gathered (RCCL, uint8) for the learner, overlapped with the
+next step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# name -> (env id, envs per GPU, depth, domain_rand, SURVEY.md 8(d) algorithmic bytes per env-step)
+WORKLOADS = {
+    "maze8192": ("MiniWorld-Maze-v0", 8192, False, False, 25600),             # north_star target / configs[4] per-GPU shape
+    "oneroom4096": ("MiniWorld-OneRoom-v0", 4096, False, False, 14700),       # configs[1]
+    "maze8192_depth": ("MiniWorld-Maze-v0", 8192, True, False, 44800),        # configs[2]
+    "fourrooms16384_dr": ("MiniWorld-FourRooms-v0", 16384, False, True, 16100),   # configs[3]
+}
+ORACLE_TASK = {"MiniWorld-Maze-v0": ("Maze", None), "MiniWorld-OneRoom-v0": ("OneRoom", None),
+               "MiniWorld-FourRooms-v0": ("FourRooms", None), "MiniWorld-Hallway-v0": ("Hallway", None)}
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ACTION_SEED = 12345
+
+
+def splitmix64(x):
+    """torch int64 splitmix64 (logical shifts emulated); matches oracle.action_stream / mwo_bench_loop."""
+    import torch
+    def lsr(v, n):
+        return (v >> n) & ((1 << (64 - n)) - 1)
+    x = x + torch.tensor(-7046029254386353131, dtype=torch.int64, device=x.device)   # 0x9E3779B97F4A7C15
+    x = (x ^ lsr(x, 30)) * torch.tensor(-4658895280553007687, dtype=torch.int64, device=x.device)   # 0xBF58476D1CE4E5B9
+    x = (x ^ lsr(x, 27)) * torch.tensor(-7723592293110705685, dtype=torch.int64, device=x.device)   # 0x94D049BB133111EB
+    return x ^ lsr(x, 31)
+
+
+def make_actions(steps, first_env, n_envs, device):
+    """[steps, n_envs] int32 actions in {0,1,2}: counter-based in (step, global env index)."""
+    import torch
+    t = torch.arange(steps, dtype=torch.int64, device=device)[:, None]
+    e = torch.arange(first_env, first_env + n_envs, dtype=torch.int64, device=device)[None, :]
+    inner = splitmix64(t * 0x100000001B3 + e)
+    v = splitmix64(inner ^ ACTION_SEED)
+    return (((v >> 33) & ((1 << 31) - 1)) % 3).to(torch.int32).contiguous()
+
+
+def cpu_baseline(env_id, depth, dr, budget_s=12.0):
+    """Oracle (CPU restatement, 1 thread) timed on this host on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    task, args = ORACLE_TASK[env_id]
+    env = O.OracleEnv(task, seed=1, domain_rand=dr, task_args=args)
+    env.reset(render=False)
+    dt = env.bench_loop(200, ACTION_SEED, 0, want_depth=depth)   # calibrate
+    n = max(200, min(20000, int(200 * budget_s / max(dt, 1e-6))))
+    dt = env.bench_loop(n, ACTION_SEED, 0, want_depth=depth)
+    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d steps of 1 env (%s, seed 1, same counter-based random actions), oracle/mw_oracle.c "
+                      "step+auto-reset+render, 1 thread of %d host cores" % (n, env_id, os.cpu_count() or 0)}
+
+
+def load_traffic(workload):
+    """HBM bytes per render launch from the newest committed rocprofv3 --pmc summary that has this
+    workload (profiles/r*_pmc_traffic.json, written by scripts/summarize_prof.py), else None."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(p) as fh:
+                v = json.load(fh).get(workload, {}).get("hbm_bytes_per_render_launch")
+            if v:
+                return v
+        except Exception:
+            pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="maze8192", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the obs all-gather for N > 1")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    from gym_miniworld_amd.distributed import ObsGatherer, dist_env, shard_range
+
+    rank, local_rank, world = dist_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    env_id, per_gpu, depth, dr, alg_bytes = WORKLOADS[args.workload]
+    if args.envs_per_gpu:
+        per_gpu = args.envs_per_gpu
+    total = per_gpu * world
+    first, count = shard_range(total, rank, world)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    env = BatchedMiniWorld(env_id, num_envs=count, seed=1, domain_rand=dr, want_depth=depth, device=local_rank,
+                           first_env_index=first)
+    K, Wm = args.steps, args.warmup
+    actions = make_actions(K + Wm, first, count, device)
+    gather = None
+    if world > 1 and not args.no_gather:
+        gather = ObsGatherer(tuple(env.obs.shape), env.obs.dtype, device, world)
+    env.reset()
+
+    def run(t0, t1):
+        for t in range(t0, t1):
+            env.step(actions[t])
+            if gather is not None:
+                gather.push(env.obs)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    run(0, Wm)
+    if gather is not None:
+        gather.drain()
+    fence()
+    env.timing_enable(True)   # HIP events on the launch stream; read back only after the timed region
+    t_start = time.perf_counter()
+    run(Wm, Wm + K)
+    if gather is not None:
+        gather.drain()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    kt = env.timing_read()
+    env.timing_enable(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        value = total * K / elapsed
+        render_ms = kt["render"]
+        achieved = alg_bytes * count / (render_ms * 1e-3) / 1e9 if render_ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/s (80x60 RGB obs)", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 sim / f32 render / u8 obs", "data": "synthetic",
+            "config": {"workload": args.workload, "env_id": env_id, "envs_per_gpu": per_gpu, "global_envs": total,
+                       "obs": "80x60 RGB" + (" + f32 depth" if depth else ""), "domain_rand": bool(dr),
+                       "actions": "uniform random over {turn_left, turn_right, move_forward}, counter-based",
+                       "auto_reset": True, "parallelism": "env-sharded x%d%s" % (world, "" if gather is None else " + RCCL all-gather(obs u8)")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
+                         "kernel": "render_kernel", "kernel_ms": render_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes * count,
+                         "note": "nominally HBM-bound path; practical limiter is VALU/LDS per ray (DESIGN.md)"},
+            "kernel_ms": {k: kt[k] for k in ("step", "reset", "prep", "render")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(env_id, depth, dr)
+            except Exception as ex:   # the oracle is only a reported baseline; never fail the GPU number on it
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

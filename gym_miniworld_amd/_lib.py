@@ -64,6 +64,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise MwbError("HIP extension %s is missing - run `python -m gym_miniworld_amd.build` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # PyTorch-ROCm wheels bundle their own libamdhip64; import torch first so that this library binds to
+    # the SAME HIP runtime (two runtimes in one process do not see each other's devices or streams)
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, i32 = ctypes.c_void_p, ctypes.c_int
     L.mwb_last_error.restype = ctypes.c_char_p

@@ -1155,7 +1155,7 @@ double mwo_bench_loop(MwoEnv *e, int n_steps, uint64_t action_seed, uint64_t env
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int t = 0; t < n_steps; t++) {
         int a = constant_action >= 0 ? constant_action
-                                     : (int)(splitmix(action_seed ^ splitmix((uint64_t)t * 0x100000001B3ull + env_index)) % 3);
+                                     : (int)((splitmix(action_seed ^ splitmix((uint64_t)t * 0x100000001B3ull + env_index)) >> 33) % 3);
         double r; int d;
         mwo_step(e, a, &r, &d);
         if (d) mwo_reset(e);

@@ -264,4 +264,4 @@ def action_stream(action_seed, step, env_index):
         x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
         x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
         return x ^ (x >> 31)
-    return sm(action_seed ^ sm((step * 0x100000001B3 + env_index) & M)) % 3
+    return (sm(action_seed ^ sm((step * 0x100000001B3 + env_index) & M)) >> 33) % 3
