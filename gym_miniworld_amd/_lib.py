@@ -24,7 +24,7 @@ class MwbConfig(ctypes.Structure):
         ("obs_width", ctypes.c_int32), ("obs_height", ctypes.c_int32), ("want_depth", ctypes.c_int32),
         ("layout", ctypes.c_int32), ("domain_rand", ctypes.c_int32), ("max_episode_steps", ctypes.c_int32),
         ("device", ctypes.c_int32), ("task_args", ctypes.c_double * 4),
-        ("use_default_params", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("use_default_params", ctypes.c_int32), ("no_auto_reset", ctypes.c_int32),
         ("params", (ctypes.c_double * 9) * NPARAM),
     ]
 

@@ -58,7 +58,7 @@ class BatchedMiniWorld:
 
     def __init__(self, env_id="MiniWorld-OneRoom-v0", num_envs=1, seed=None, domain_rand=False, obs_width=80,
                  obs_height=60, want_depth=False, layout="HWC", device=0, max_episode_steps=None, params=None,
-                 task=None, task_args=None, first_env_index=0):
+                 task=None, task_args=None, first_env_index=0, auto_reset=True):
         import torch
         self.torch = torch
         self.L = _lib.load()
@@ -100,6 +100,7 @@ class BatchedMiniWorld:
         for i in range(4):
             cfg.task_args[i] = float(ta[i])
         cfg.use_default_params = 0
+        cfg.no_auto_reset = 0 if auto_reset else 1
         table = self.params.to_table()
         for i in range(_lib.NPARAM):
             for j in range(9):

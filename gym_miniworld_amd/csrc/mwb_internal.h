@@ -69,7 +69,7 @@ struct MwbParam { double def[3], lo[3], hi[3]; };
 // everything a kernel needs, passed by value
 struct MwbDev {
     int N, task, W, H, want_depth, layout, domain_rand, max_episode_steps;
-    int R_max, S_max;
+    int R_max, S_max, auto_reset;
     double task_args[4];
     MwbParam params[MWB_NPARAM];
     // sim state (f64 SoA)

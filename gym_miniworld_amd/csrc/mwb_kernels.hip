@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) step_kernel(MwbDev d, const int32_t *__re
         }
     }
     d.reward64[e] = r; d.reward[e] = (float)r; d.done[e] = (uint8_t)done; d.ep_steps[e] = sc;
-    d.need_reset[e] = (uint8_t)done;   // worker auto-reset, vec_env/subproc_vec_env.py:10-13
+    d.need_reset[e] = (uint8_t)(done && d.auto_reset);   // worker auto-reset, vec_env/subproc_vec_env.py:10-13
 }
 
 __global__ void mark_reset_kernel(MwbDev d, const uint8_t *__restrict__ mask) {

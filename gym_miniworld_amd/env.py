@@ -1,0 +1,123 @@
+"""Single-environment Gym-style view (a batch of one) for code written against
+gym_miniworld.miniworld.MiniWorldEnv: seed / reset / step / render_obs / render_depth and the
+attributes callers and the reference's run_tests.py read (miniworld.py:425-531, 658-716,
+933-971, 1160-1220).  Plain Gym semantics: step() returns the terminal observation and the
+caller resets.
+"""
+from enum import IntEnum
+
+import numpy as np
+
+from .vec_env import Box, Discrete
+
+
+class _Ent:
+    def __init__(self, radius, height):
+        self.pos, self.dir, self.radius, self.height = None, None, radius, height
+
+    @property
+    def dir_vec(self):   # entity.py:72-80
+        return np.array([np.cos(self.dir), 0, -np.sin(self.dir)])
+
+    @property
+    def right_vec(self):   # entity.py:82-90
+        return np.array([np.sin(self.dir), 0, np.cos(self.dir)])
+
+
+class _Room:
+    def __init__(self, words):
+        self.min_x, self.max_x, self.min_z, self.max_z, self.wall_height = (float(w) for w in words[:5])
+
+
+class MiniWorldEnv:
+    class Actions(IntEnum):   # miniworld.py:437-454
+        turn_left = 0
+        turn_right = 1
+        move_forward = 2
+        move_back = 3
+        pickup = 4
+        drop = 5
+        toggle = 6
+        done = 7
+
+    def __init__(self, env_id="MiniWorld-OneRoom-v0", domain_rand=False, obs_width=80, obs_height=60, device=0,
+                 seed=None, **kwargs):
+        from .batch import BatchedMiniWorld
+        self._b = BatchedMiniWorld(env_id, num_envs=1, domain_rand=domain_rand, obs_width=obs_width,
+                                   obs_height=obs_height, want_depth=True, layout="HWC", device=device,
+                                   auto_reset=False, **kwargs)
+        self.actions = MiniWorldEnv.Actions
+        self.action_space = Discrete(self.actions.move_forward + 1)   # e.g. envs/hallway.py:23
+        self.observation_space = Box(0, 255, (obs_height, obs_width, 3), np.uint8)
+        self.max_episode_steps = self._b.max_episode_steps
+        self.domain_rand = bool(self._b.domain_rand)
+        self.params = self._b.params
+        self.agent, self.box = _Ent(0.4, 1.6), _Ent(float(np.sqrt(0.8 * 0.8 + 0.8 * 0.8) / 2), 0.8)
+        self.entities = [self.box, self.agent]
+        self.rooms, self.step_count = [], 0
+        self._seeded = False
+        if seed is not None:
+            self.seed(seed)
+
+    def seed(self, seed=None):
+        if seed is None:   # the reference seeds from entropy (miniworld.py:522,528-530)
+            seed = int(np.random.SeedSequence().entropy % (2 ** 63))
+        self._b.seed(np.array([seed], dtype=np.uint64))
+        self._seeded = True
+        return [seed]
+
+    def _sync(self):
+        st = self._b.get_state()
+        self.agent.pos, self.agent.dir = st["agent_pos"][0].copy(), float(st["agent_dir"][0])
+        self.box.pos, self.box.dir = st["box_pos"][0].copy(), float(st["box_dir"][0])
+        self.box.color_vec = st["box_color"][0].copy()
+        (self.agent.cam_height, self.agent.cam_fwd_disp, self.agent.cam_pitch, self.agent.cam_fov_y) = st["cam"][0]
+        self.sky_color, self.light_pos = st["sky_color"][0], st["light_pos"][0]
+        self.light_color, self.light_ambient = st["light_color"][0], st["light_ambient"][0]
+        self.step_count = int(st["step_count"][0])
+
+    def reset(self):
+        if not self._seeded:
+            self.seed()
+        obs = self._b.reset().cpu().numpy()[0]
+        rooms, _ = self._b.get_geometry(0)
+        self.rooms = [_Room(w) for w in rooms]
+        self._sync()
+        return obs
+
+    def step(self, action):
+        import torch
+        self._b.step(torch.tensor([int(action)], dtype=torch.int32))
+        obs = self._b.obs.cpu().numpy()[0]
+        reward, done = float(self._b.reward64.cpu()[0]), bool(self._b.done.cpu()[0])
+        self._sync()
+        return obs, reward, done, {}
+
+    def render_obs(self):
+        return self._b.render().cpu().numpy()[0]
+
+    def render_depth(self):
+        self._b.render()
+        return self._b.depth.cpu().numpy()[0]
+
+    def intersect(self, ent, pos, radius):
+        """miniworld.py:933-959: True for a wall, the other entity for an entity hit, else None."""
+        r = self._b.intersect(0, pos[0], pos[2], radius)
+        if r == 1:
+            return True
+        if r == 2 and ent is not self.box:
+            return self.box
+        return None
+
+    def near(self, ent0, ent1=None):   # miniworld.py:961-971
+        ent1 = ent1 or self.agent
+        dist = np.linalg.norm(ent0.pos - ent1.pos)
+        return dist < ent0.radius + ent1.radius + 1.1 * self.params.get_max("forward_step")
+
+    def close(self):
+        self._b.close()
+
+
+def make(env_id, **kwargs):
+    """gym.make('MiniWorld-<Class>-v0') for the covered ids (envs/__init__.py:43-49)."""
+    return MiniWorldEnv(env_id, **kwargs)

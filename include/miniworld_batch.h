@@ -55,7 +55,8 @@ typedef struct mwb_config {
     int32_t device;            /* HIP device ordinal */
     double task_args[4];       /* see MWB_TASK_*; 0 = the class default */
     int32_t use_default_params; /* 1: params.py:110-123 DEFAULT_PARAMS; 0: `params` below */
-    int32_t reserved;
+    int32_t no_auto_reset;     /* 0: a finished env is reset inside mwb_step (VecEnv worker, subproc_vec_env.py:10-13);
+                                  1: plain Gym semantics, the caller resets (miniworld.py:658-716) */
     double params[MWB_NPARAM][9]; /* default[3], min[3], max[3] per parameter (DomainParams.set) */
 } mwb_config;
 

@@ -1,0 +1,121 @@
+"""GPU: the VecEnv / Gym front-ends reproduce the reference harness' batch semantics
+(vec_env/subproc_vec_env.py:5-33,58-75; envs.py:96-165) on top of the HIP path, and the
+reference's own smoke tests (run_tests.py) hold."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_vecenv_matches_per_env_oracle_with_autoreset(oracle_mod):
+    import torch
+    from gym_miniworld_amd.vec_env import MiniWorldVecEnv
+    O = oracle_mod
+    n, seed = 6, 40
+    v = MiniWorldVecEnv("MiniWorld-Hallway-v0", n, seed=seed, transpose=True, to_float=True, torch_api=True)
+    assert v.observation_space.shape == (3, 80, 60) and v.action_space.n == 3
+    refs = [O.OracleEnv("Hallway", seed=seed + i) for i in range(n)]   # env i seeded seed + i, envs.py:36
+    obs = v.reset()
+    assert obs.dtype == torch.float32 and tuple(obs.shape) == (n, 3, 80, 60)
+    for i, r in enumerate(refs):
+        d = np.abs(obs[i].cpu().numpy() - r.reset().transpose(2, 1, 0).astype(np.float32))
+        assert d.max() <= 1
+    rng = np.random.default_rng(0)
+    seen_done = False
+    for t in range(260):
+        a = rng.choice(3, size=(n, 1), p=[0.15, 0.15, 0.7])
+        obs, rew, done, infos = v.step(torch.from_numpy(a))
+        assert rew.shape == (n, 1) and rew.dtype == torch.float32 and rew.device.type == "cpu"
+        assert done.dtype == bool and len(infos) == n
+        for i, r in enumerate(refs):
+            _, rr, dd, _ = r.step(int(a[i, 0]))
+            assert np.float32(rr) == rew[i, 0].item() and dd == done[i]
+            if dd:   # worker: `if done: ob = env.reset()` - the returned obs is the NEW episode's first
+                seen_done = True
+                first = r.reset().transpose(2, 1, 0).astype(np.float32)
+                assert np.abs(obs[i].cpu().numpy() - first).max() <= 1
+    assert seen_done
+    v.close()
+
+
+def test_frame_stack_semantics():
+    """VecPyTorchFrameStack (envs.py:135-165) restated in numpy on the same observation stream."""
+    import torch
+    from gym_miniworld_amd.vec_env import MiniWorldVecEnv
+    n = 5
+    v = MiniWorldVecEnv("MiniWorld-OneRoomS6-v0", n, seed=3, frame_stack=4)
+    plain = MiniWorldVecEnv("MiniWorld-OneRoomS6-v0", n, seed=3, frame_stack=0)
+    assert v.observation_space.shape == (12, 80, 60)
+    st = v.reset().cpu().numpy()
+    ob = plain.reset().cpu().numpy()
+    ref = np.zeros((n, 12, 80, 60), np.float32)
+    ref[:, -3:] = ob
+    assert np.array_equal(st, ref)
+    g = torch.Generator().manual_seed(1)
+    any_done = False
+    for t in range(130):
+        a = torch.randint(0, 3, (n, 1), generator=g)
+        st, _, done, _ = v.step(a)
+        ob, _, done2, _ = plain.step(a)
+        assert np.array_equal(done, done2)
+        ref[:, :-3] = ref[:, 3:].copy()
+        ref[done] = 0
+        ref[:, -3:] = ob.cpu().numpy()
+        any_done |= bool(done.any())
+        assert np.array_equal(st.cpu().numpy(), ref)
+    assert any_done
+    v.close(); plain.close()
+
+
+def test_mask_and_feature_info():
+    import torch
+    from gym_miniworld_amd.vec_env import make_vec_envs
+    v = make_vec_envs("MiniWorld-FourRooms-v0", 1, 4, device="cuda:0")   # the fork's main.py:66 call shape
+    obs = v.reset()
+    assert tuple(obs.shape) == (4, 12, 80, 60) and obs.device.type == "cuda"
+    mask = np.array([0, 1, 0, 1])
+    obs, rew, done, infos = v.step(torch.full((4, 1), 2, dtype=torch.long), mask)
+    assert rew[1, 0] == -99 and rew[3, 0] == -99 and not done[1] and not done[3]
+    assert all("feature" in i and len(i["feature"]) == 2 for i in infos)   # main.py:614-619
+    v.close()
+
+
+def test_gym_view_reference_smoke_tests():
+    """run_tests.py:11-28 and 51-59 through the single-env Gym view."""
+    from gym_miniworld_amd.env import make
+    env = make("MiniWorld-Hallway-v0", seed=0)
+    first = env.reset()
+    for _ in range(10):
+        obs, _, _, _ = env.step(0)
+    assert 0 < first.mean() < 255
+    assert first.shape == env.observation_space.shape == obs.shape
+    d = env.render_depth()
+    assert d.shape == (60, 80, 1) and d.min() > 0
+    env.close()
+    env = make("MiniWorld-OneRoom-v0", seed=5)
+    for _ in range(6):
+        env.reset()
+        room = env.rooms[0]
+        assert not env.intersect(env.agent, env.agent.pos, env.agent.radius)   # run_tests.py:69
+        for _ in range(30):
+            _, _, done, _ = env.step(env.actions.move_forward)
+            x, _, z = env.agent.pos
+            assert room.min_x <= x <= room.max_x and room.min_z <= z <= room.max_z
+            if done:
+                break
+    env.close()
+
+
+def test_gym_view_returns_terminal_obs_without_autoreset(oracle_mod):
+    from gym_miniworld_amd.env import make
+    O = oracle_mod
+    env = make("MiniWorld-OneRoomS6-v0", seed=9)
+    ref = O.OracleEnv("OneRoom", seed=9, task_args=[6], max_episode_steps=100)
+    env.reset(); ref.reset(render=False)
+    for t in range(100):
+        obs, r, d, _ = env.step(1)
+        _, rr, dd, _ = ref.step(1)
+        assert (r, d) == (rr, dd)
+    assert d and env.step_count == 100   # timeout at max_episode_steps, state kept (no reset happened)
+    assert np.abs(obs.astype(int) - ref.render_obs().astype(int)).max() <= 1
+    env.close()

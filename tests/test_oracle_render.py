@@ -1,0 +1,110 @@
+"""CPU: the oracle's render half.  No reference pixels exist (no OpenGL anywhere in this
+pipeline), so it is pinned in two independent ways:
+  1. its INPUTS - every polygon, texcoord, normal, colour, light and camera argument - equal what
+     the unmodified reference handed to OpenGL (tests/golden/glstream_*.json);
+  2. its OUTPUT equals, to +-1 LSB, a brute-force float64 z-buffer rendition of that captured GL
+     stream (tests/soup_renderer.py) that knows nothing about rooms or portals.
+Plus the reference's own pixel sanity checks (run_tests.py:18-28)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STREAMS = [("Hallway", "Hallway", None, 0), ("Hallway", "Hallway", None, 1), ("OneRoom", "OneRoom", None, 0),
+           ("OneRoom", "OneRoom", None, 1), ("FourRooms", "FourRooms", None, 0), ("FourRooms", "FourRooms", None, 1),
+           ("MazeS3", "Maze", [3, 3, 3], 1), ("Maze", "Maze", None, 0)]
+
+
+def load_stream(name, dr):
+    with open(os.path.join(GOLD, "glstream_%s_dr%d.json" % (name, dr))) as fh:
+        return json.load(fh)
+
+
+@pytest.mark.parametrize("name,task,args,dr", STREAMS)
+def test_scene_inputs_equal_reference_gl_stream(oracle_mod, name, task, args, dr):
+    O = oracle_mod
+    g = load_stream(name, dr)
+    env = O.OracleEnv(task, seed=g["seed"], domain_rand=dr, task_args=args)
+    env.reset(render=False)
+    geo, s = env.geometry(), env.state()
+    R = s.n_rooms
+    polys = g["polys"]
+    assert len(polys) == 3 * R + 1
+    for r in range(R):
+        fl, ce, wa = polys[3 * r: 3 * r + 3]
+        o = geo["outline"][r]
+        floor_v = np.stack([o[:, 0], np.zeros(4), o[:, 1]], axis=1)
+        assert np.array_equal(np.array(fl["verts"]), floor_v) and fl["norms"][0] == [0.0, 1.0, 0.0]
+        assert np.array_equal(np.array(fl["texcs"]), geo["floor_texcs"][r])
+        ceil_v = np.stack([o[::-1, 0], np.full(4, geo["wall_height"][r]), o[::-1, 1]], axis=1)
+        assert np.array_equal(np.array(ce["verts"]), ceil_v) and ce["norms"][0] == [0.0, -1.0, 0.0]
+        assert np.array_equal(np.array(ce["texcs"]), geo["ceil_texcs"][r])
+        q0, q1 = geo["quad_offsets"][r] * 4, geo["quad_offsets"][r + 1] * 4
+        assert np.array_equal(np.array(wa["verts"]).reshape(-1, 3), geo["wall_verts"][q0:q1])
+        assert np.array_equal(np.array(wa["norms"]).reshape(-1, 3), geo["wall_norms"][q0:q1])
+        assert np.array_equal(np.array(wa["texcs"], dtype=np.float64).reshape(-1, 2), geo["wall_texcs"][q0:q1].astype(np.float64))
+        assert fl["color"] == [1.0, 1.0, 1.0] and fl["tex_on"]
+        assert [O.TEX_FILES[i] for i in geo["tex_ids"][r]] == g["room_tex"][r]
+    box = polys[-1]
+    assert not box["tex_on"] and box["color"] == pytest.approx(list(s.box_color), abs=0)
+    assert box["xform"][0] == ["translate"] + list(s.box_pos)
+    assert box["xform"][1][0] == "rotate" and box["xform"][1][1] == s.box_dir * (180 / np.pi)
+    # light: (light_pos + 1, w = 0) as float32 ctypes (miniworld.py:1026), ambient / diffuse
+    lp = np.array(g["lights"]["GL_POSITION"])
+    assert lp[3] == 0.0 and np.array_equal(lp[:3], (np.array(s.light_pos) + 1).astype(np.float32))
+    assert np.array_equal(np.array(g["lights"]["GL_AMBIENT"][:3]), np.array(s.light_ambient).astype(np.float32))
+    assert np.array_equal(np.array(g["lights"]["GL_DIFFUSE"][:3]), np.array(s.light_color).astype(np.float32))
+    assert g["misc"]["glClearColor"][:3] == list(s.sky_color)
+    fovy, aspect, near, far = g["misc"]["gluPerspective"]
+    assert fovy == s.cam_fov_y and aspect == 80 / 60 and (near, far) == (0.04, 100.0)
+    la = np.array(g["misc"]["gluLookAt"])
+    assert np.abs(la[0:3] - np.array(s.cam_pos)).max() <= 4.5e-16
+    assert np.abs((la[3:6] - la[0:3]) - np.array(s.cam_dir)).max() <= 1e-14 and list(la[6:9]) == [0, 1, 0]
+
+
+@pytest.mark.parametrize("name,task,args,dr", STREAMS)
+def test_render_equals_bruteforce_rendition_of_gl_stream(oracle_mod, name, task, args, dr):
+    import soup_renderer as SR
+    O = oracle_mod
+    g = load_stream(name, dr)
+    tex = O.load_textures()
+    textures = {O.TEX_FILES[i]: tex[i][2] for i in tex}
+    env = O.OracleEnv(task, seed=g["seed"], domain_rand=dr, task_args=args)
+    a = env.reset()
+    b = SR.render_stream(g, textures)
+    d = np.abs(a.astype(int) - b.astype(int))
+    # float32 portal traversal vs float64 polygon soup: a sample exactly on an edge may flip (1/8 weight)
+    assert (d.max(axis=2) > 1).mean() <= 2e-3, (int(d.max()), int((d.max(axis=2) > 1).sum()))
+    assert d.mean() < 0.02
+
+
+def test_reference_pixel_sanity_and_depth(oracle_mod):
+    """run_tests.py:18-28: 0 < mean < 255, obs shape == observation_space.shape; depth map plausible."""
+    O = oracle_mod
+    for task in ("Hallway", "OneRoom", "FourRooms", "Maze"):
+        for dr in (0, 1):
+            env = O.OracleEnv(task, seed=4, domain_rand=dr)
+            obs = env.reset()
+            assert obs.shape == (60, 80, 3) and obs.dtype == np.uint8 and 0 < obs.mean() < 255
+            _, dep = env.render_obs(depth=True)
+            assert dep.shape == (60, 80) and dep.min() > 0.25 and dep.max() < 40
+            for a in (2, 2, 0, 2, 1, 2):
+                env.step(a)
+            obs2 = env.render_obs()
+            assert obs2.shape == obs.shape and not np.array_equal(obs, obs2)
+
+
+def test_mip_chain_spec(oracle_mod):
+    O = oracle_mod
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(8, 8, 3), dtype=np.uint8)
+    lv = O.build_mip_chain(img)
+    assert [l.shape[0] for l in lv] == [8, 4, 2, 1]
+    bot = np.flipud(img).astype(int)
+    exp = (bot[0::2, 0::2] + bot[0::2, 1::2] + bot[1::2, 0::2] + bot[1::2, 1::2] + 2) // 4
+    assert np.array_equal(lv[1][..., :3], exp)
+    img3 = rng.integers(0, 256, size=(3, 3, 3), dtype=np.uint8)
+    lv3 = O.build_mip_chain(img3)
+    assert len(lv3) == 2 and np.array_equal(lv3[1][0, 0, :3], (img3.astype(int).sum(axis=(0, 1)) + 4) // 9)
