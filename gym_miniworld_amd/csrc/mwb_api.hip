@@ -182,6 +182,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     d.N = cfg->num_envs; d.task = cfg->task; d.W = cfg->obs_width; d.H = cfg->obs_height;
     d.want_depth = cfg->want_depth ? 1 : 0; d.layout = cfg->layout; d.domain_rand = cfg->domain_rand ? 1 : 0;
     d.auto_reset = cfg->no_auto_reset ? 0 : 1;
+    { const char *dbg = getenv("MWB_DEBUG"); d.debug_flags = dbg ? atoi(dbg) : 0; }
     static const double dflt[4][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}};
     for (int i = 0; i < 4; i++) d.task_args[i] = cfg->task_args[i] != 0 ? cfg->task_args[i] : dflt[cfg->task][i];
     int mes = cfg->max_episode_steps;

@@ -56,6 +56,7 @@
 #define FC_BOX_LO 61     // ray origin in box-local axes (3)
 #define FC_CULL_OC 64    // box bounding-sphere centre minus eye (3)
 #define FC_CULL_CC 67    // |oc|^2 - R^2
+#define FC_CULL_CC_PIXEL 68   // same with R grown by a pixel footprint
 
 struct MwbTexDesc {
     int w, h, n_levels;
@@ -70,6 +71,7 @@ struct MwbParam { double def[3], lo[3], hi[3]; };
 struct MwbDev {
     int N, task, W, H, want_depth, layout, domain_rand, max_episode_steps;
     int R_max, S_max, auto_reset;
+    int debug_flags;   // MWB_DEBUG env var at mwb_create: bit0 = resolve every pixel with the full 8-sample path
     double task_args[4];
     MwbParam params[MWB_NPARAM];
     // sim state (f64 SoA)

@@ -687,7 +687,14 @@ __global__ void __launch_bounds__(256) prep_kernel(MwbDev d) {
     float oc[3] = {bpos[0] - eye[0], 0.5f * sy - eye[1], bpos[2] - eye[2]};
     float R = 1.02f * sqrtf(hx * hx + 0.25f * sy * sy + hz * hz);
     fc[FC_CULL_OC] = oc[0]; fc[FC_CULL_OC + 1] = oc[1]; fc[FC_CULL_OC + 2] = oc[2];
-    fc[FC_CULL_CC] = (oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2]) - R * R;
+    float oc2 = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2];
+    fc[FC_CULL_CC] = oc2 - R * R;
+    // the same sphere grown by a pixel's footprint at the far side of the box: any ray within 1.5 pixel
+    // half-diagonals of a pixel's centre ray that touches the box has its centre ray inside this one
+    float tw = (float)(th * ((double)d.W / (double)d.H)) / (float)d.W, thh = (float)th / (float)d.H;
+    float rho = 1.5f * 2.0f * sqrtf(tw * tw + thh * thh);
+    float Rp = R + rho * (sqrtf(oc2) + R);
+    fc[FC_CULL_CC_PIXEL] = oc2 - Rp * Rp;
 }
 
 // ================================================================================ render kernel
@@ -705,6 +712,7 @@ struct Cam {
     float eye[3], F[3], S[3], U[3], TW, TH, invW, invH, Wf, Hf;
 };
 
+// ---- visibility: these functions are part of the bit-exact render spec -------
 __device__ __forceinline__ void make_ray(const Cam &c, float wx, float wy, float *dv) {
     float nx = (2.0f * wx - c.Wf) * c.invW, ny = (2.0f * wy - c.Hf) * c.invH;
     float ax = nx * c.TW, ay = ny * c.TH;
@@ -712,64 +720,92 @@ __device__ __forceinline__ void make_ray(const Cam &c, float wx, float wy, float
     for (int k = 0; k < 3; k++) dv[k] = fmaf(c.U[k], ay, fmaf(c.S[k], ax, c.F[k]));
 }
 
-// portal traversal of the LDS room table: nearest opaque surface along (eye, d)
+// Portal traversal of the LDS room table: nearest opaque surface along (eye, d).
+// All LDS reads of a step are issued together (both candidate sides are fetched) and the loop has
+// one exit.  With PATH the sequence of sides crossed is returned as 2 bits per crossing (exact for
+// up to 15 crossings; longer paths are flagged by bit 31 so that they never compare equal).
+template <bool PATH>
 __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms, int n_rooms, int room, const float *o,
-                                                const float *dv, float &t_hit) {
+                                                const float *dv, float &t_hit, uint32_t &path) {
     t_hit = INFINITY;
-    if (room < 0) return MAKE_KEY(KIND_SKY, 0, 0);
-    float ix = dv[0] != 0 ? 1.0f / dv[0] : 0.0f, iy = dv[1] != 0 ? 1.0f / dv[1] : 0.0f, iz = dv[2] != 0 ? 1.0f / dv[2] : 0.0f;
+    path = 0;
+    uint32_t key = MAKE_KEY(KIND_SKY, 0, 0);
+    if (room < 0) return key;
+    const bool xpos = dv[0] > 0, xnz = dv[0] != 0, zpos = dv[2] > 0, znz = dv[2] != 0, ypos = dv[1] > 0, yneg = dv[1] < 0;
+    // per-ray reciprocals (one correctly rounded division each); plane distances are (c - o) * inv
+    const float ix = xnz ? 1.0f / dv[0] : 0.0f, iy = (ypos || yneg) ? 1.0f / dv[1] : 0.0f, iz = znz ? 1.0f / dv[2] : 0.0f;
+    const float tfloor = yneg ? (0.0f - o[1]) * iy : INFINITY;
+    const int sx = xpos ? 0 : 2, sz = zpos ? 3 : 1;
+    int steps = 0;
     for (int iter = 0; iter <= n_rooms; iter++) {
         const float *r = rooms + room * MWB_ROOM_WORDS;
-        float4 rect = *(const float4 *)(r + RW_MINX);   // min_x max_x min_z max_z
-        float height = r[RW_HEIGHT];
-        float tx = INFINITY, tz = INFINITY;
-        int sx = 0, sz = 1;
-        if (dv[0] > 0) { tx = (rect.y - o[0]) * ix; sx = 0; } else if (dv[0] < 0) { tx = (rect.x - o[0]) * ix; sx = 2; }
-        if (dv[2] > 0) { tz = (rect.w - o[2]) * iz; sz = 3; } else if (dv[2] < 0) { tz = (rect.z - o[2]) * iz; sz = 1; }
-        float ts; int s;
-        if (tx <= tz) { ts = tx; s = sx; } else { ts = tz; s = sz; }
-        if (dv[1] < 0) { float tf = (0.0f - o[1]) * iy; if (tf <= ts) { t_hit = tf; return MAKE_KEY(KIND_FLOOR, 0, room); } }
-        if (dv[1] > 0) { float tc = (height - o[1]) * iy; if (tc <= ts) { t_hit = tc; return MAKE_KEY(KIND_CEIL, 0, room); } }
-        if (!(ts < INFINITY)) return MAKE_KEY(KIND_SKY, 0, 0);
-        const float *sd = r + RW_SIDE0 + 8 * s;
-        float4 port = *(const float4 *)(sd);   // lo hi min_y max_y
-        int nbr = __float_as_int(sd[RS_NBR]);
-        float hc = (s == 0 || s == 2) ? fmaf(ts, dv[2], o[2]) : fmaf(ts, dv[0], o[0]);
-        float y = fmaf(ts, dv[1], o[1]);
-        if (nbr >= 0 && port.x < hc && hc < port.y && port.z < y && y < port.w) { room = nbr; continue; }
-        t_hit = ts;
-        return MAKE_KEY(KIND_WALL, s, room);
+        const float4 rect = *(const float4 *)(r + RW_MINX);   // min_x max_x min_z max_z
+        const float height = r[RW_HEIGHT];
+        const float *sdx = r + RW_SIDE0 + 8 * sx, *sdz = r + RW_SIDE0 + 8 * sz;
+        const float4 portx = *(const float4 *)(sdx), portz = *(const float4 *)(sdz);   // lo hi min_y max_y
+        const int nbrx = __float_as_int(sdx[RS_NBR]), nbrz = __float_as_int(sdz[RS_NBR]);
+        const float tx = xnz ? ((xpos ? rect.y : rect.x) - o[0]) * ix : INFINITY;
+        const float tz = znz ? ((zpos ? rect.w : rect.z) - o[2]) * iz : INFINITY;
+        const bool usex = tx <= tz;
+        const float ts = usex ? tx : tz;
+        const int s = usex ? sx : sz;
+        const float tc = ypos ? (height - o[1]) * iy : INFINITY;
+        const bool hit_floor = tfloor <= ts;
+        const bool hit_ceil = tc <= ts;
+        const bool escaped = !(ts < INFINITY);
+        const float4 port = usex ? portx : portz;
+        const int nbr = usex ? nbrx : nbrz;
+        const float hc = usex ? fmaf(ts, dv[2], o[2]) : fmaf(ts, dv[0], o[0]);
+        const float y = fmaf(ts, dv[1], o[1]);
+        const bool pass = nbr >= 0 && port.x < hc && hc < port.y && port.z < y && y < port.w;
+        if (hit_floor || hit_ceil || escaped || !pass) {
+            // same precedence as the sequential tests of the spec: floor, ceiling, escape, wall
+            if (hit_floor) { t_hit = tfloor; key = MAKE_KEY(KIND_FLOOR, 0, room); }
+            else if (hit_ceil) { t_hit = tc; key = MAKE_KEY(KIND_CEIL, 0, room); }
+            else if (!escaped) {
+                t_hit = ts; key = MAKE_KEY(KIND_WALL, s, room);
+                // a wall with a portal is not convex: tag the convex piece (left / right / above / below the
+                // opening) so that the corner-ray classification never spans the opening
+                if (PATH && nbr >= 0) key |= (hc <= port.x ? 1u : hc >= port.y ? 2u : y >= port.w ? 3u : 0u) << 28;
+            }
+            break;
+        }
+        if (PATH) { path = (path << 2) | (uint32_t)s; steps++; }
+        room = nbr;
     }
-    return MAKE_KEY(KIND_SKY, 0, 0);
+    if (PATH && steps > 15) path = 0x80000000u | (uint32_t)steps;
+    return key;
 }
+
 
 // slab test in box-local axes; returns face 0..5 (-x,+x,-y,+y,-z,+z) or -1
 __device__ __forceinline__ int trace_box(const float *fc, const float *dv, float &t_out) {
-    float c = fc[FC_BOX_C], s = fc[FC_BOX_S];
-    float ld[3] = {fmaf(dv[0], c, -(dv[2] * s)), dv[1], fmaf(dv[0], s, dv[2] * c)};
-    float lo_[3] = {fc[FC_BOX_LO], fc[FC_BOX_LO + 1], fc[FC_BOX_LO + 2]};
-    float lo[3] = {-fc[FC_BOX_HX], 0.0f, -fc[FC_BOX_HZ]}, hi[3] = {fc[FC_BOX_HX], fc[FC_BOX_SY], fc[FC_BOX_HZ]};
+    const float c = fc[FC_BOX_C], s = fc[FC_BOX_S];
+    const float ld[3] = {fmaf(dv[0], c, -(dv[2] * s)), dv[1], fmaf(dv[0], s, dv[2] * c)};
+    const float lo_[3] = {fc[FC_BOX_LO], fc[FC_BOX_LO + 1], fc[FC_BOX_LO + 2]};
+    const float lo[3] = {-fc[FC_BOX_HX], 0.0f, -fc[FC_BOX_HZ]}, hi[3] = {fc[FC_BOX_HX], fc[FC_BOX_SY], fc[FC_BOX_HZ]};
     float tn = -INFINITY, tf = INFINITY;
     int face = -1;
+    bool miss = false;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        if (ld[a] == 0) { if (lo_[a] < lo[a] || lo_[a] > hi[a]) return -1; continue; }
+        if (ld[a] == 0) { miss = miss || lo_[a] < lo[a] || lo_[a] > hi[a]; continue; }
         float inv = 1.0f / ld[a];
         float t1 = (lo[a] - lo_[a]) * inv, t2 = (hi[a] - lo_[a]) * inv;
         float tmin = t1 < t2 ? t1 : t2, tmax = t1 < t2 ? t2 : t1;
         if (tmin > tn) { tn = tmin; face = a * 2 + (ld[a] > 0 ? 0 : 1); }
         if (tmax < tf) tf = tmax;
     }
-    if (face < 0 || !(tn <= tf) || !(tn > 0)) return -1;
+    if (miss || face < 0 || !(tn <= tf) || !(tn > 0)) return -1;
     t_out = tn;
     return face;
 }
 
+// ---- shading: continuous in its inputs, so fused / approximate arithmetic is within the +-1 LSB bar
 struct TexLds { int w, h, n_levels; float sc_s, sc_t; int pad[3]; uint32_t off[MWB_MAX_LEVELS]; };
 static_assert(sizeof(TexLds) == sizeof(MwbTexDesc), "TexLds mirrors MwbTexDesc");
 
-__device__ __forceinline__ int imod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
-
+#pragma clang fp contract(fast)
 __device__ __forceinline__ void bilinear(const uint32_t *__restrict__ texels, uint32_t off, int w, int h, float s, float t, float *rgb) {
     float uu = s * (float)w - 0.5f, vv = t * (float)h - 0.5f;
     float fu = floorf(uu), fv = floorf(vv);
@@ -778,74 +814,234 @@ __device__ __forceinline__ void bilinear(const uint32_t *__restrict__ texels, ui
     // s,t in [0,1): i0 in [-1, w-1]; wrap with compares instead of integer division
     int i1 = i0 + 1; if (i1 >= w) i1 -= w; if (i0 < 0) i0 += w;
     int j1 = j0 + 1; if (j1 >= h) j1 -= h; if (j0 < 0) j0 += h;
-    uint32_t t00 = texels[off + j0 * w + i0], t10 = texels[off + j0 * w + i1];
-    uint32_t t01 = texels[off + j1 * w + i0], t11 = texels[off + j1 * w + i1];
+    const uint32_t *row0 = texels + off + j0 * w, *row1 = texels + off + j1 * w;
+    uint32_t t00 = row0[i0], t10 = row0[i1], t01 = row1[i0], t11 = row1[i1];
+    float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float c00 = (float)((t00 >> (8 * k)) & 255u), c10 = (float)((t10 >> (8 * k)) & 255u);
         float c01 = (float)((t01 >> (8 * k)) & 255u), c11 = (float)((t11 >> (8 * k)) & 255u);
-        float top = c00 * (1.0f - a) + c10 * a, bot = c01 * (1.0f - a) + c11 * a;
-        rgb[k] = top * (1.0f - b) + bot * b;
+        rgb[k] = c00 * w00 + c10 * w10 + c01 * w01 + c11 * w11;
     }
 }
 
 __device__ __forceinline__ void sample_texture(const uint32_t *__restrict__ texels, const TexLds &T, float s, float t, float sx,
                                                float tx, float sy, float ty, bool valid, float *rgb) {
-    int maxl = T.n_levels - 1;
-    float lambda;
-    if (!valid) lambda = (float)maxl;
-    else {
+    const int maxl = T.n_levels - 1;
+    float lambda = (float)maxl;
+    if (valid) {
         float dsdx = (sx - s) * (float)T.w, dtdx = (tx - t) * (float)T.h;
         float dsdy = (sy - s) * (float)T.w, dtdy = (ty - t) * (float)T.h;
         float r1 = dsdx * dsdx + dtdx * dtdx, r2 = dsdy * dsdy + dtdy * dtdy;
         float rho2 = r1 > r2 ? r1 : r2;
-        if (!(rho2 < INFINITY)) lambda = (float)maxl;
-        else if (rho2 <= 1.0f) lambda = 0.0f;
-        else lambda = 0.5f * log2f(rho2);
+        if (rho2 < INFINITY) lambda = rho2 <= 1.0f ? 0.0f : 0.5f * __log2f(rho2);
     }
     float ws = s - floorf(s), wt = t - floorf(t);   // GL_REPEAT
-    if (lambda <= 0.0f) { bilinear(texels, T.off[0], T.w, T.h, ws, wt, rgb); return; }
     float fl = floorf(lambda);
     int l0 = (int)fl; if (l0 > maxl) l0 = maxl;
     int l1 = l0 + 1 > maxl ? maxl : l0 + 1;
-    float fr = l0 == maxl ? 0.0f : lambda - fl;
-    float c0[3], c1[3];
+    float fr = (l0 == maxl) ? 0.0f : lambda - fl;
+    float c0[3];
     int w0 = T.w >> l0; if (w0 < 1) w0 = 1;
     int h0 = T.h >> l0; if (h0 < 1) h0 = 1;
     bilinear(texels, T.off[l0], w0, h0, ws, wt, c0);
-    if (l1 == l0 || fr == 0.0f) { rgb[0] = c0[0]; rgb[1] = c0[1]; rgb[2] = c0[2]; return; }
-    int w1 = T.w >> l1; if (w1 < 1) w1 = 1;
-    int h1 = T.h >> l1; if (h1 < 1) h1 = 1;
-    bilinear(texels, T.off[l1], w1, h1, ws, wt, c1);
+    rgb[0] = c0[0]; rgb[1] = c0[1]; rgb[2] = c0[2];
+    if (fr > 0.0f) {
+        float c1[3];
+        int w1 = T.w >> l1; if (w1 < 1) w1 = 1;
+        int h1 = T.h >> l1; if (h1 < 1) h1 = 1;
+        bilinear(texels, T.off[l1], w1, h1, ws, wt, c1);
 #pragma unroll
-    for (int k = 0; k < 3; k++) rgb[k] = c0[k] * (1.0f - fr) + c1[k] * fr;
+        for (int k = 0; k < 3; k++) rgb[k] = c0[k] + (c1[k] - c0[k]) * fr;
+    }
 }
 
-// texture coordinates where ray (eye, dv) meets the plane of surface `key`; false if behind
-__device__ __forceinline__ bool surf_texcoord(const float *__restrict__ rooms, uint32_t key, const float *o, const float *dv,
-                                              float sc_s, float sc_t, float &s, float &t) {
-    uint32_t kind = key & 7u, side = (key >> 3) & 7u;
-    const float *r = rooms + (key >> 6) * MWB_ROOM_WORDS;
-    if (kind == KIND_FLOOR || kind == KIND_CEIL) {
-        float py = kind == KIND_FLOOR ? 0.0f : r[RW_HEIGHT];
-        if (dv[1] == 0) return false;
-        float tt = (py - o[1]) / dv[1];
-        if (!(tt > 0)) return false;
-        s = (o[0] + tt * dv[0]) * sc_s; t = (o[2] + tt * dv[2]) * sc_t;
-        return true;
-    }
-    float plane, od, oo;
-    int along;
-    if (side == 0 || side == 2) { plane = side == 0 ? r[RW_MAXX] : r[RW_MINX]; od = dv[0]; oo = o[0]; along = 2; }
-    else { plane = side == 3 ? r[RW_MAXZ] : r[RW_MINZ]; od = dv[2]; oo = o[2]; along = 0; }
-    if (od == 0) return false;
-    float tt = (plane - oo) / od;
-    if (!(tt > 0)) return false;
-    float hc = (along == 2 ? o[2] + tt * dv[2] : o[0] + tt * dv[0]), y = o[1] + tt * dv[1];
-    const float *sd = r + RW_SIDE0 + 8 * side;
-    s = ((hc - sd[RS_UORG]) * sd[RS_USGN]) * sc_s; t = y * sc_t;
-    return true;
+// texture coordinates where ray (o, dv) meets the plane {axis = plane}; false if behind / parallel
+__device__ __forceinline__ bool plane_texcoord(int axis, float plane, float u_org, float u_scale, float sc_t, const float *o,
+                                               const float *dv, float &s, float &t) {
+    float od = axis == 0 ? dv[0] : axis == 1 ? dv[1] : dv[2];
+    float oo = axis == 0 ? o[0] : axis == 1 ? o[1] : o[2];
+    float tt = (plane - oo) * __builtin_amdgcn_rcpf(od);
+    float px = o[0] + tt * dv[0], py = o[1] + tt * dv[1], pz = o[2] + tt * dv[2];
+    // floor / ceiling: (x, z) * scale; walls: (distance along the edge, y) * scale (miniworld.py:19-68)
+    float a = axis == 0 ? pz : px;
+    float b = axis == 1 ? pz : py;
+    s = (a - u_org) * u_scale; t = b * sc_t;
+    return od != 0.0f && tt > 0.0f;
 }
+#pragma clang fp contract(off)
+
+struct RenderCtx {
+    const float *rooms, *fc;
+    const TexLds *tex;
+    const uint32_t *texels;
+    uint8_t *fb;
+    float *depth;   // this env's depth map or null
+    Cam cam;
+    int n_rooms, cam_room, W, H, layout, dbg;
+    float cull_cc, cull_oc[3], zA, zB;
+
+    __device__ __forceinline__ void shade(uint32_t key, int first_k, float cx, float cy, const float *dc, const float *dx,
+                                          const float *dy, float *col) const {
+        const uint32_t kind = key & 7u, side = (key >> 3) & 7u;
+        if (kind == KIND_SKY) { col[0] = fc[FC_SKY]; col[1] = fc[FC_SKY + 1]; col[2] = fc[FC_SKY + 2]; return; }
+        if (kind == KIND_BOX) {
+            const float *lb = fc + FC_LIT_BOX + 3 * side;
+            col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2];
+            return;
+        }
+        const float *r = rooms + (key >> 6) * MWB_ROOM_WORDS;
+        const uint32_t texw = (uint32_t)__float_as_int(r[RW_TEX]);
+        const int tex_id = kind == KIND_FLOOR ? (texw >> 8) & 255u : kind == KIND_CEIL ? (texw >> 16) & 255u : texw & 255u;
+        const TexLds &T = tex[tex_id];
+        const float *lit = kind == KIND_FLOOR ? fc + FC_LIT_FLOOR : kind == KIND_CEIL ? fc + FC_LIT_CEIL : fc + FC_LIT_WALL + 3 * side;
+        const bool wall = kind == KIND_WALL;
+        const float *sd = r + RW_SIDE0 + 8 * side;
+        // plane of the surface: axis (0 x, 1 y, 2 z) and coordinate, selected without control flow
+        const float4 rect = *(const float4 *)(r + RW_MINX);   // min_x max_x min_z max_z
+        const float height = r[RW_HEIGHT];
+        const bool is_x = wall && (side == 0u || side == 2u), is_z = wall && (side == 1u || side == 3u);
+        const float wall_plane = side == 0u ? rect.y : side == 2u ? rect.x : side == 3u ? rect.w : rect.z;
+        const int axis = is_x ? 0 : (is_z ? 2 : 1);
+        const float plane = wall ? wall_plane : (kind == KIND_CEIL ? height : 0.0f);
+        // s = (a - u_org) * u_sgn * sc_s for walls, a * sc_s for floor / ceiling
+        const float u_org = wall ? sd[RS_UORG] : 0.0f, u_scale = (wall ? sd[RS_USGN] : 1.0f) * T.sc_s;
+        float s0, t0, s1, t1, s2, t2;
+        bool valid;
+        if (!plane_texcoord(axis, plane, u_org, u_scale, T.sc_t, cam.eye, dc, s0, t0)) {
+            float dv[3];   // centre ray misses the plane: shade at the sample's own hit point
+            make_ray(cam, cx + c_sample_x[first_k], cy + c_sample_y[first_k], dv);
+            plane_texcoord(axis, plane, u_org, u_scale, T.sc_t, cam.eye, dv, s0, t0);
+            valid = false; s1 = s2 = s0; t1 = t2 = t0;
+        } else {
+            bool v1 = plane_texcoord(axis, plane, u_org, u_scale, T.sc_t, cam.eye, dx, s1, t1);
+            bool v2 = plane_texcoord(axis, plane, u_org, u_scale, T.sc_t, cam.eye, dy, s2, t2);
+            valid = v1 && v2;
+        }
+        float texel[3];
+        sample_texture(texels, T, s0, t0, s1, t1, s2, t2, valid, texel);
+#pragma unroll
+        for (int q = 0; q < 3; q++) col[q] = lit[q] * (texel[q] * (1.0f / 255.0f));
+    }
+
+    // acc = sum over the 8 samples of their colour; t_s0 / kind of sample 0 for the depth map
+    __device__ __forceinline__ void write_pixel(int px, int py, const float *acc, bool s0_drawn, float t_s0) const {
+        uint8_t out[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            float v = acc[q] * 0.125f;
+            v = v < 0 ? 0 : (v > 1 ? 1 : v);
+            out[q] = (uint8_t)(int)floorf(v * 255.0f + 0.5f);   // RGBA32F -> unorm8 resolve
+        }
+        if (layout == MWB_LAYOUT_HWC) {
+            uint8_t *p = fb + (py * W + px) * 3;
+            p[0] = out[0]; p[1] = out[1]; p[2] = out[2];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; q++) fb[(q * W + px) * H + py] = out[q];
+        }
+        if (depth) {
+            int z16 = 65535;   // DEPTH_COMPONENT16 of sample 0; cleared to 1.0 where nothing was drawn
+            if (s0_drawn) {
+                float zndc = zA - zB / t_s0;
+                float dd = 0.5f * zndc + 0.5f;
+                int z = (int)floorf(dd * 65535.0f + 0.5f);
+                z16 = z < 0 ? 0 : (z > 65535 ? 65535 : z);
+            }
+            // get_depth_map, opengl.py:362-367 in float32
+            float dm = (float)z16 / 65535.0f;
+            float clip_z = (dm - 0.5f) * 2.0f;
+            depth[py * W + px] = (float)(-2.0 * 100.0 * 0.04) / (clip_z * (float)(100.0 - 0.04) - (float)(100.0 + 0.04));
+        }
+    }
+
+    // the full 8-sample path for one pixel
+    __device__ __forceinline__ void pixel_full(int px, int py) const {
+        const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
+        // distinct surfaces among the 8 coverage samples, in order of first appearance:
+        // up to 4 slots (key, count, first sample); a 5th distinct surface is shaded on the spot
+        uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0, firsts = 0;
+        uint32_t key_s0 = 0;
+        float t_s0 = INFINITY;
+        float acc[3] = {0, 0, 0};
+        float dc[3], dx[3], dy[3];
+        make_ray(cam, cx, cy, dc);
+        make_ray(cam, cx + 1.0f, cy, dx);
+        make_ray(cam, cx, cy + 1.0f, dy);
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) {
+            float dv[3], th;
+            uint32_t path;
+            make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
+            uint32_t key = trace_rooms<false>(rooms, n_rooms, cam_room, cam.eye, dv, th, path);
+            // conservative bounding-sphere cull, then the exact slab test
+            const float b = dv[0] * cull_oc[0] + dv[1] * cull_oc[1] + dv[2] * cull_oc[2];
+            const float dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+            if (cull_cc <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc)) {
+                float tb;
+                int face = trace_box(fc, dv, tb);
+                if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, 0); th = tb; }
+            }
+            if (k == 0) { key_s0 = key; t_s0 = th; }
+            const bool h0 = c0 > 0 && key == k0, h1 = c1 > 0 && key == k1, h2 = c2 > 0 && key == k2, h3 = c3 > 0 && key == k3;
+            c0 += h0; c1 += h1; c2 += h2; c3 += h3;
+            if (!(h0 || h1 || h2 || h3)) {
+                if (c0 == 0) { k0 = key; c0 = 1; firsts |= k; }
+                else if (c1 == 0) { k1 = key; c1 = 1; firsts |= k << 3; }
+                else if (c2 == 0) { k2 = key; c2 = 1; firsts |= k << 6; }
+                else if (c3 == 0) { k3 = key; c3 = 1; firsts |= k << 9; }
+                else {
+                    float col[3];
+                    shade(key, k, cx, cy, dc, dx, dy, col);
+                    acc[0] += col[0]; acc[1] += col[1]; acc[2] += col[2];
+                }
+            }
+        }
+#pragma unroll 1
+        for (int it = 0; it < 4 && c0 > 0; it++) {
+            float col[3];
+            shade(k0, firsts & 7, cx, cy, dc, dx, dy, col);
+            const float cnt = (float)c0;
+#pragma unroll
+            for (int q = 0; q < 3; q++) acc[q] += cnt * col[q];
+            k0 = k1; c0 = c1; k1 = k2; c1 = c2; k2 = k3; c2 = c3; c3 = 0; firsts >>= 3;
+        }
+        write_pixel(px, py, acc, (key_s0 & 7u) != KIND_SKY, t_s0);
+    }
+
+    // a pixel whose 8 samples provably see one room surface: one shade, colour x 8 / 8
+    __device__ __forceinline__ void pixel_interior(int px, int py, uint32_t key) const {
+        const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
+        float dc[3], dx[3], dy[3], col[3], acc[3];
+        make_ray(cam, cx, cy, dc);
+        make_ray(cam, cx + 1.0f, cy, dx);
+        make_ray(cam, cx, cy + 1.0f, dy);
+        shade(key, 0, cx, cy, dc, dx, dy, col);
+#pragma unroll
+        for (int q = 0; q < 3; q++) acc[q] = 8.0f * col[q];
+        float t_s0 = 1.0f;
+        if (depth) {   // sample 0's ray meets the known surface at the distance the traversal would report
+            float dv[3];
+            make_ray(cam, cx + c_sample_x[0], cy + c_sample_y[0], dv);
+            const uint32_t kind = key & 7u, side = (key >> 3) & 7u;
+            const float *r = rooms + (key >> 6) * MWB_ROOM_WORDS;
+            const float4 rect = *(const float4 *)(r + RW_MINX);
+            const bool wall = kind == KIND_WALL;
+            const bool is_x = wall && (side == 0u || side == 2u), is_z = wall && (side == 1u || side == 3u);
+            const float wall_plane = side == 0u ? rect.y : side == 2u ? rect.x : side == 3u ? rect.w : rect.z;
+            const float plane = wall ? wall_plane : (kind == KIND_CEIL ? r[RW_HEIGHT] : 0.0f);
+            const float od = is_x ? dv[0] : (is_z ? dv[2] : dv[1]);
+            const float oo = is_x ? cam.eye[0] : (is_z ? cam.eye[2] : cam.eye[1]);
+            t_s0 = (plane - oo) * (1.0f / od);
+        }
+        write_pixel(px, py, acc, true, t_s0);
+    }
+};
+
+#define TILE_CX 16   // corner grid of one wave pass: 16 x 4 corners -> 15 x 3 pixels
+#define TILE_CY 4
+#define QUEUE_CAP 128
 
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) render_kernel(MwbDev d) {
@@ -860,6 +1056,7 @@ __global__ void __launch_bounds__(THREADS) render_kernel(MwbDev d) {
     float *fc = (float *)(smem + off); off += MWB_FRAME_WORDS * 4;
     TexLds *tex = (TexLds *)(smem + off); off += sizeof(TexLds) * MWB_MAX_TEX;
     int *cam_room_s = (int *)(smem + off); off += 16;
+    uint16_t *queues = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
     uint8_t *fb = smem + off;
 
     {   // stage the room table, the frame constants and the texture descriptors
@@ -874,7 +1071,11 @@ __global__ void __launch_bounds__(THREADS) render_kernel(MwbDev d) {
         if (tid == 0) *cam_room_s = 0x7fffffff;
     }
     __syncthreads();
-    Cam cam;
+    RenderCtx ctx;
+    ctx.rooms = rooms; ctx.fc = fc; ctx.tex = tex; ctx.texels = d.texels; ctx.fb = fb;
+    ctx.depth = d.want_depth ? d.depth + (size_t)e * W * H : nullptr;
+    ctx.n_rooms = n_rooms; ctx.W = W; ctx.H = H; ctx.layout = d.layout; ctx.dbg = d.debug_flags;
+    Cam &cam = ctx.cam;
 #pragma unroll
     for (int k = 0; k < 3; k++) { cam.eye[k] = fc[FC_EYE + k]; cam.F[k] = fc[FC_F + k]; cam.S[k] = fc[FC_S + k]; cam.U[k] = fc[FC_U + k]; }
     cam.TW = fc[FC_TW]; cam.TH = fc[FC_TH];
@@ -886,118 +1087,63 @@ __global__ void __launch_bounds__(THREADS) render_kernel(MwbDev d) {
             atomicMin(cam_room_s, i);
     }
     __syncthreads();
-    int cam_room = *cam_room_s;
-    if (cam_room == 0x7fffffff) cam_room = -1;
-
+    ctx.cam_room = *cam_room_s;
+    if (ctx.cam_room == 0x7fffffff) ctx.cam_room = -1;
     const float zn = 0.04f, zf = 100.0f;   // gluPerspective near / far, miniworld.py:1186-1187
-    const float zA = (zf + zn) / (zf - zn), zB = (2.0f * zf * zn) / (zf - zn);
-    const int tiles_x = (W + 15) / 16, tiles_y = (H + 3) / 4;
+    ctx.zA = (zf + zn) / (zf - zn); ctx.zB = (2.0f * zf * zn) / (zf - zn);
+    ctx.cull_cc = fc[FC_CULL_CC];
+    ctx.cull_oc[0] = fc[FC_CULL_OC]; ctx.cull_oc[1] = fc[FC_CULL_OC + 1]; ctx.cull_oc[2] = fc[FC_CULL_OC + 2];
+    const float cull_cc_px = fc[FC_CULL_CC_PIXEL];   // sphere inflated by a pixel footprint (prep_kernel)
+
+    // Pass structure per wave: a 16x4 grid of rays through PIXEL CORNERS classifies 15x3 pixels.
+    // If the four corner rays of a pixel reach the same convex piece of a room surface through the
+    // same portal sequence, every ray inside the pixel does (rooms, portals and the pieces are convex,
+    // samples lie >= 1/16 pixel inside the corners) and, unless the box may intrude, the pixel is shaded once.
+    // All other pixels go to a per-wave queue and are resolved 64 at a time with the full
+    // 8-sample path, so that pass runs with dense lanes.
+    const int tiles_x = (W + TILE_CX - 2) / (TILE_CX - 1), tiles_y = (H + TILE_CY - 2) / (TILE_CY - 1);
     const int n_tiles = tiles_x * tiles_y;
     const int wave = tid / WAVE, lane = tid % WAVE, n_waves = THREADS / WAVE;
-    const float cull_cc = fc[FC_CULL_CC];
+    uint16_t *queue = queues + wave * QUEUE_CAP;
+    int q_count = 0;   // wave-uniform
+    const int ci = lane & (TILE_CX - 1), cj = lane / TILE_CX;
 
     for (int tile = wave; tile < n_tiles; tile += n_waves) {
-        int px = (tile % tiles_x) * 16 + (lane & 15), py = (tile / tiles_x) * 4 + (lane >> 4);
-        bool active = px < W && py < H;
-        if (!active) continue;
-        float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
-        uint32_t keys[8];
-        float t0 = INFINITY;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            float dv[3], th;
-            make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
-            uint32_t key = trace_rooms(rooms, n_rooms, cam_room, cam.eye, dv, th);
-            // conservative sphere cull, then the exact slab test
-            float b = dv[0] * fc[FC_CULL_OC] + dv[1] * fc[FC_CULL_OC + 1] + dv[2] * fc[FC_CULL_OC + 2];
-            float dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
-            if (cull_cc <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc)) {
-                float tb;
-                int face = trace_box(fc, dv, tb);
-                if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, 0); th = tb; }
-            }
-            keys[k] = key;
-            if (k == 0) t0 = th;
+        const int x0 = (tile % tiles_x) * (TILE_CX - 1), y0 = (tile / tiles_x) * (TILE_CY - 1);
+        float dv[3], th;
+        uint32_t path;
+        // corner (ci, cj): window x = x0 + ci, window y (up) = H - (y0 + cj)
+        make_ray(cam, (float)(x0 + ci), (float)(H - (y0 + cj)), dv);
+        uint32_t key = trace_rooms<true>(rooms, n_rooms, ctx.cam_room, cam.eye, dv, th, path);
+        const uint32_t kind = key & 7u;
+        bool ok = kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL;
+        ok = ok && !(path & 0x80000000u);
+        const uint32_t k1 = __shfl(key, lane + 1), k2 = __shfl(key, lane + TILE_CX), k3 = __shfl(key, lane + TILE_CX + 1);
+        const uint32_t p1 = __shfl(path, lane + 1), p2 = __shfl(path, lane + TILE_CX), p3 = __shfl(path, lane + TILE_CX + 1);
+        const int px = x0 + ci, py = y0 + cj;
+        const bool is_pixel = ci < TILE_CX - 1 && cj < TILE_CY - 1 && px < W && py < H;
+        bool interior = !(d.debug_flags & 1) && is_pixel && ok && key == k1 && key == k2 && key == k3 && path == p1 && path == p2 && path == p3;
+        if (interior) {   // may the box intrude?  centre ray against the footprint-inflated bounding sphere
+            float dc[3];
+            make_ray(cam, (float)px + 0.5f, (float)(H - 1 - py) + 0.5f, dc);
+            const float b = dc[0] * ctx.cull_oc[0] + dc[1] * ctx.cull_oc[1] + dc[2] * ctx.cull_oc[2];
+            const float dd = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
+            if (cull_cc_px <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc_px)) interior = false;
         }
-        float dc[3], dx[3], dy[3];
-        make_ray(cam, cx, cy, dc);
-        make_ray(cam, cx + 1.0f, cy, dx);
-        make_ray(cam, cx, cy + 1.0f, dy);
-        float acc[3] = {0, 0, 0};
-        uint32_t rem = 0xFFu;
-        while (rem) {
-            int k = __ffs(rem) - 1;
-            uint32_t key = keys[0];
-#pragma unroll
-            for (int j = 1; j < 8; j++) key = (k == j) ? keys[j] : key;
-            uint32_t m = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) m |= (keys[j] == key ? 1u : 0u) << j;
-            m &= rem;
-            rem &= ~m;
-            float cnt = (float)__popc(m);
-            float col[3];
-            uint32_t kind = key & 7u;
-            if (kind == KIND_SKY) { col[0] = fc[FC_SKY]; col[1] = fc[FC_SKY + 1]; col[2] = fc[FC_SKY + 2]; }
-            else if (kind == KIND_BOX) {
-                const float *lb = fc + FC_LIT_BOX + 3 * ((key >> 3) & 7u);
-                col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2];
-            } else {
-                const float *r = rooms + (key >> 6) * MWB_ROOM_WORDS;
-                uint32_t texw = (uint32_t)__float_as_int(r[RW_TEX]);
-                int tex_id = kind == KIND_FLOOR ? (texw >> 8) & 255u : kind == KIND_CEIL ? (texw >> 16) & 255u : texw & 255u;
-                const TexLds &T = tex[tex_id];
-                const float *lit = kind == KIND_FLOOR ? fc + FC_LIT_FLOOR : kind == KIND_CEIL ? fc + FC_LIT_CEIL
-                                                                                               : fc + FC_LIT_WALL + 3 * ((key >> 3) & 7u);
-                float sc_s = T.sc_s, sc_t = T.sc_t;   // TEX_DENSITY / texture size, miniworld.py:17,30-31
-                float s0, t0_, s1, t1, s2, t2;
-                bool valid;
-                if (!surf_texcoord(rooms, key, cam.eye, dc, sc_s, sc_t, s0, t0_)) {
-                    float dv[3];   // centre ray misses the plane: shade at the sample's own hit point
-                    make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
-                    surf_texcoord(rooms, key, cam.eye, dv, sc_s, sc_t, s0, t0_);
-                    valid = false; s1 = s2 = s0; t1 = t2 = t0_;
-                } else {
-                    bool v1 = surf_texcoord(rooms, key, cam.eye, dx, sc_s, sc_t, s1, t1);
-                    bool v2 = surf_texcoord(rooms, key, cam.eye, dy, sc_s, sc_t, s2, t2);
-                    valid = v1 && v2;
-                }
-                float texel[3];
-                sample_texture(d.texels, T, s0, t0_, s1, t1, s2, t2, valid, texel);
-#pragma unroll
-                for (int q = 0; q < 3; q++) col[q] = lit[q] * (texel[q] * (1.0f / 255.0f));
-            }
-#pragma unroll
-            for (int q = 0; q < 3; q++) acc[q] += cnt * col[q];
+        const bool edge = is_pixel && !interior;
+        const unsigned long long em = __ballot(edge);
+        if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)(py * W + px);
+        q_count += __popcll(em);
+        if (interior) ctx.pixel_interior(px, py, key & 0x0FFFFFFFu);
+        if (q_count >= WAVE) {
+            q_count -= WAVE;
+            const int p = queue[q_count + lane];
+            ctx.pixel_full(p % W, p / W);
         }
-        uint8_t out[3];
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            float v = acc[q] * 0.125f;
-            v = v < 0 ? 0 : (v > 1 ? 1 : v);
-            out[q] = (uint8_t)(int)floorf(v * 255.0f + 0.5f);   // RGBA32F -> unorm8 resolve
-        }
-        if (d.layout == MWB_LAYOUT_HWC) {
-            uint8_t *p = fb + (py * W + px) * 3;
-            p[0] = out[0]; p[1] = out[1]; p[2] = out[2];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 3; q++) fb[(q * W + px) * H + py] = out[q];
-        }
-        if (d.want_depth) {
-            int z16 = 65535;   // DEPTH_COMPONENT16 of sample 0; cleared to 1.0 where nothing was drawn
-            if ((keys[0] & 7u) != KIND_SKY) {
-                float zndc = zA - zB / t0;
-                float dd = 0.5f * zndc + 0.5f;
-                int z = (int)floorf(dd * 65535.0f + 0.5f);
-                z16 = z < 0 ? 0 : (z > 65535 ? 65535 : z);
-            }
-            // get_depth_map, opengl.py:362-367 in float32
-            float dm = (float)z16 / 65535.0f;
-            float clip_z = (dm - 0.5f) * 2.0f;
-            float wz = (float)(-2.0 * 100.0 * 0.04) / (clip_z * (float)(100.0 - 0.04) - (float)(100.0 + 0.04));
-            d.depth[(size_t)e * W * H + py * W + px] = wz;
-        }
+    }
+    if (lane < q_count) {
+        const int p = queue[lane];
+        ctx.pixel_full(p % W, p / W);
     }
     __syncthreads();
     {   // framebuffer LDS -> HBM, 16 bytes per lane
@@ -1028,6 +1174,7 @@ __global__ void intersect_kernel(MwbDev d, int e, double x, double z, double rad
 }
 
 // ====================================================================================== launch
+#define RENDER_THREADS 256
 size_t mwb_reset_lds_bytes(const MwbDev &d) {
     size_t b = (size_t)d.R_max * sizeof(WRoom) + (size_t)d.S_max * 4 * sizeof(double) + (size_t)d.R_max * sizeof(double) +
                (size_t)((d.R_max + 3) & ~3) * sizeof(int) + 624 * sizeof(uint32_t);
@@ -1035,7 +1182,7 @@ size_t mwb_reset_lds_bytes(const MwbDev &d) {
 }
 size_t mwb_render_lds_bytes(const MwbDev &d) {
     size_t b = (((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15) + MWB_FRAME_WORDS * 4 + sizeof(TexLds) * MWB_MAX_TEX + 16 +
-               (size_t)d.W * d.H * 3;
+               (RENDER_THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t) + (size_t)d.W * d.H * 3;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -1052,7 +1199,7 @@ void mwb_launch_prep(const MwbDev &d, hipStream_t s) {
     hipLaunchKernelGGL(prep_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d);
 }
 void mwb_launch_render(const MwbDev &d, hipStream_t s) {
-    render_kernel<256><<<dim3(d.N), dim3(256), mwb_render_lds_bytes(d), s>>>(d);
+    render_kernel<RENDER_THREADS><<<dim3(d.N), dim3(RENDER_THREADS), mwb_render_lds_bytes(d), s>>>(d);
 }
 void mwb_launch_intersect(const MwbDev &d, int env, double x, double z, double radius, int *result_dev, hipStream_t s) {
     hipLaunchKernelGGL(intersect_kernel, dim3(1), dim3(64), 0, s, d, env, x, z, radius, result_dev);
