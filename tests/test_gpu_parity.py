@@ -240,3 +240,29 @@ def test_random_view_sweep_matches_oracle(oracle_mod, env_id, task, args, mes, d
             assert d.max() <= 1, (env_id, dr, rnd, i, int(d.max()), int((d > 1).sum()))
             assert np.abs(dep[i] - refd).max() <= 1e-4, (env_id, dr, rnd, i)
     b.close()
+
+
+@pytest.mark.parametrize("env_id,n,steps,dr", [("MiniWorld-Maze-v0", 2048, 40, 0), ("MiniWorld-FourRooms-v0", 2048, 40, 1),
+                                               ("MiniWorld-MazeS3-v0", 1024, 40, 1), ("MiniWorld-Hallway-v0", 1024, 30, 1)])
+def test_fast_path_equals_full_sample_path(env_id, n, steps, dr, monkeypatch):
+    """The corner-ray interior classification must never change a result: tens of thousands of frames
+    rendered with it are bit-identical (obs and depth) to the same frames rendered with every pixel
+    resolved by the full 8-sample path (MWB_DEBUG=1 disables the classification at mwb_create)."""
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    fast = BatchedMiniWorld(env_id, num_envs=n, seed=31, domain_rand=dr, want_depth=True)
+    monkeypatch.setenv("MWB_DEBUG", "1")
+    full = BatchedMiniWorld(env_id, num_envs=n, seed=31, domain_rand=dr, want_depth=True)
+    monkeypatch.delenv("MWB_DEBUG")
+    assert torch.equal(fast.reset(), full.reset()) and torch.equal(fast.depth, full.depth)
+    g = torch.Generator().manual_seed(3)
+    for t in range(steps):
+        a = torch.randint(0, 3, (n,), generator=g, dtype=torch.int32)
+        fast.step(a)
+        full.step(a)
+        same = torch.equal(fast.obs, full.obs) and torch.equal(fast.depth, full.depth)
+        if not same:
+            bad = (fast.obs != full.obs).flatten(1).any(1).nonzero().flatten().tolist()
+            raise AssertionError((env_id, t, "envs with differing pixels", bad[:8], len(bad)))
+        assert torch.equal(fast.reward64, full.reward64)
+    fast.close(); full.close()
