@@ -508,9 +508,11 @@ extern "C" int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_ro
         int n = *n_rooms < max_rooms ? *n_rooms : max_rooms;
         if (n > 0) HIP_TRY(hipMemcpy(rooms, d.rooms + (size_t)env * d.R_max * MWB_ROOM_WORDS, (size_t)n * MWB_ROOM_WORDS * 4, hipMemcpyDeviceToHost));
     }
-    if (segs) {
+    if (segs) {   // device layout is transposed: element (i, c) of env e at segs[(i*4 + c) * N + e]
         int n = *n_segs < max_segs ? *n_segs : max_segs;
-        if (n > 0) HIP_TRY(hipMemcpy(segs, d.segs + (size_t)env * d.S_max * 4, (size_t)n * 4 * 8, hipMemcpyDeviceToHost));
+        if (n > 0)
+            HIP_TRY(hipMemcpy2D(segs, sizeof(double), d.segs + env, (size_t)d.N * sizeof(double), sizeof(double), (size_t)n * 4,
+                                hipMemcpyDeviceToHost));
     }
     return MWB_OK;
 }

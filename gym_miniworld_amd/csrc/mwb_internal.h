@@ -4,7 +4,8 @@
 //   sim  : per-env f64 pose / episode parameters (arrays of N), i32 counters, u8 flags
 //   rng  : per-env MT19937 state, N x 625 u32 (624 key words + position), env-major
 //   rooms: per-env room table, N x R_max x MWB_ROOM_WORDS f32 words (render kernel stages it in LDS)
-//   segs : per-env collision segments, N x S_max x 4 f64 (a.x a.z b.x b.z), reference order
+//   segs : collision segments, S_max x 4 x N f64 (a.x a.z b.x b.z; segment-major, env-minor so that
+//          one-env-per-lane reads coalesce), reference order per env
 //   frame: per-env render constants (camera basis, lit colours, box frame), N x FRAME_WORDS f32
 //   tex  : RGBA8 mip pyramids of the 7 textures, shared by all envs (L2 / Infinity Cache resident)
 //   out  : obs u8 [N,H,W,3] or [N,3,W,H], depth f32 [N,H,W], reward f32/f64 [N], done u8 [N]
@@ -84,7 +85,7 @@ struct MwbDev {
     uint8_t *need_reset;
     uint32_t *rng;          // [N][625]
     float *rooms;           // [N][R_max][MWB_ROOM_WORDS]
-    double *segs;           // [N][S_max][4]
+    double *segs;           // [S_max][4][N]
     float *frame;           // [N][MWB_FRAME_WORDS]
     const uint32_t *texels;
     const MwbTexDesc *tex_desc;   // [MWB_MAX_TEX] in device memory

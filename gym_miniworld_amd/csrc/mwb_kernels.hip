@@ -112,7 +112,7 @@ __device__ __forceinline__ double box_radius() {
     return sqrt(sx * sx + sz * sz) / 2;
 }
 
-__global__ void __launch_bounds__(256) step_kernel(MwbDev d, const int32_t *__restrict__ actions,
+__global__ void __launch_bounds__(64) step_kernel(MwbDev d, const int32_t *__restrict__ actions,
                                                    const uint8_t *__restrict__ skip) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= d.N) return;
@@ -144,10 +144,30 @@ __global__ void __launch_bounds__(256) step_kernel(MwbDev d, const int32_t *__re
         // pos + dir_vec*fwd + right_vec*drift with dir_vec=(cos,0,-sin), right_vec=(sin,0,cos)
         double nx = (ax + c * fd) + s * fwd_drift;
         double nz = (az + (-s) * fd) + c * fwd_drift;
-        const double *sg = d.segs + (size_t)e * d.S_max * 4;
+        // segments are stored transposed (segment-major, env-minor) so that the lanes of a wave - one
+        // env each - read consecutive addresses.  No early exit (keeps the loads independent); a
+        // segment whose bounding box grown by the radius (+1e-9 guard) excludes the point cannot be
+        // within the radius, so skipping it is exact.
+        const double *sg = d.segs + e;
+        const size_t N = (size_t)d.N;
         int ns = d.n_segs[e];
         bool hit = false;
-        for (int i = 0; i < ns && !hit; i++) hit = seg_hit(sg + i * 4, nx, nz, AGENT_RADIUS);
+        const double guard = AGENT_RADIUS + 1e-9;
+        for (int i0 = 0; i0 < ns; i0 += 8) {   // 8 segments (32 coalesced loads) in flight, then the tests
+            double q[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = (i0 + k < ns) ? i0 + k : ns - 1;   // clamp: re-testing a segment is harmless
+#pragma unroll
+                for (int c = 0; c < 4; c++) q[k][c] = sg[(size_t)(i * 4 + c) * N];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                bool nearby = nx >= fmin(q[k][0], q[k][2]) - guard && nx <= fmax(q[k][0], q[k][2]) + guard &&
+                              nz >= fmin(q[k][1], q[k][3]) - guard && nz <= fmax(q[k][1], q[k][3]) + guard;
+                if (nearby) hit = seg_hit(q[k], nx, nz, AGENT_RADIUS) || hit;
+            }
+        }
         if (!hit) {   // entity test, miniworld.py:946-957 (the box is the only other entity)
             double ddx = bx - nx, ddz = bz - nz;
             double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
@@ -192,6 +212,7 @@ struct WRoom {
     double height;
     double p_start[4], p_end[4], p_maxy[4];   // at most one portal per edge in the four tasks
     double min_x, max_x, min_z, max_z, area;
+    double edx[4], edz[4], elen[4];   // edge direction (p1 - p0) / norm and length, computed once
     int n_port[4], nbr[4];
     int tex_fam[3], tex_id[3];      // wall, floor, ceil
 };
@@ -222,6 +243,11 @@ struct WorldGen {
         }
         r.min_x = mnx; r.max_x = mxx; r.min_z = mnz; r.max_z = mxz;
         r.area = (mxx - mnx) * (mxz - mnz);
+        for (int e = 0; e < 4; e++) {   // edge direction as Room.__init__ / add_portal compute it
+            double ex = ox[(e + 1) & 3] - ox[e], ez = oz[(e + 1) & 3] - oz[e];
+            double len = sqrt((ex * ex + 0.0) + ez * ez);
+            r.edx[e] = ex / len; r.edz[e] = ez / len; r.elen[e] = len;
+        }
         r.height = height;
         r.tex_fam[0] = wall_fam; r.tex_fam[1] = floor_fam; r.tex_fam[2] = ceil_fam;
         return n_rooms++;
@@ -232,10 +258,8 @@ struct WorldGen {
         return add_room(ox, oz, 2.74, wall_fam, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES);
     }
     // edge direction as Room.__init__ / add_portal compute it: (p1 - p0) / norm
-    __device__ void edge(const WRoom &r, int e, double &dx, double &dz, double &len) const {
-        double ex = r.ox[(e + 1) & 3] - r.ox[e], ez = r.oz[(e + 1) & 3] - r.oz[e];
-        len = sqrt((ex * ex + 0.0) + ez * ez);
-        dx = ex / len; dz = ez / len;
+    __device__ __forceinline__ void edge(const WRoom &r, int e, double &dx, double &dz, double &len) const {
+        dx = r.edx[e]; dz = r.edz[e]; len = r.elen[e];
     }
     // Room.add_portal, miniworld.py:140-218; mode 0 start/end, 1 min_x/max_x, 2 min_z/max_z
     __device__ void add_portal(int ri, int e, int mode, double a, double b, bool has_max_y, double max_y_in,
@@ -259,22 +283,22 @@ struct WorldGen {
     }
     // connect_rooms, miniworld.py:757-843
     __device__ void connect_rooms(int ia, int ib, int mode, double lo, double hi, bool has_max_y, double max_y) {
+        // find_facing_edges (miniworld.py:771-790): first (i, j) in i-major order whose inward normals face
+        // each other and whose lines touch.  The 16 candidates are tested by 16 lanes; the lowest set
+        // bit of the ballot is the pair the sequential loops would return.
         int idx_a = -1, idx_b = -1;
-        for (int i = 0; i < 4 && idx_a < 0; i++)
-            for (int j = 0; j < 4; j++) {
-                double adx, adz, bdx, bdz, l;
-                edge(rooms[ia], i, adx, adz, l);
-                edge(rooms[ib], j, bdx, bdz, l);
-                // edge_norms = -cross(edge_dir, Y) = (dz, 0, -dx) (unit for axis-aligned edges)
-                double nax = adz, naz = -adx, nbx = bdz, nbz = -bdx;
-                double dotn = (nax * nbx + 0.0) + naz * nbz;
-                if (dotn > -0.9) continue;
-                double ddx = rooms[ib].ox[j] - rooms[ia].ox[i], ddz = rooms[ib].oz[j] - rooms[ia].oz[i];
-                double dd = (nax * ddx + 0.0) + naz * ddz;
-                if (dd > 0.05) continue;
-                idx_a = i; idx_b = j;
-                break;
-            }
+        {
+            const int ci = (lane >> 2) & 3, cj = lane & 3;
+            double adx = rooms[ia].edx[ci], adz = rooms[ia].edz[ci], bdx = rooms[ib].edx[cj], bdz = rooms[ib].edz[cj];
+            // edge_norms = -cross(edge_dir, Y) = (dz, 0, -dx) (unit for axis-aligned edges)
+            double nax = adz, naz = -adx, nbx = bdz, nbz = -bdx;
+            double dotn = (nax * nbx + 0.0) + naz * nbz;
+            double ddx = rooms[ib].ox[cj] - rooms[ia].ox[ci], ddz = rooms[ib].oz[cj] - rooms[ia].oz[ci];
+            double dd = (nax * ddx + 0.0) + naz * ddz;
+            bool okc = lane < 16 && !(dotn > -0.9) && !(dd > 0.05);
+            unsigned long long m = __ballot(okc);
+            if (m) { int first = __ffsll((long long)m) - 1; idx_a = first >> 2; idx_b = first & 3; }
+        }
         if (idx_a < 0) { fail = true; return; }
         double sa, ea, sb, eb;
         add_portal(ia, idx_a, mode, lo, hi, has_max_y, max_y, sa, ea);
@@ -352,18 +376,33 @@ struct WorldGen {
     }
     // MiniWorldEnv._gen_static_data, miniworld.py:981-998 (+ Room._gen_static_data 243-245, 311-375)
     __device__ void gen_static_data(bool use_rng, int S_max) {
-        for (int i = 0; i < n_rooms; i++)
-            for (int k = 0; k < 3; k++) {   // Texture.get, opengl.py:40-69
-                int fam = rooms[i].tex_fam[k];
-                int idx = use_rng ? rng.randint(0, c_texf_count[fam]) : 0;
-                rooms[i].tex_id[k] = c_texf_first[fam] + idx;
-            }
+        if (use_rng) {   // Texture.get, opengl.py:40-69: rng.int(0, n_variants) per room and slot, in order
+            for (int i = 0; i < n_rooms; i++)
+                for (int k = 0; k < 3; k++) {
+                    int fam = rooms[i].tex_fam[k];
+                    int idx = rng.randint(0, c_texf_count[fam]);
+                    __syncthreads();
+                    if (lane == 0) rooms[i].tex_id[k] = c_texf_first[fam] + idx;
+                }
+        } else {
+            for (int i = lane; i < n_rooms; i += WAVE)
+                for (int k = 0; k < 3; k++) rooms[i].tex_id[k] = c_texf_first[rooms[i].tex_fam[k]];
+        }
+        __syncthreads();
+        for (int i = lane; i < n_rooms; i += WAVE) {   // segments per room, lane-parallel
+            int c = 0;
+            for (int e = 0; e < 4; e++) c += edge_segs(rooms[i], e, nullptr);
+            seg_off[i] = c;
+        }
         __syncthreads();
         int off = 0;
-        for (int i = 0; i < n_rooms; i++) {
-            seg_off[i] = off;
-            for (int e = 0; e < 4; e++) off += edge_segs(rooms[i], e, nullptr);
+        for (int i = 0; i < n_rooms; i++) {   // exclusive prefix in room order (the reference's segment order)
+            int c = seg_off[i];
+            __syncthreads();
+            if (lane == 0) seg_off[i] = off;
+            off += c;
         }
+        __syncthreads();
         n_segs = off;
         if (n_segs > S_max) { fail = true; n_segs = S_max; }
         __syncthreads();
@@ -373,17 +412,20 @@ struct WorldGen {
         }
         __syncthreads();
         double sum = pairwise_area_sum(0, n_rooms);
-        // RandomState.choice(p): cdf = p.cumsum(); cdf /= cdf[-1]
+        // room_probs = area / sum (miniworld.py:997-998); RandomState.choice(p): cdf = p.cumsum(); cdf /= cdf[-1]
+        for (int i = lane; i < n_rooms; i += WAVE) cdf[i] = rooms[i].area / sum;   // the divisions, lane-parallel
+        __syncthreads();
         double acc = 0;
-        for (int i = 0; i < n_rooms; i++) {
-            double p = rooms[i].area / sum;
+        for (int i = 0; i < n_rooms; i++) {   // sequential cumsum, every lane the same
+            double p = cdf[i];
             acc = (i == 0) ? p : acc + p;
-            cdf[i] = acc;
+            __syncthreads();
+            if (lane == 0) cdf[i] = acc;
         }
         __syncthreads();
         double last = cdf[n_rooms - 1];
         __syncthreads();
-        for (int i = 0; i < n_rooms; i++) cdf[i] = cdf[i] / last;
+        for (int i = lane; i < n_rooms; i += WAVE) cdf[i] = cdf[i] / last;
         __syncthreads();
     }
     // MiniWorldEnv.intersect walls part, all lanes
@@ -568,8 +610,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         d.n_segs[e] = w.n_segs;
         d.need_reset[e] = 0;
     }
-    double *gsegs = d.segs + (size_t)e * d.S_max * 4;
-    for (int i = lane; i < w.n_segs * 4; i += WAVE) gsegs[i] = segs[i];
+    for (int i = lane; i < w.n_segs * 4; i += WAVE) d.segs[(size_t)i * d.N + e] = segs[i];   // transposed, see step_kernel
     float *grooms = d.rooms + (size_t)e * d.R_max * MWB_ROOM_WORDS;
     for (int ri = lane; ri < w.n_rooms; ri += WAVE) {
         const WRoom &r = rooms[ri];
@@ -1134,14 +1175,14 @@ __global__ void __launch_bounds__(THREADS) render_kernel(MwbDev d) {
         const unsigned long long em = __ballot(edge);
         if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)(py * W + px);
         q_count += __popcll(em);
-        if (interior) ctx.pixel_interior(px, py, key & 0x0FFFFFFFu);
+        if (interior && !(d.debug_flags & 4)) ctx.pixel_interior(px, py, key & 0x0FFFFFFFu);
         if (q_count >= WAVE) {
             q_count -= WAVE;
             const int p = queue[q_count + lane];
-            ctx.pixel_full(p % W, p / W);
+            if (!(d.debug_flags & 2)) ctx.pixel_full(p % W, p / W);
         }
     }
-    if (lane < q_count) {
+    if (lane < q_count && !(d.debug_flags & 2)) {
         const int p = queue[lane];
         ctx.pixel_full(p % W, p / W);
     }
@@ -1163,9 +1204,12 @@ __global__ void __launch_bounds__(THREADS) render_kernel(MwbDev d) {
 __global__ void intersect_kernel(MwbDev d, int e, double x, double z, double radius, int *result) {
     // MiniWorldEnv.intersect(agent, pos, radius), miniworld.py:933-959
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double *sg = d.segs + (size_t)e * d.S_max * 4;
     int ns = d.n_segs[e], res = 0;
-    for (int i = 0; i < ns && !res; i++) if (seg_hit(sg + i * 4, x, z, radius)) res = 1;
+    for (int i = 0; i < ns && !res; i++) {
+        double q[4];
+        for (int c = 0; c < 4; c++) q[c] = d.segs[(size_t)(i * 4 + c) * d.N + e];
+        if (seg_hit(q, x, z, radius)) res = 1;
+    }
     if (!res) {
         double ddx = d.box_x[e] - x, ddz = d.box_z[e] - z;
         if (sqrt(ddx * ddx + 0.0 + ddz * ddz) < radius + box_radius()) res = 2;
@@ -1187,7 +1231,7 @@ size_t mwb_render_lds_bytes(const MwbDev &d) {
 }
 
 void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *skip, hipStream_t s) {
-    hipLaunchKernelGGL(step_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d, actions, skip);
+    hipLaunchKernelGGL(step_kernel, dim3((d.N + 63) / 64), dim3(64), 0, s, d, actions, skip);
 }
 void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s) {
     hipLaunchKernelGGL(mark_reset_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d, mask);
