@@ -39,7 +39,11 @@ struct mwb_handle {
     bool timing;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used;
-    hipEvent_t *ev;   // the current pass' five events
+    hipEvent_t *ev;   // the current pass' events: 0-4 on the caller's stream, 5-6 around reset_kernel
+    // mwb_step overlaps world generation of the finished envs with the bulk render on a side stream
+    bool overlap_reset;
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
 };
 
 extern "C" const char *mwb_last_error(void) { return g_err.c_str(); }
@@ -211,7 +215,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
 #define A(ptr, n) if (rc == MWB_OK) rc = dev_alloc(h, &(ptr), (n))
     A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N); A(d.box_z, N); A(d.box_dir, N);
     A(d.box_color, N * 3); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
-    A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.need_reset, N);
+    A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.need_reset, N); A(d.reset_set, N);
     A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * MWB_ROOM_WORDS); A(d.segs, N * d.S_max * 4); A(d.frame, N * MWB_FRAME_WORDS);
     A(d.obs, N * d.W * d.H * 3);
     if (d.want_depth) { A(d.depth, N * d.W * d.H); }
@@ -224,6 +228,14 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     h->texels_dev = nullptr; d.texels = nullptr;
     h->seeded = false; h->textures_dirty = false; h->have_textures = false;
     h->timing = false; h->ev_used = 0; h->ev = nullptr;
+    { const char *no = getenv("MWB_NO_OVERLAP"); h->overlap_reset = !(no && atoi(no)); }
+    h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        mwb_destroy(h);
+        return set_err(MWB_EHIP, "mwb_create: could not create the side stream / events");
+    }
     for (int i = 0; i < MWB_MAX_TEX; i++) { h->tex_w[i] = 0; h->tex_h[i] = 0; }
     if (mwb_reset_lds_bytes(d) > 64 * 1024 || mwb_render_lds_bytes(d) > 64 * 1024) {
         mwb_destroy(h);
@@ -240,6 +252,9 @@ extern "C" int mwb_destroy(mwb_handle *h) {
     for (void *p : h->allocs) hipFree(p);
     if (h->texels_dev) hipFree(h->texels_dev);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->side) hipStreamDestroy(h->side);
     delete h;
     return MWB_OK;
 }
@@ -341,25 +356,26 @@ static int check_launch(const char *what) {
     return MWB_OK;
 }
 
+#define EVN 7
 static int timing_begin(mwb_handle *h, hipStream_t s) {
     if (!h->timing) return MWB_OK;
-    if (h->ev_used + 5 > h->ev_pool.size()) {
+    if (h->ev_used + EVN > h->ev_pool.size()) {
         size_t old = h->ev_pool.size();
-        h->ev_pool.resize(old + 5 * 256);
+        h->ev_pool.resize(old + EVN * 256);
         for (size_t i = old; i < h->ev_pool.size(); i++) HIP_TRY(hipEventCreate(&h->ev_pool[i]));
     }
     h->ev = &h->ev_pool[h->ev_used];
-    h->ev_used += 5;
+    h->ev_used += EVN;
     HIP_TRY(hipEventRecord(h->ev[0], s));
     return MWB_OK;
 }
 #define TMARK(i) do { if (h->timing) HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
 
-static int render_tail(mwb_handle *h, hipStream_t s) {
-    mwb_launch_prep(h->dev, s);
+static int render_tail(mwb_handle *h, int mode, hipStream_t s) {
+    mwb_launch_prep(h->dev, mode, s);
     int rc = check_launch("prep_kernel"); if (rc) return rc;
     TMARK(3);
-    mwb_launch_render(h->dev, s);
+    mwb_launch_render(h->dev, mode, s);
     rc = check_launch("render_kernel"); if (rc) return rc;
     TMARK(4);
     return MWB_OK;
@@ -379,11 +395,11 @@ extern "C" int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream) {
     rc = timing_begin(h, s); if (rc) return rc;
     mwb_launch_mark_reset(h->dev, mask_dev, s);
     rc = check_launch("mark_reset_kernel"); if (rc) return rc;
-    TMARK(1);
+    TMARK(1); TMARK(5);
     mwb_launch_reset(h->dev, s);
     rc = check_launch("reset_kernel"); if (rc) return rc;
-    TMARK(2);
-    return render_tail(h, s);
+    TMARK(6); TMARK(2);
+    return render_tail(h, 0, s);
 }
 
 extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask_dev, void *stream) {
@@ -394,18 +410,38 @@ extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t
     mwb_launch_step(h->dev, actions_dev, skip_mask_dev, s);
     rc = check_launch("step_kernel"); if (rc) return rc;
     TMARK(1);
-    mwb_launch_reset(h->dev, s);
+    if (!h->overlap_reset) {
+        TMARK(5);
+        mwb_launch_reset(h->dev, s);
+        rc = check_launch("reset_kernel"); if (rc) return rc;
+        TMARK(6); TMARK(2);
+        return render_tail(h, 0, s);
+    }
+    // fork: the few envs that ended are regenerated, prepared and rendered on the side stream while the
+    // caller's stream renders everybody else; join before returning control of the outputs
+    HIP_TRY(hipEventRecord(h->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->side));
+    mwb_launch_reset(h->dev, h->side);
     rc = check_launch("reset_kernel"); if (rc) return rc;
+    if (h->timing) HIP_TRY(hipEventRecord(h->ev[6], h->side));
+    mwb_launch_prep(h->dev, 1, h->side);
+    rc = check_launch("prep_kernel"); if (rc) return rc;
+    mwb_launch_render(h->dev, 1, h->side);
+    rc = check_launch("render_kernel"); if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev_join, h->side));
     TMARK(2);
-    return render_tail(h, s);
+    rc = render_tail(h, 2, s); if (rc) return rc;
+    HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+    return MWB_OK;
 }
 
 extern "C" int mwb_render(mwb_handle *h, void *stream) {
     int rc = ensure_ready(h); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     rc = timing_begin(h, s); if (rc) return rc;
-    TMARK(1); TMARK(2);
-    return render_tail(h, s);
+    TMARK(1); TMARK(5); TMARK(6); TMARK(2);
+    return render_tail(h, 0, s);
 }
 
 extern "C" int mwb_get_outputs(mwb_handle *h, mwb_outputs *out) {
@@ -532,11 +568,12 @@ extern "C" int mwb_timing_read(mwb_handle *h, double *ms_step, double *ms_reset,
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipDeviceSynchronize());
     double acc[4] = {0, 0, 0, 0};
-    int passes = (int)(h->ev_used / 5);
+    int passes = (int)(h->ev_used / EVN);
+    static const int A_[4] = {0, 5, 2, 3}, B_[4] = {1, 6, 3, 4};   // step, reset (its own stream), prep, render
     for (int p = 0; p < passes; p++)
         for (int i = 0; i < 4; i++) {
             float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[p * 5 + i], h->ev_pool[p * 5 + i + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[p * EVN + A_[i]], h->ev_pool[p * EVN + B_[i]]));
             acc[i] += ms;
         }
     int cnt = passes > 0 ? passes : 1;

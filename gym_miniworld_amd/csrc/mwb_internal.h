@@ -82,7 +82,8 @@ struct MwbDev {
     double *cam;            // [N][4] height, fwd_disp, pitch, fov_y
     double *sky_color, *light_pos, *light_color, *light_ambient;   // [N][3]
     int32_t *step_count, *n_rooms, *n_segs;
-    uint8_t *need_reset;
+    uint8_t *need_reset;    // set by step / mark_reset, consumed and cleared by reset_kernel
+    uint8_t *reset_set;     // the same flags, kept until the next step: which envs were (re)generated this pass
     uint32_t *rng;          // [N][625]
     float *rooms;           // [N][R_max][MWB_ROOM_WORDS]
     double *segs;           // [S_max][4][N]
@@ -101,8 +102,9 @@ struct MwbDev {
 void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *skip_mask, hipStream_t s);
 void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s);
 void mwb_launch_reset(const MwbDev &d, hipStream_t s);
-void mwb_launch_prep(const MwbDev &d, hipStream_t s);
-void mwb_launch_render(const MwbDev &d, hipStream_t s);
+// mode 0: every env; 1: only envs with reset_set; 2: only envs without (lets reset overlap the bulk render)
+void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s);
+void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s);
 void mwb_launch_intersect(const MwbDev &d, int env, double x, double z, double radius, int *result_dev, hipStream_t s);
 size_t mwb_reset_lds_bytes(const MwbDev &d);
 size_t mwb_render_lds_bytes(const MwbDev &d);

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(64) step_kernel(MwbDev d, const int32_t *__res
     if (e >= d.N) return;
     if (skip && skip[e]) {   // the fork's 'dummy' command, vec_env/subproc_vec_env.py:26-31
         d.reward[e] = -99.0f; d.reward64[e] = -99.0; d.done[e] = 0; d.ep_steps[e] = d.step_count[e];
-        d.need_reset[e] = 0;
+        d.need_reset[e] = 0; d.reset_set[e] = 0;
         return;
     }
     int sc = d.step_count[e] + 1;   // miniworld.py:663
@@ -194,12 +194,14 @@ __global__ void __launch_bounds__(64) step_kernel(MwbDev d, const int32_t *__res
     }
     d.reward64[e] = r; d.reward[e] = (float)r; d.done[e] = (uint8_t)done; d.ep_steps[e] = sc;
     d.need_reset[e] = (uint8_t)(done && d.auto_reset);   // worker auto-reset, vec_env/subproc_vec_env.py:10-13
+    d.reset_set[e] = (uint8_t)(done && d.auto_reset);
 }
 
 __global__ void mark_reset_kernel(MwbDev d, const uint8_t *__restrict__ mask) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= d.N) return;
     d.need_reset[e] = mask ? (mask[e] ? 1 : 0) : 1;
+    d.reset_set[e] = d.need_reset[e];
 }
 
 // ================================================================================= reset kernel
@@ -207,7 +209,7 @@ __global__ void mark_reset_kernel(MwbDev d, const uint8_t *__restrict__ mask) {
 // identical values (the RNG stream is inherently serial) and split the wide parts: the MT19937
 // twist, the circle-vs-segments tests of the placement loop and the emission of the room / segment
 // tables.  The float64 room store lives in LDS.
-struct WRoom {
+struct alignas(16) WRoom {
     double ox[4], oz[4];            // outline, reference order (miniworld.py:732-741, 826)
     double height;
     double p_start[4], p_end[4], p_maxy[4];   // at most one portal per edge in the four tasks
@@ -669,9 +671,10 @@ __device__ __forceinline__ void lit_color(const float *L, const float *amb, cons
     }
 }
 
-__global__ void __launch_bounds__(256) prep_kernel(MwbDev d) {
+__global__ void __launch_bounds__(256) prep_kernel(MwbDev d, int mode) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= d.N) return;
+    if (mode && (d.reset_set[e] != 0) != (mode == 1)) return;
     float *fc = d.frame + (size_t)e * MWB_FRAME_WORDS;
     double adir = d.agent_dir[e];
     double cam_h = d.cam[e * 4 + 0], cam_fd = d.cam[e * 4 + 1], cam_pitch = d.cam[e * 4 + 2], fov = d.cam[e * 4 + 3];
@@ -774,7 +777,11 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
     if (room < 0) return key;
     const bool xpos = dv[0] > 0, xnz = dv[0] != 0, zpos = dv[2] > 0, znz = dv[2] != 0, ypos = dv[1] > 0, yneg = dv[1] < 0;
     // per-ray reciprocals (one correctly rounded division each); plane distances are (c - o) * inv
-    const float ix = xnz ? 1.0f / dv[0] : 0.0f, iy = (ypos || yneg) ? 1.0f / dv[1] : 0.0f, iz = znz ? 1.0f / dv[2] : 0.0f;
+    // Sample rays (PATH == false) are part of the bit-exact spec: correctly rounded divisions.  Corner rays
+    // (PATH == true) only classify pixels, conservatively by 1/16 pixel, so v_rcp_f32 (1 ulp) is enough.
+    const float ix = xnz ? (PATH ? __builtin_amdgcn_rcpf(dv[0]) : 1.0f / dv[0]) : 0.0f;
+    const float iy = (ypos || yneg) ? (PATH ? __builtin_amdgcn_rcpf(dv[1]) : 1.0f / dv[1]) : 0.0f;
+    const float iz = znz ? (PATH ? __builtin_amdgcn_rcpf(dv[2]) : 1.0f / dv[2]) : 0.0f;
     const float tfloor = yneg ? (0.0f - o[1]) * iy : INFINITY;
     const int sx = xpos ? 0 : 2, sz = zpos ? 3 : 1;
     int steps = 0;
@@ -882,19 +889,17 @@ __device__ __forceinline__ void sample_texture(const uint32_t *__restrict__ texe
     int l0 = (int)fl; if (l0 > maxl) l0 = maxl;
     int l1 = l0 + 1 > maxl ? maxl : l0 + 1;
     float fr = (l0 == maxl) ? 0.0f : lambda - fl;
-    float c0[3];
+    // both levels are always fetched (l1 == l0 when there is nothing to blend) so that the eight texel
+    // loads are issued together and waited for once
+    float c0[3], c1[3];
     int w0 = T.w >> l0; if (w0 < 1) w0 = 1;
     int h0 = T.h >> l0; if (h0 < 1) h0 = 1;
+    int w1 = T.w >> l1; if (w1 < 1) w1 = 1;
+    int h1 = T.h >> l1; if (h1 < 1) h1 = 1;
     bilinear(texels, T.off[l0], w0, h0, ws, wt, c0);
-    rgb[0] = c0[0]; rgb[1] = c0[1]; rgb[2] = c0[2];
-    if (fr > 0.0f) {
-        float c1[3];
-        int w1 = T.w >> l1; if (w1 < 1) w1 = 1;
-        int h1 = T.h >> l1; if (h1 < 1) h1 = 1;
-        bilinear(texels, T.off[l1], w1, h1, ws, wt, c1);
+    bilinear(texels, T.off[l1], w1, h1, ws, wt, c1);
 #pragma unroll
-        for (int k = 0; k < 3; k++) rgb[k] = c0[k] + (c1[k] - c0[k]) * fr;
-    }
+    for (int k = 0; k < 3; k++) rgb[k] = c0[k] + (c1[k] - c0[k]) * fr;
 }
 
 // texture coordinates where ray (o, dv) meets the plane {axis = plane}; false if behind / parallel
@@ -965,6 +970,14 @@ struct RenderCtx {
         for (int q = 0; q < 3; q++) col[q] = lit[q] * (texel[q] * (1.0f / 255.0f));
     }
 
+    // rays through the +1 pixel neighbours (for the LOD differences): the ray is affine in the window
+    // coordinates, so they are the centre ray plus a per-frame constant (shading-only, tolerance-bound)
+    __device__ __forceinline__ void neighbour_rays(const float *dc, float *dx, float *dy) const {
+        const float sx = 2.0f * cam.invW * cam.TW, sy = 2.0f * cam.invH * cam.TH;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { dx[k] = dc[k] + cam.S[k] * sx; dy[k] = dc[k] + cam.U[k] * sy; }
+    }
+
     // acc = sum over the 8 samples of their colour; t_s0 / kind of sample 0 for the depth map
     __device__ __forceinline__ void write_pixel(int px, int py, const float *acc, bool s0_drawn, float t_s0) const {
         uint8_t out[3];
@@ -1008,8 +1021,7 @@ struct RenderCtx {
         float acc[3] = {0, 0, 0};
         float dc[3], dx[3], dy[3];
         make_ray(cam, cx, cy, dc);
-        make_ray(cam, cx + 1.0f, cy, dx);
-        make_ray(cam, cx, cy + 1.0f, dy);
+        neighbour_rays(dc, dx, dy);
 #pragma unroll 1
         for (int k = 0; k < 8; k++) {
             float dv[3], th;
@@ -1056,8 +1068,7 @@ struct RenderCtx {
         const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
         float dc[3], dx[3], dy[3], col[3], acc[3];
         make_ray(cam, cx, cy, dc);
-        make_ray(cam, cx + 1.0f, cy, dx);
-        make_ray(cam, cx, cy + 1.0f, dy);
+        neighbour_rays(dc, dx, dy);
         shade(key, 0, cx, cy, dc, dx, dy, col);
 #pragma unroll
         for (int q = 0; q < 3; q++) acc[q] = 8.0f * col[q];
@@ -1085,9 +1096,10 @@ struct RenderCtx {
 #define QUEUE_CAP 128
 
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS) render_kernel(MwbDev d) {
+__global__ void __launch_bounds__(THREADS, 4) render_kernel(MwbDev d, int mode) {
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
+    if (mode && (d.reset_set[e] != 0) != (mode == 1)) return;   // block-uniform
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = d.W, H = d.H;
     int n_rooms = d.n_rooms[e];
@@ -1098,7 +1110,7 @@ __global__ void __launch_bounds__(THREADS) render_kernel(MwbDev d) {
     TexLds *tex = (TexLds *)(smem + off); off += sizeof(TexLds) * MWB_MAX_TEX;
     int *cam_room_s = (int *)(smem + off); off += 16;
     uint16_t *queues = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
-    uint8_t *fb = smem + off;
+    uint8_t *fb = d.obs + (size_t)e * W * H * 3;   // straight to HBM; the XCD's L2 merges a frame's byte stores
 
     {   // stage the room table, the frame constants and the texture descriptors
         const float4 *src = (const float4 *)(d.rooms + (size_t)e * d.R_max * MWB_ROOM_WORDS);
@@ -1186,18 +1198,6 @@ __global__ void __launch_bounds__(THREADS) render_kernel(MwbDev d) {
         const int p = queue[lane];
         ctx.pixel_full(p % W, p / W);
     }
-    __syncthreads();
-    {   // framebuffer LDS -> HBM, 16 bytes per lane
-        const int nbytes = W * H * 3;
-        uint8_t *dst = d.obs + (size_t)e * nbytes;
-        if ((nbytes & 15) == 0) {
-            const uint4 *s4 = (const uint4 *)fb;
-            uint4 *d4 = (uint4 *)dst;
-            for (int i = tid; i < nbytes / 16; i += THREADS) d4[i] = s4[i];
-        } else {
-            for (int i = tid; i < nbytes; i += THREADS) dst[i] = fb[i];
-        }
-    }
 }
 
 // ============================================================================== small utilities
@@ -1226,7 +1226,8 @@ size_t mwb_reset_lds_bytes(const MwbDev &d) {
 }
 size_t mwb_render_lds_bytes(const MwbDev &d) {
     size_t b = (((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15) + MWB_FRAME_WORDS * 4 + sizeof(TexLds) * MWB_MAX_TEX + 16 +
-               (RENDER_THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t) + (size_t)d.W * d.H * 3;
+               (RENDER_THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
+    b += (size_t)(d.debug_flags >> 8) * 1024;   // MWB_DEBUG bits 8+: KiB of LDS padding (occupancy experiments)
     return (b + 15) & ~(size_t)15;
 }
 
@@ -1239,11 +1240,11 @@ void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s) 
 void mwb_launch_reset(const MwbDev &d, hipStream_t s) {
     hipLaunchKernelGGL(reset_kernel, dim3(d.N), dim3(WAVE), mwb_reset_lds_bytes(d), s, d);
 }
-void mwb_launch_prep(const MwbDev &d, hipStream_t s) {
-    hipLaunchKernelGGL(prep_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d);
+void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s) {
+    hipLaunchKernelGGL(prep_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d, mode);
 }
-void mwb_launch_render(const MwbDev &d, hipStream_t s) {
-    render_kernel<RENDER_THREADS><<<dim3(d.N), dim3(RENDER_THREADS), mwb_render_lds_bytes(d), s>>>(d);
+void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
+    render_kernel<RENDER_THREADS><<<dim3(d.N), dim3(RENDER_THREADS), mwb_render_lds_bytes(d), s>>>(d, mode);
 }
 void mwb_launch_intersect(const MwbDev &d, int env, double x, double z, double radius, int *result_dev, hipStream_t s) {
     hipLaunchKernelGGL(intersect_kernel, dim3(1), dim3(64), 0, s, d, env, x, z, radius, result_dev);
