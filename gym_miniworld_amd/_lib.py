@@ -34,6 +34,7 @@ class MwbOutputs(ctypes.Structure):
         ("obs", ctypes.c_void_p), ("depth", ctypes.c_void_p), ("reward", ctypes.c_void_p),
         ("reward64", ctypes.c_void_p), ("done", ctypes.c_void_p), ("ep_steps", ctypes.c_void_p),
         ("obs_bytes", ctypes.c_size_t), ("depth_bytes", ctypes.c_size_t),
+        ("stack", ctypes.c_void_p), ("stack_bytes", ctypes.c_size_t),
     ]
 
 
@@ -46,7 +47,7 @@ class MwbState(ctypes.Structure):
 EXPORTS = [
     "mwb_create", "mwb_destroy", "mwb_last_error", "mwb_abi_version", "mwb_set_texture", "mwb_seed", "mwb_reset",
     "mwb_step", "mwb_render", "mwb_get_outputs", "mwb_get_state", "mwb_set_agent", "mwb_intersect",
-    "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read",
+    "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read", "mwb_stack_enable", "mwb_stack_update",
 ]
 
 _lib = None
@@ -83,6 +84,8 @@ def load():
     L.mwb_intersect.argtypes = [vp, i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(i32)]
     L.mwb_get_geometry.argtypes = [vp, i32, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.mwb_timing_enable.argtypes = [vp, i32]
+    L.mwb_stack_enable.argtypes = [vp, i32, i32]
+    L.mwb_stack_update.argtypes = [vp, i32, vp]
     L.mwb_timing_read.argtypes = [vp] + [ctypes.POINTER(ctypes.c_double)] * 4 + [ctypes.POINTER(i32)]
     if L.mwb_abi_version() != ABI_VERSION:
         raise MwbError("libmwbatch.so ABI version mismatch")

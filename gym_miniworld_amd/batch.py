@@ -229,6 +229,23 @@ class BatchedMiniWorld:
                                            ctypes.byref(ns)))
         return rooms[:nr.value], segs[:ns.value]
 
+    # ------------------------------------------------------------------------------ frame stack
+    def stack_enable(self, nstack=4, dtype="float32"):
+        """Library-owned [N, nstack*3, W, H] stack kept by one fused HIP pass per step
+        (VecPyTorchFrameStack + .float(), pytorch-a2c-ppo-acktr/envs.py:117-165). Needs layout='CWH'."""
+        torch = self.torch
+        is_f = {"float32": 1, "uint8": 0}[dtype]
+        _lib.check(self.L.mwb_stack_enable(self.h, int(nstack), is_f))
+        out = _lib.MwbOutputs()
+        _lib.check(self.L.mwb_get_outputs(self.h, ctypes.byref(out)))
+        shape = (self.num_envs, nstack * 3, self.W, self.H)
+        self.stack = torch.as_tensor(_DevView(out.stack, shape, "<f4" if is_f else "|u1", self), device=self.device)
+        return self.stack
+
+    def stack_update(self, after_reset=False):
+        _lib.check(self.L.mwb_stack_update(self.h, int(bool(after_reset)), self._stream()))
+        return self.stack
+
     def timing_enable(self, on=True):
         _lib.check(self.L.mwb_timing_enable(self.h, int(on)))
 

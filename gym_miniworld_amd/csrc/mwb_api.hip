@@ -42,6 +42,9 @@ struct mwb_handle {
     hipEvent_t *ev;   // the current pass' events: 0-4 on the caller's stream, 5-6 around reset_kernel
     // mwb_step overlaps world generation of the finished envs with the bulk render on a side stream
     bool overlap_reset;
+    void *stack;
+    int stack_n, stack_dtype;
+    size_t stack_bytes;
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
 };
@@ -230,6 +233,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     h->timing = false; h->ev_used = 0; h->ev = nullptr;
     { const char *no = getenv("MWB_NO_OVERLAP"); h->overlap_reset = !(no && atoi(no)); }
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
+    h->stack = nullptr; h->stack_n = 0; h->stack_dtype = 0; h->stack_bytes = 0;
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -451,7 +455,32 @@ extern "C" int mwb_get_outputs(mwb_handle *h, mwb_outputs *out) {
     out->ep_steps = d.ep_steps;
     out->obs_bytes = (size_t)d.N * d.W * d.H * 3;
     out->depth_bytes = d.want_depth ? (size_t)d.N * d.W * d.H * 4 : 0;
+    out->stack = h->stack; out->stack_bytes = h->stack_bytes;
     return MWB_OK;
+}
+
+// ---------------------------------------------------------------------------------- frame stack
+extern "C" int mwb_stack_enable(mwb_handle *h, int nstack, int dtype) {
+    if (!h) return set_err(MWB_EINVAL, "mwb_stack_enable: null handle");
+    const MwbDev &d = h->dev;
+    if (nstack < 1 || nstack > 16 || (dtype != 0 && dtype != 1)) return set_err(MWB_EINVAL, "mwb_stack_enable: bad nstack / dtype");
+    if (d.layout != MWB_LAYOUT_CWH) return set_err(MWB_EINVAL, "mwb_stack_enable: the frame stack is channel-first, create the handle with MWB_LAYOUT_CWH");
+    if ((d.W * d.H) % 4) return set_err(MWB_EINVAL, "mwb_stack_enable: W*H must be a multiple of 4");
+    if (h->stack) return set_err(MWB_ESTATE, "mwb_stack_enable: already enabled");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    size_t bytes = (size_t)d.N * nstack * 3 * d.W * d.H * (dtype == 1 ? 4 : 1);
+    uint8_t *p = nullptr;
+    int rc = dev_alloc(h, &p, bytes);
+    if (rc) return rc;
+    h->stack = p; h->stack_n = nstack; h->stack_dtype = dtype; h->stack_bytes = bytes;
+    return MWB_OK;
+}
+
+extern "C" int mwb_stack_update(mwb_handle *h, int after_reset, void *stream) {
+    if (!h || !h->stack) return set_err(MWB_ESTATE, "mwb_stack_update: call mwb_stack_enable first");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    mwb_launch_stack(h->dev, h->stack, h->stack_n, h->stack_dtype, after_reset, (hipStream_t)stream);
+    return check_launch("stack_kernel");
 }
 
 // -------------------------------------------------------------------------------- introspection

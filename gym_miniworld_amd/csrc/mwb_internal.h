@@ -105,6 +105,7 @@ void mwb_launch_reset(const MwbDev &d, hipStream_t s);
 // mode 0: every env; 1: only envs with reset_set; 2: only envs without (lets reset overlap the bulk render)
 void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s);
 void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s);
+void mwb_launch_stack(const MwbDev &d, void *stack, int nstack, int dtype, int after_reset, hipStream_t s);
 void mwb_launch_intersect(const MwbDev &d, int env, double x, double z, double radius, int *result_dev, hipStream_t s);
 size_t mwb_reset_lds_bytes(const MwbDev &d);
 size_t mwb_render_lds_bytes(const MwbDev &d);

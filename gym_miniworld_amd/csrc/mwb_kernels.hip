@@ -1200,6 +1200,46 @@ __global__ void __launch_bounds__(THREADS, 4) render_kernel(MwbDev d, int mode) 
     }
 }
 
+// ================================================================================== frame stack
+// VecPyTorchFrameStack.step_wait / reset (pytorch-a2c-ppo-acktr/envs.py:149-162) fused with VecPyTorch's
+// uint8 -> float conversion (envs.py:128): one streaming pass, 16 bytes per lane.  HBM-bound: per env it
+// reads (C-3) planes + the new observation and writes C planes.
+template <typename V, bool IS_FLOAT>
+__global__ void __launch_bounds__(256) stack_kernel(MwbDev d, V *__restrict__ stack, int C, int after_reset) {
+    const int e = blockIdx.y;
+    const int plane4 = (d.W * d.H) / 4;   // vectors of 4 pixels per channel plane
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= plane4) return;
+    V *base = stack + (size_t)e * C * plane4;
+    const bool clear = after_reset || d.done[e];
+    V zero;
+    memset(&zero, 0, sizeof(V));
+    for (int c = 0; c < C - 3; c++) {
+        V v = zero;
+        if (!clear) v = base[(size_t)(c + 3) * plane4 + j];
+        base[(size_t)c * plane4 + j] = v;
+    }
+    const uint32_t *obs = (const uint32_t *)(d.obs + (size_t)e * 3 * d.W * d.H);   // CWH: [3][W][H]
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint32_t p = obs[(size_t)k * plane4 + j];
+        V v;
+        if constexpr (IS_FLOAT) {
+            v.x = (float)(p & 255u); v.y = (float)((p >> 8) & 255u); v.z = (float)((p >> 16) & 255u); v.w = (float)(p >> 24);
+        } else {
+            v = p;
+        }
+        base[(size_t)(C - 3 + k) * plane4 + j] = v;
+    }
+}
+
+void mwb_launch_stack(const MwbDev &d, void *stack, int nstack, int dtype, int after_reset, hipStream_t s) {
+    const int plane4 = (d.W * d.H) / 4;
+    dim3 grid((plane4 + 255) / 256, d.N);
+    if (dtype == 1) stack_kernel<float4, true><<<grid, dim3(256), 0, s>>>(d, (float4 *)stack, nstack * 3, after_reset);
+    else stack_kernel<uint32_t, false><<<grid, dim3(256), 0, s>>>(d, (uint32_t *)stack, nstack * 3, after_reset);
+}
+
 // ============================================================================== small utilities
 __global__ void intersect_kernel(MwbDev d, int e, double x, double z, double radius, int *result) {
     // MiniWorldEnv.intersect(agent, pos, radius), miniworld.py:933-959

@@ -94,8 +94,8 @@ class MiniWorldVecEnv(VecEnv):
         if self.nstack:
             assert transpose, "frame stacking follows VecPyTorchFrameStack: channel-first observations"
             shape = (shape[0] * self.nstack,) + shape[1:]
-            self.stackedobs = torch.zeros((num_envs,) + shape, dtype=torch.float32 if to_float else torch.uint8,
-                                          device=b.device)
+            # fused in the library: shift + zero-on-done + append + uint8->float in one HBM pass
+            self.stackedobs = b.stack_enable(self.nstack, "float32" if to_float else "uint8")
         VecEnv.__init__(self, num_envs, Box(0, 255, shape, np.float32 if to_float else np.uint8), Discrete(3))
         self.device = b.device
         self.feature_info = feature_info
@@ -104,19 +104,10 @@ class MiniWorldVecEnv(VecEnv):
 
     # ---------------------------------------------------------------------------------- helpers
     def _obs_out(self, done=None):
+        if self.nstack:   # VecPyTorchFrameStack.reset / step_wait, envs.py:149-162
+            return self.batch.stack_update(after_reset=done is None)
         obs = self.batch.obs
-        if self.to_float:
-            obs = obs.float()   # torch.from_numpy(obs).float().to(device), envs.py:119,128
-        if not self.nstack:
-            return obs
-        d0 = self.shape_dim0
-        if done is None:   # reset: VecPyTorchFrameStack.reset, envs.py:158-162
-            self.stackedobs.zero_()
-        else:              # step_wait, envs.py:149-156: shift, zero the finished envs, append
-            self.stackedobs[:, :-d0] = self.stackedobs[:, d0:].clone()
-            self.stackedobs[done.bool()] = 0
-        self.stackedobs[:, -d0:] = obs
-        return self.stackedobs
+        return obs.float() if self.to_float else obs   # torch.from_numpy(obs).float().to(device), envs.py:119,128
 
     # ----------------------------------------------------------------------------------- VecEnv
     def reset(self):

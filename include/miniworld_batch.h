@@ -71,6 +71,8 @@ typedef struct mwb_outputs {
     uint8_t *done;      /* u8  [N]                                                                */
     int32_t *ep_steps;  /* i32 [N]  step_count of the transition just taken (before auto-reset)   */
     size_t obs_bytes, depth_bytes;
+    void *stack;        /* frame stack [N, nstack*3, W, H], f32 or u8 (mwb_stack_enable), or NULL              */
+    size_t stack_bytes;
 } mwb_outputs;
 
 /* host-side snapshot of the simulator state of a contiguous env range, for tests / debugging;
@@ -121,6 +123,15 @@ int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask
 /* replaces: MiniWorldEnv.render_obs / render_depth (miniworld.py:1160-1220) for the whole batch */
 int mwb_render(mwb_handle *h, void *stream);
 int mwb_get_outputs(mwb_handle *h, mwb_outputs *out);
+
+/* ---- learner-side layout fusion ---------------------------------------- */
+/* replaces: VecPyTorchFrameStack + VecPyTorch's .float() (pytorch-a2c-ppo-acktr/envs.py:117-165): a
+ * library-owned channel-first stack [N, nstack*3, W, H] (needs MWB_LAYOUT_CWH), dtype 0 = u8, 1 = f32
+ * (values 0..255).  mwb_stack_update(after_reset != 0) implements reset(): zero, newest obs in the last 3
+ * channels (envs.py:158-162); after_reset == 0 implements step_wait(): shift by 3 channels, zero the envs
+ * whose `done` is set, append the newest obs (envs.py:149-156) - one pass over the stack. */
+int mwb_stack_enable(mwb_handle *h, int nstack, int dtype);
+int mwb_stack_update(mwb_handle *h, int after_reset, void *stream);
 
 /* ---- introspection (tests, Gym single-env view) ------------------------------------------- */
 int mwb_get_state(mwb_handle *h, int first_env, int count, mwb_state *out);          /* synchronous */

@@ -266,3 +266,41 @@ def test_fast_path_equals_full_sample_path(env_id, n, steps, dr, monkeypatch):
             raise AssertionError((env_id, t, "envs with differing pixels", bad[:8], len(bad)))
         assert torch.equal(fast.reward64, full.reward64)
     fast.close(); full.close()
+
+
+@pytest.mark.parametrize("env_id,kwargs,task,args,mes", [
+    ("MiniWorld-OneRoomS6Fast-v0", {}, "OneRoom", [6], 50),          # envs/oneroom.py:52-66: params override, no DR
+    ("MiniWorld-MazeS3Fast-v0", {}, "Maze", [3, 3, 3], 300),          # envs/maze.py:123-141
+    ("MiniWorld-MazeS2-v0", {}, "Maze", [2, 2, 3], 0),                # envs/maze.py:115-117
+    ("MiniWorld-Hallway-v0", {"task_args": [6]}, "Hallway", [6], 0),  # Hallway(length=6), hallway.py:13
+    ("MiniWorld-Maze-v0", {"task_args": [2, 4, 2.5], "max_episode_steps": 200}, "Maze", [2, 4, 2.5], 200),
+])
+def test_constructor_variants_match_oracle(oracle_mod, env_id, kwargs, task, args, mes):
+    """Constructor parameters of the task classes and custom DomainParams tables reach the kernels:
+    state bit-exact after reset, rewards/dones exact over a rollout, first observation +-1 LSB."""
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld, ENV_SPECS
+    O = oracle_mod
+    n = 12
+    b = BatchedMiniWorld(env_id, num_envs=n, seed=77, **kwargs)
+    spec_params = ENV_SPECS[env_id][3]
+    table = spec_params().to_table() if spec_params else None
+    envs = [O.OracleEnv(task, seed=77 + i, domain_rand=b.domain_rand, task_args=args, max_episode_steps=mes, params=table)
+            for i in range(n)]
+    obs = b.reset().cpu().numpy()
+    for i, e in enumerate(envs):
+        assert np.abs(obs[i].astype(int) - e.reset().astype(int)).max() <= 1
+    assert_state_equal(b.get_state(), oracle_states(envs), tag=env_id)
+    assert b.max_episode_steps == envs[0].state().max_episode_steps
+    rng = np.random.default_rng(2)
+    for t in range(120):
+        a = rng.choice(3, size=n, p=[0.2, 0.2, 0.6]).astype(np.int32)
+        b.step(torch.from_numpy(a))
+        rew, done = b.reward64.cpu().numpy(), b.done.cpu().numpy()
+        for i, e in enumerate(envs):
+            _, r, d, _ = e.step(int(a[i]))
+            assert r == rew[i] and d == bool(done[i]), (env_id, t, i)
+            if d:
+                e.reset(render=False)
+    assert_state_equal(b.get_state(), oracle_states(envs), exact_pose=False, tag=env_id + " end")
+    b.close()

@@ -119,3 +119,20 @@ def test_gym_view_returns_terminal_obs_without_autoreset(oracle_mod):
     assert d and env.step_count == 100   # timeout at max_episode_steps, state kept (no reset happened)
     assert np.abs(obs.astype(int) - ref.render_obs().astype(int)).max() <= 1
     env.close()
+
+
+def test_fused_stack_u8_and_bandwidth_shape():
+    """The uint8 variant of the fused stack equals the float one; the stack tensor is library-owned."""
+    import torch
+    from gym_miniworld_amd.vec_env import MiniWorldVecEnv
+    n = 64
+    f = MiniWorldVecEnv("MiniWorld-OneRoomS6-v0", n, seed=8, frame_stack=4, to_float=True)
+    u = MiniWorldVecEnv("MiniWorld-OneRoomS6-v0", n, seed=8, frame_stack=4, to_float=False)
+    assert torch.equal(f.reset(), u.reset().float())
+    g = torch.Generator().manual_seed(2)
+    for t in range(110):
+        a = torch.randint(0, 3, (n, 1), generator=g)
+        sf, rf, df, _ = f.step(a)
+        su, ru, du, _ = u.step(a)
+        assert su.dtype == torch.uint8 and torch.equal(sf, su.float()) and np.array_equal(df, du)
+    f.close(); u.close()
