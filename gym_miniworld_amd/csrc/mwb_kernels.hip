@@ -927,8 +927,15 @@ struct RenderCtx {
     int n_rooms, cam_room, W, H, layout, dbg;
     float cull_cc, cull_oc[3], zA, zB;
 
-    __device__ __forceinline__ void shade(uint32_t key, int first_k, float cx, float cy, const float *dc, const float *dx,
-                                          const float *dy, float *col) const {
+    // rays through the +1 pixel neighbours (for the LOD differences): the ray is affine in the window
+    // coordinates, so they are the centre ray plus a per-frame constant (shading-only, tolerance-bound)
+    __device__ __forceinline__ void neighbour_rays(const float *dc, float *dx, float *dy) const {
+        const float sx = 2.0f * cam.invW * cam.TW, sy = 2.0f * cam.invH * cam.TH;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { dx[k] = dc[k] + cam.S[k] * sx; dy[k] = dc[k] + cam.U[k] * sy; }
+    }
+
+    __device__ __forceinline__ void shade(uint32_t key, int first_k, float cx, float cy, float *col) const {
         const uint32_t kind = key & 7u, side = (key >> 3) & 7u;
         if (kind == KIND_SKY) { col[0] = fc[FC_SKY]; col[1] = fc[FC_SKY + 1]; col[2] = fc[FC_SKY + 2]; return; }
         if (kind == KIND_BOX) {
@@ -952,6 +959,11 @@ struct RenderCtx {
         const float plane = wall ? wall_plane : (kind == KIND_CEIL ? height : 0.0f);
         // s = (a - u_org) * u_sgn * sc_s for walls, a * sc_s for floor / ceiling
         const float u_org = wall ? sd[RS_UORG] : 0.0f, u_scale = (wall ? sd[RS_USGN] : 1.0f) * T.sc_s;
+        // centre ray and the rays through the +1 pixel neighbours, recomputed here rather than kept live
+        // across the sample loop (registers are what limits occupancy)
+        float dc[3], dx[3], dy[3];
+        make_ray(cam, cx, cy, dc);
+        neighbour_rays(dc, dx, dy);
         float s0, t0, s1, t1, s2, t2;
         bool valid;
         if (!plane_texcoord(axis, plane, u_org, u_scale, T.sc_t, cam.eye, dc, s0, t0)) {
@@ -968,14 +980,6 @@ struct RenderCtx {
         sample_texture(texels, T, s0, t0, s1, t1, s2, t2, valid, texel);
 #pragma unroll
         for (int q = 0; q < 3; q++) col[q] = lit[q] * (texel[q] * (1.0f / 255.0f));
-    }
-
-    // rays through the +1 pixel neighbours (for the LOD differences): the ray is affine in the window
-    // coordinates, so they are the centre ray plus a per-frame constant (shading-only, tolerance-bound)
-    __device__ __forceinline__ void neighbour_rays(const float *dc, float *dx, float *dy) const {
-        const float sx = 2.0f * cam.invW * cam.TW, sy = 2.0f * cam.invH * cam.TH;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { dx[k] = dc[k] + cam.S[k] * sx; dy[k] = dc[k] + cam.U[k] * sy; }
     }
 
     // acc = sum over the 8 samples of their colour; t_s0 / kind of sample 0 for the depth map
@@ -1019,9 +1023,6 @@ struct RenderCtx {
         uint32_t key_s0 = 0;
         float t_s0 = INFINITY;
         float acc[3] = {0, 0, 0};
-        float dc[3], dx[3], dy[3];
-        make_ray(cam, cx, cy, dc);
-        neighbour_rays(dc, dx, dy);
 #pragma unroll 1
         for (int k = 0; k < 8; k++) {
             float dv[3], th;
@@ -1046,7 +1047,7 @@ struct RenderCtx {
                 else if (c3 == 0) { k3 = key; c3 = 1; firsts |= k << 9; }
                 else {
                     float col[3];
-                    shade(key, k, cx, cy, dc, dx, dy, col);
+                    shade(key, k, cx, cy, col);
                     acc[0] += col[0]; acc[1] += col[1]; acc[2] += col[2];
                 }
             }
@@ -1054,7 +1055,7 @@ struct RenderCtx {
 #pragma unroll 1
         for (int it = 0; it < 4 && c0 > 0; it++) {
             float col[3];
-            shade(k0, firsts & 7, cx, cy, dc, dx, dy, col);
+            shade(k0, firsts & 7, cx, cy, col);
             const float cnt = (float)c0;
 #pragma unroll
             for (int q = 0; q < 3; q++) acc[q] += cnt * col[q];
@@ -1066,10 +1067,8 @@ struct RenderCtx {
     // a pixel whose 8 samples provably see one room surface: one shade, colour x 8 / 8
     __device__ __forceinline__ void pixel_interior(int px, int py, uint32_t key) const {
         const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
-        float dc[3], dx[3], dy[3], col[3], acc[3];
-        make_ray(cam, cx, cy, dc);
-        neighbour_rays(dc, dx, dy);
-        shade(key, 0, cx, cy, dc, dx, dy, col);
+        float col[3], acc[3];
+        shade(key, 0, cx, cy, col);
 #pragma unroll
         for (int q = 0; q < 3; q++) acc[q] = 8.0f * col[q];
         float t_s0 = 1.0f;
@@ -1096,7 +1095,7 @@ struct RenderCtx {
 #define QUEUE_CAP 128
 
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS, 4) render_kernel(MwbDev d, int mode) {
+__global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d, int mode) {
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
     if (mode && (d.reset_set[e] != 0) != (mode == 1)) return;   // block-uniform
@@ -1129,9 +1128,11 @@ __global__ void __launch_bounds__(THREADS, 4) render_kernel(MwbDev d, int mode) 
     ctx.depth = d.want_depth ? d.depth + (size_t)e * W * H : nullptr;
     ctx.n_rooms = n_rooms; ctx.W = W; ctx.H = H; ctx.layout = d.layout; ctx.dbg = d.debug_flags;
     Cam &cam = ctx.cam;
+    // frame constants are workgroup-uniform: pin them to scalar registers
+    auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
 #pragma unroll
-    for (int k = 0; k < 3; k++) { cam.eye[k] = fc[FC_EYE + k]; cam.F[k] = fc[FC_F + k]; cam.S[k] = fc[FC_S + k]; cam.U[k] = fc[FC_U + k]; }
-    cam.TW = fc[FC_TW]; cam.TH = fc[FC_TH];
+    for (int k = 0; k < 3; k++) { cam.eye[k] = uni(fc[FC_EYE + k]); cam.F[k] = uni(fc[FC_F + k]); cam.S[k] = uni(fc[FC_S + k]); cam.U[k] = uni(fc[FC_U + k]); }
+    cam.TW = uni(fc[FC_TW]); cam.TH = uni(fc[FC_TH]);
     cam.Wf = (float)W; cam.Hf = (float)H; cam.invW = 1.0f / (float)W; cam.invH = 1.0f / (float)H;
     // room containing the eye: first (lowest index) rectangle that holds it, bounds inclusive
     for (int i = tid; i < n_rooms; i += THREADS) {
@@ -1140,13 +1141,13 @@ __global__ void __launch_bounds__(THREADS, 4) render_kernel(MwbDev d, int mode) 
             atomicMin(cam_room_s, i);
     }
     __syncthreads();
-    ctx.cam_room = *cam_room_s;
+    ctx.cam_room = __builtin_amdgcn_readfirstlane(*cam_room_s);
     if (ctx.cam_room == 0x7fffffff) ctx.cam_room = -1;
     const float zn = 0.04f, zf = 100.0f;   // gluPerspective near / far, miniworld.py:1186-1187
     ctx.zA = (zf + zn) / (zf - zn); ctx.zB = (2.0f * zf * zn) / (zf - zn);
-    ctx.cull_cc = fc[FC_CULL_CC];
-    ctx.cull_oc[0] = fc[FC_CULL_OC]; ctx.cull_oc[1] = fc[FC_CULL_OC + 1]; ctx.cull_oc[2] = fc[FC_CULL_OC + 2];
-    const float cull_cc_px = fc[FC_CULL_CC_PIXEL];   // sphere inflated by a pixel footprint (prep_kernel)
+    ctx.cull_cc = uni(fc[FC_CULL_CC]);
+    ctx.cull_oc[0] = uni(fc[FC_CULL_OC]); ctx.cull_oc[1] = uni(fc[FC_CULL_OC + 1]); ctx.cull_oc[2] = uni(fc[FC_CULL_OC + 2]);
+    const float cull_cc_px = uni(fc[FC_CULL_CC_PIXEL]);   // sphere inflated by a pixel footprint (prep_kernel)
 
     // Pass structure per wave: a 16x4 grid of rays through PIXEL CORNERS classifies 15x3 pixels.
     // If the four corner rays of a pixel reach the same convex piece of a room surface through the
