@@ -1094,11 +1094,13 @@ struct RenderCtx {
 #define TILE_CY 4
 #define QUEUE_CAP 128
 
-template <int THREADS>
-__global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d, int mode) {
+// MODE 0: every env; 1: only the envs regenerated this step (side stream); 2: all the others (bulk).
+// A template parameter so that the three launches carry distinct kernel names in profiles.
+template <int THREADS, int MODE>
+__global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
-    if (mode && (d.reset_set[e] != 0) != (mode == 1)) return;   // block-uniform
+    if (MODE && (d.reset_set[e] != 0) != (MODE == 1)) return;   // block-uniform
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = d.W, H = d.H;
     int n_rooms = d.n_rooms[e];
@@ -1285,7 +1287,11 @@ void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s) {
     hipLaunchKernelGGL(prep_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d, mode);
 }
 void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
-    render_kernel<RENDER_THREADS><<<dim3(d.N), dim3(RENDER_THREADS), mwb_render_lds_bytes(d), s>>>(d, mode);
+    const dim3 g(d.N), b(RENDER_THREADS);
+    const size_t lds = mwb_render_lds_bytes(d);
+    if (mode == 1) render_kernel<RENDER_THREADS, 1><<<g, b, lds, s>>>(d);
+    else if (mode == 2) render_kernel<RENDER_THREADS, 2><<<g, b, lds, s>>>(d);
+    else render_kernel<RENDER_THREADS, 0><<<g, b, lds, s>>>(d);
 }
 void mwb_launch_intersect(const MwbDev &d, int env, double x, double z, double radius, int *result_dev, hipStream_t s) {
     hipLaunchKernelGGL(intersect_kernel, dim3(1), dim3(64), 0, s, d, env, x, z, radius, result_dev);

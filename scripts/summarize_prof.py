@@ -18,7 +18,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(root, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 
-stats = list(csv.DictReader(open(glob.glob(os.path.join(prof, "trace", "*", "*_kernel_stats.csv"))[0])))
+stats = list(csv.DictReader(open(max(glob.glob(os.path.join(prof, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime))))
 ours = [r for r in stats if any(k in r["Name"] for k in ("render_kernel", "reset_kernel", "step_kernel", "prep_kernel", "env_kernel"))]
 with open(os.path.join(out_dir, "%s_%s_kernel_stats.csv" % (tag, workload)), "w") as fh:
     w = csv.DictWriter(fh, fieldnames=list(stats[0].keys()))
@@ -31,7 +31,7 @@ def counters(sub):
     files = glob.glob(os.path.join(prof, sub, "*", "*_counter_collection.csv"))
     if not files:
         return {}
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     # drop each kernel's first dispatch (the all-env reset / cold caches) when there are several
@@ -39,7 +39,14 @@ def counters(sub):
             if "kernel" in k and "at::" not in k}
 
 summary = {"workload": workload, "fetch": counters("pmc_fetch"), "write": counters("pmc_write"), "sq": counters("pmc_sq")}
-rk = next((k for k in summary["fetch"] if "render" in k or "env_kernel" in k), None)
+def pick_render(keys):
+    ks = [k for k in keys if "render_kernel" in k]
+    for want in (", 2>", ", 0>"):   # the bulk launch (mode 2) if the run overlapped reset, else mode 0
+        for k in ks:
+            if want in k:
+                return k
+    return ks[0] if ks else None
+rk = pick_render(summary["fetch"])
 traffic = None
 if rk:
     f_kib = summary["fetch"][rk]["FETCH_SIZE"]
