@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the obs all-gather for N > 1")
+    ap.add_argument("--force-gather", action="store_true", help="run the staging + exchange path even at N = 1 (self-test)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "ring", "direct"],
+                    help="exchange method of the obs all-gather (auto: time both in the warm-up, keep the faster)")
     args = ap.parse_args()
 
     import torch
@@ -120,8 +123,8 @@ def main():
     K, Wm = args.steps, args.warmup
     actions = make_actions(K + Wm, first, count, device)
     gather = None
-    if world > 1 and not args.no_gather:
-        gather = ObsGatherer(tuple(env.obs.shape), env.obs.dtype, device, world)
+    if (world > 1 and not args.no_gather) or args.force_gather:
+        gather = ObsGatherer(tuple(env.obs.shape), env.obs.dtype, device, world, rank=rank, method=args.gather)
     env.reset()
 
     def run(t0, t1):
@@ -165,7 +168,8 @@ def main():
             "config": {"workload": args.workload, "env_id": env_id, "envs_per_gpu": per_gpu, "global_envs": total,
                        "obs": "80x60 RGB" + (" + f32 depth" if depth else ""), "domain_rand": bool(dr),
                        "actions": "uniform random over {turn_left, turn_right, move_forward}, counter-based",
-                       "auto_reset": True, "parallelism": "env-sharded x%d%s" % (world, "" if gather is None else " + RCCL all-gather(obs u8)")},
+                       "auto_reset": True, "parallelism": "env-sharded x%d%s" % (world, "" if gather is None else " + RCCL all-gather(obs u8, %s)" % gather.method),
+                       "gather_tuning_s": None if gather is None else gather.tuned},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
                          "kernel": "render_kernel", "kernel_ms": render_ms,

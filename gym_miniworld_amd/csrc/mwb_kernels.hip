@@ -1187,6 +1187,13 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
             if (cull_cc_px <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc_px)) interior = false;
         }
         const bool edge = is_pixel && !interior;
+        if ((d.debug_flags & 16) && edge) {   // statistics mode: paint the class of every edge pixel
+            const uint32_t ka = key & 7u, kb = k1 & 7u, kc = k2 & 7u, kd = k3 & 7u;
+            const bool same_kind = ka == kb && ka == kc && ka == kd;
+            float acc[3] = {same_kind && ka == KIND_FLOOR ? 8.0f : 0.0f, same_kind && ka == KIND_CEIL ? 8.0f : 0.0f,
+                            same_kind && ka == KIND_WALL ? 8.0f : 0.0f};
+            ctx.write_pixel(px, py, acc, false, 1.0f);
+        }
         const unsigned long long em = __ballot(edge);
         if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)(py * W + px);
         q_count += __popcll(em);
