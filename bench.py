@@ -54,18 +54,41 @@ def make_actions(steps, first_env, n_envs, device):
     return (((v >> 33) & ((1 << 31) - 1)) % 3).to(torch.int32).contiguous()
 
 
-def cpu_baseline(env_id, depth, dr, budget_s=12.0):
-    """Oracle (CPU restatement, 1 thread) timed on this host on a bounded sample of the same workload."""
+def cpu_baseline(env_id, depth, dr, budget_s=10.0):
+    """Oracle (CPU restatement, scalar C) timed on this host on a bounded sample of the same workload:
+    one env per thread on every host core (the reference's own parallelism is one process per env,
+    vec_env/subproc_vec_env.py:36-56), plus the single-thread rate."""
+    import threading
     from oracle import oracle as O
     task, args = ORACLE_TASK[env_id]
-    env = O.OracleEnv(task, seed=1, domain_rand=dr, task_args=args)
-    env.reset(render=False)
-    dt = env.bench_loop(200, ACTION_SEED, 0, want_depth=depth)   # calibrate
-    n = max(200, min(20000, int(200 * budget_s / max(dt, 1e-6))))
-    dt = env.bench_loop(n, ACTION_SEED, 0, want_depth=depth)
-    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d steps of 1 env (%s, seed 1, same counter-based random actions), oracle/mw_oracle.c "
-                      "step+auto-reset+render, 1 thread of %d host cores" % (n, env_id, os.cpu_count() or 0)}
+
+    def make(i):
+        e = O.OracleEnv(task, seed=1 + i, domain_rand=dr, task_args=args)
+        e.reset(render=False)
+        return e
+    env0 = make(0)
+    dt = env0.bench_loop(200, ACTION_SEED, 0, want_depth=depth)   # calibrate
+    n1 = max(200, min(6000, int(200 * 4.0 / max(dt, 1e-6))))
+    dt1 = env0.bench_loop(n1, ACTION_SEED, 0, want_depth=depth)
+    single = n1 / dt1
+    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    envs = [make(i) for i in range(cores)]
+    n = max(100, min(6000, int(single * budget_s)))
+    times = [0.0] * cores
+
+    def run(i):   # ctypes releases the GIL inside the C loop
+        times[i] = envs[i].bench_loop(n, ACTION_SEED, i, want_depth=depth)
+    th = [threading.Thread(target=run, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    return {"value": cores * n / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "single_thread_value": single,
+            "sample": "%d envs x %d steps (%s, seeds 1.., same counter-based random actions), oracle/mw_oracle.c "
+                      "step+auto-reset+render, one env per thread on %d host cores" % (cores, n, env_id, cores)}
 
 
 def load_traffic(workload):

@@ -849,7 +849,6 @@ typedef struct { int kind; /* 0 sky, 1 floor, 2 ceil, 3 wall, 4 box */ int room,
 
 static int build_rrooms(MwoEnv *e, RRoom *rr) {
     int n = e->n_rooms;
-    int side_of_edge[MWO_MAX_ROOMS][4];
     for (int i = 0; i < n; i++) {
         Room *r = &e->rooms[i]; RRoom *o = &rr[i];
         o->min_x = (float)r->min_x; o->max_x = (float)r->max_x; o->min_z = (float)r->min_z; o->max_z = (float)r->max_z;
@@ -862,7 +861,6 @@ static int build_rrooms(MwoEnv *e, RRoom *rr) {
             if (nrm[0] == -1 && nrm[2] == 0) s = 0; else if (nrm[0] == 0 && nrm[2] == 1) s = 1;
             else if (nrm[0] == 1 && nrm[2] == 0) s = 2; else if (nrm[0] == 0 && nrm[2] == -1) s = 3;
             else fail("render: only axis-aligned rectangular rooms are supported");
-            side_of_edge[i][ed] = s;
             int ax = (s == 0 || s == 2) ? 2 : 0; /* coordinate that runs along this side */
             double p0c = r->outline[ed][ax], dirc = r->edge_dirs[ed][ax];
             o->side[s].u_org = (float)p0c; o->side[s].u_sgn = (float)dirc;
@@ -891,7 +889,6 @@ static int build_rrooms(MwoEnv *e, RRoom *rr) {
             if (found < 0) fail("render: portal without a neighbour room");
             rr[i].side[s].nbr = found;
         }
-    (void)side_of_edge;
     return n;
 }
 
@@ -1033,7 +1030,7 @@ static int surf_texcoord(const RRoom *rr, const Hit *h, const float *o, const fl
 }
 
 void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
-    static RRoom rr[MWO_MAX_ROOMS];
+    RRoom *rr = (RRoom *)malloc(sizeof(RRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));   /* per call: thread-safe */
     int n_rooms = build_rrooms(e, rr);
     /* camera: gluPerspective(fov_y, W/H, 0.04, 100), gluLookAt(cam_pos, cam_pos+cam_dir, +Y) */
     double cp[3], cd[3];
@@ -1140,6 +1137,7 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
                 depth[py * W + px] = wz;
             }
         }
+    free(rr);
 }
 
 /* ====================================================================== bench helper */
