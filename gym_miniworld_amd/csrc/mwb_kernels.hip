@@ -1111,6 +1111,8 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     TexLds *tex = (TexLds *)(smem + off); off += sizeof(TexLds) * MWB_MAX_TEX;
     int *cam_room_s = (int *)(smem + off); off += 16;
     uint16_t *queues = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
+    uint32_t *ikeys = (uint32_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint32_t);
+    uint16_t *ipix = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
     uint8_t *fb = d.obs + (size_t)e * W * H * 3;   // straight to HBM; the XCD's L2 merges a frame's byte stores
 
     {   // stage the room table, the frame constants and the texture descriptors
@@ -1157,11 +1159,14 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     // samples lie >= 1/16 pixel inside the corners) and, unless the box may intrude, the pixel is shaded once.
     // All other pixels go to a per-wave queue and are resolved 64 at a time with the full
     // 8-sample path, so that pass runs with dense lanes.
+    if (d.debug_flags & 32) return;   // timing experiments: prologue only
     const int tiles_x = (W + TILE_CX - 2) / (TILE_CX - 1), tiles_y = (H + TILE_CY - 2) / (TILE_CY - 1);
     const int n_tiles = tiles_x * tiles_y;
     const int wave = tid / WAVE, lane = tid % WAVE, n_waves = THREADS / WAVE;
     uint16_t *queue = queues + wave * QUEUE_CAP;
-    int q_count = 0;   // wave-uniform
+    uint32_t *iq_key = ikeys + wave * QUEUE_CAP;
+    uint16_t *iq_pix = ipix + wave * QUEUE_CAP;
+    int q_count = 0, iq_count = 0;   // wave-uniform
     const int ci = lane & (TILE_CX - 1), cj = lane / TILE_CX;
 
     for (int tile = wave; tile < n_tiles; tile += n_waves) {
@@ -1197,12 +1202,28 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
         const unsigned long long em = __ballot(edge);
         if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)(py * W + px);
         q_count += __popcll(em);
-        if (interior && !(d.debug_flags & 4)) ctx.pixel_interior(px, py, key & 0x0FFFFFFFu);
+        // interior pixels are queued too (only 45 of 64 lanes own a pixel in the corner grid) and shaded
+        // 64 at a time
+        const unsigned long long im = __ballot(interior);
+        if (interior) {
+            const int slot = iq_count + __popcll(im & ((1ull << lane) - 1ull));
+            iq_key[slot] = key & 0x0FFFFFFFu; iq_pix[slot] = (uint16_t)(py * W + px);
+        }
+        iq_count += __popcll(im);
+        if (iq_count >= WAVE) {
+            iq_count -= WAVE;
+            const int p = iq_pix[iq_count + lane];
+            if (!(d.debug_flags & 4)) ctx.pixel_interior(p % W, p / W, iq_key[iq_count + lane]);
+        }
         if (q_count >= WAVE) {
             q_count -= WAVE;
             const int p = queue[q_count + lane];
             if (!(d.debug_flags & 2)) ctx.pixel_full(p % W, p / W);
         }
+    }
+    if (lane < iq_count && !(d.debug_flags & 4)) {
+        const int p = iq_pix[lane];
+        ctx.pixel_interior(p % W, p / W, iq_key[lane]);
     }
     if (lane < q_count && !(d.debug_flags & 2)) {
         const int p = queue[lane];
@@ -1276,7 +1297,7 @@ size_t mwb_reset_lds_bytes(const MwbDev &d) {
 }
 size_t mwb_render_lds_bytes(const MwbDev &d) {
     size_t b = (((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15) + MWB_FRAME_WORDS * 4 + sizeof(TexLds) * MWB_MAX_TEX + 16 +
-               (RENDER_THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
+               (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t));
     b += (size_t)(d.debug_flags >> 8) * 1024;   // MWB_DEBUG bits 8+: KiB of LDS padding (occupancy experiments)
     return (b + 15) & ~(size_t)15;
 }

@@ -6,7 +6,7 @@ from gym_miniworld_amd.batch import BatchedMiniWorld
 wl = sys.argv[1] if len(sys.argv) > 1 else "MiniWorld-Maze-v0"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 envs = {}
-for dbg in ("0", str(5<<8), str(18<<8), str(26<<8)):
+for dbg in ("0", "32", "6", "2", "4"):
     os.environ["MWB_DEBUG"] = dbg
     envs[dbg] = BatchedMiniWorld(wl, num_envs=n, seed=1)
     envs[dbg].reset()
