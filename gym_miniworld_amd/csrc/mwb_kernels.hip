@@ -1153,72 +1153,78 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     ctx.cull_oc[0] = uni(fc[FC_CULL_OC]); ctx.cull_oc[1] = uni(fc[FC_CULL_OC + 1]); ctx.cull_oc[2] = uni(fc[FC_CULL_OC + 2]);
     const float cull_cc_px = uni(fc[FC_CULL_CC_PIXEL]);   // sphere inflated by a pixel footprint (prep_kernel)
 
-    // Pass structure per wave: a 16x4 grid of rays through PIXEL CORNERS classifies 15x3 pixels.
-    // If the four corner rays of a pixel reach the same convex piece of a room surface through the
-    // same portal sequence, every ray inside the pixel does (rooms, portals and the pieces are convex,
-    // samples lie >= 1/16 pixel inside the corners) and, unless the box may intrude, the pixel is shaded once.
-    // All other pixels go to a per-wave queue and are resolved 64 at a time with the full
-    // 8-sample path, so that pass runs with dense lanes.
-    if (d.debug_flags & 32) return;   // timing experiments: prologue only
-    const int tiles_x = (W + TILE_CX - 2) / (TILE_CX - 1), tiles_y = (H + TILE_CY - 2) / (TILE_CY - 1);
-    const int n_tiles = tiles_x * tiles_y;
+    // Pass structure per wave: a 16 x 4 grid of rays through PIXEL CORNERS per pass, marching down a
+    // 15-pixel-wide strip; the last corner row of a pass is carried in registers, so a pass classifies
+    // 15 x 4 pixels (1.07 corner rays per pixel).  If the four corner rays of a pixel reach the same
+    // convex piece of a room surface through the same portal sequence, every ray inside the pixel does
+    // (rooms, portals and the pieces are convex, samples lie >= 1/16 pixel inside the corners) and,
+    // unless the box may intrude, the pixel is shaded once ("interior").  All other pixels are resolved
+    // by the full 8-sample path.  Both kinds go through per-wave LDS queues and are processed 64 at a
+    // time, so that the shading and the 8-sample path always run with dense lanes.
     const int wave = tid / WAVE, lane = tid % WAVE, n_waves = THREADS / WAVE;
     uint16_t *queue = queues + wave * QUEUE_CAP;
     uint32_t *iq_key = ikeys + wave * QUEUE_CAP;
     uint16_t *iq_pix = ipix + wave * QUEUE_CAP;
     int q_count = 0, iq_count = 0;   // wave-uniform
     const int ci = lane & (TILE_CX - 1), cj = lane / TILE_CX;
+    const int n_strips = (W + TILE_CX - 2) / (TILE_CX - 1);
+    const int half_h = (H + 1) / 2;                       // pixel rows per half strip
+    const int n_items = n_strips * 2;                     // (strip, upper / lower half)
+    const int n_pass = (half_h + 1 + TILE_CY - 1) / TILE_CY;   // corner rows per half: half_h + 1
 
-    for (int tile = wave; tile < n_tiles; tile += n_waves) {
-        const int x0 = (tile % tiles_x) * (TILE_CX - 1), y0 = (tile / tiles_x) * (TILE_CY - 1);
-        float dv[3], th;
-        uint32_t path;
-        // corner (ci, cj): window x = x0 + ci, window y (up) = H - (y0 + cj)
-        make_ray(cam, (float)(x0 + ci), (float)(H - (y0 + cj)), dv);
-        uint32_t key = trace_rooms<true>(rooms, n_rooms, ctx.cam_room, cam.eye, dv, th, path);
-        const uint32_t kind = key & 7u;
-        bool ok = kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL;
-        ok = ok && !(path & 0x80000000u);
-        const uint32_t k1 = __shfl(key, lane + 1), k2 = __shfl(key, lane + TILE_CX), k3 = __shfl(key, lane + TILE_CX + 1);
-        const uint32_t p1 = __shfl(path, lane + 1), p2 = __shfl(path, lane + TILE_CX), p3 = __shfl(path, lane + TILE_CX + 1);
-        const int px = x0 + ci, py = y0 + cj;
-        const bool is_pixel = ci < TILE_CX - 1 && cj < TILE_CY - 1 && px < W && py < H;
-        bool interior = !(d.debug_flags & 1) && is_pixel && ok && key == k1 && key == k2 && key == k3 && path == p1 && path == p2 && path == p3;
-        if (interior) {   // may the box intrude?  centre ray against the footprint-inflated bounding sphere
-            float dc[3];
-            make_ray(cam, (float)px + 0.5f, (float)(H - 1 - py) + 0.5f, dc);
-            const float b = dc[0] * ctx.cull_oc[0] + dc[1] * ctx.cull_oc[1] + dc[2] * ctx.cull_oc[2];
-            const float dd = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
-            if (cull_cc_px <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc_px)) interior = false;
-        }
-        const bool edge = is_pixel && !interior;
-        if ((d.debug_flags & 16) && edge) {   // statistics mode: paint the class of every edge pixel
-            const uint32_t ka = key & 7u, kb = k1 & 7u, kc = k2 & 7u, kd = k3 & 7u;
-            const bool same_kind = ka == kb && ka == kc && ka == kd;
-            float acc[3] = {same_kind && ka == KIND_FLOOR ? 8.0f : 0.0f, same_kind && ka == KIND_CEIL ? 8.0f : 0.0f,
-                            same_kind && ka == KIND_WALL ? 8.0f : 0.0f};
-            ctx.write_pixel(px, py, acc, false, 1.0f);
-        }
-        const unsigned long long em = __ballot(edge);
-        if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)(py * W + px);
-        q_count += __popcll(em);
-        // interior pixels are queued too (only 45 of 64 lanes own a pixel in the corner grid) and shaded
-        // 64 at a time
-        const unsigned long long im = __ballot(interior);
-        if (interior) {
-            const int slot = iq_count + __popcll(im & ((1ull << lane) - 1ull));
-            iq_key[slot] = key & 0x0FFFFFFFu; iq_pix[slot] = (uint16_t)(py * W + px);
-        }
-        iq_count += __popcll(im);
-        if (iq_count >= WAVE) {
-            iq_count -= WAVE;
-            const int p = iq_pix[iq_count + lane];
-            if (!(d.debug_flags & 4)) ctx.pixel_interior(p % W, p / W, iq_key[iq_count + lane]);
-        }
-        if (q_count >= WAVE) {
-            q_count -= WAVE;
-            const int p = queue[q_count + lane];
-            if (!(d.debug_flags & 2)) ctx.pixel_full(p % W, p / W);
+    for (int item = wave; item < n_items; item += n_waves) {
+        const int x0 = (item >> 1) * (TILE_CX - 1), row0 = (item & 1) * half_h;
+        const int rows = (item & 1) ? H - half_h : half_h;   // pixel rows of this half
+        uint32_t prev_key = 0, prev_path = 0;
+        for (int p = 0; p < n_pass; p++) {
+            const int crow = row0 + p * TILE_CY + cj;        // corner row (0 .. H), window y (up) = H - crow
+            float dv[3], th;
+            uint32_t path;
+            make_ray(cam, (float)(x0 + ci), (float)(H - crow), dv);
+            uint32_t key = trace_rooms<true>(rooms, n_rooms, ctx.cam_room, cam.eye, dv, th, path);
+            const uint32_t kind = key & 7u;
+            bool ok = (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
+            // the pixel whose bottom-left corner this lane traced: corners (crow-1, ci), (crow-1, ci+1),
+            // (crow, ci), (crow, ci+1); row crow-1 comes from the lanes above or from the previous pass
+            const uint32_t k_br = __shfl(key, lane + 1), p_br = __shfl(path, lane + 1);
+            const uint32_t k_up = __shfl(key, lane - TILE_CX), k_upr = __shfl(key, lane - TILE_CX + 1);
+            const uint32_t p_up = __shfl(path, lane - TILE_CX), p_upr = __shfl(path, lane - TILE_CX + 1);
+            const uint32_t k_pv = __shfl(prev_key, lane + 3 * TILE_CX), k_pvr = __shfl(prev_key, lane + 3 * TILE_CX + 1);
+            const uint32_t p_pv = __shfl(prev_path, lane + 3 * TILE_CX), p_pvr = __shfl(prev_path, lane + 3 * TILE_CX + 1);
+            const uint32_t k_tl = cj ? k_up : k_pv, k_tr = cj ? k_upr : k_pvr;
+            const uint32_t p_tl = cj ? p_up : p_pv, p_tr = cj ? p_upr : p_pvr;
+            prev_key = key; prev_path = path;
+            const int px = x0 + ci, py = crow - 1;
+            const bool is_pixel = ci < TILE_CX - 1 && px < W && py >= row0 && py < row0 + rows && !(p == 0 && cj == 0);
+            bool interior = !(d.debug_flags & 1) && is_pixel && ok && key == k_br && key == k_tl && key == k_tr &&
+                            path == p_br && path == p_tl && path == p_tr;
+            if (interior) {   // may the box intrude?  centre ray against the footprint-inflated bounding sphere
+                float dc[3];
+                make_ray(cam, (float)px + 0.5f, (float)(H - 1 - py) + 0.5f, dc);
+                const float b = dc[0] * ctx.cull_oc[0] + dc[1] * ctx.cull_oc[1] + dc[2] * ctx.cull_oc[2];
+                const float dd = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
+                if (cull_cc_px <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc_px)) interior = false;
+            }
+            const bool edge = is_pixel && !interior;
+            const unsigned long long em = __ballot(edge);
+            if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)(py * W + px);
+            q_count += __popcll(em);
+            const unsigned long long im = __ballot(interior);
+            if (interior) {
+                const int slot = iq_count + __popcll(im & ((1ull << lane) - 1ull));
+                iq_key[slot] = key & 0x0FFFFFFFu; iq_pix[slot] = (uint16_t)(py * W + px);
+            }
+            iq_count += __popcll(im);
+            if (iq_count >= WAVE) {
+                iq_count -= WAVE;
+                const int q = iq_pix[iq_count + lane];
+                if (!(d.debug_flags & 4)) ctx.pixel_interior(q % W, q / W, iq_key[iq_count + lane]);
+            }
+            if (q_count >= WAVE) {
+                q_count -= WAVE;
+                const int q = queue[q_count + lane];
+                if (!(d.debug_flags & 2)) ctx.pixel_full(q % W, q / W);
+            }
         }
     }
     if (lane < iq_count && !(d.debug_flags & 4)) {
