@@ -766,13 +766,13 @@ __device__ __forceinline__ void make_ray(const Cam &c, float wx, float wy, float
 
 // Portal traversal of the LDS room table: nearest opaque surface along (eye, d).
 // All LDS reads of a step are issued together (both candidate sides are fetched) and the loop has
-// one exit.  With PATH the sequence of sides crossed is returned as 2 bits per crossing (exact for
-// up to 15 crossings; longer paths are flagged by bit 31 so that they never compare equal).
+// one exit.  With PATH the sequence of sides crossed is returned as 2 bits per crossing under a leading 1
+// (exact for up to 15 crossings; longer paths are flagged by bit 31 and treated as never equal).
 template <bool PATH>
 __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms, int n_rooms, int room, const float *o,
                                                 const float *dv, float &t_hit, uint32_t &path) {
     t_hit = INFINITY;
-    path = 0;
+    path = 1;   // leading sentinel bit: the word encodes the length as well as the sides
     uint32_t key = MAKE_KEY(KIND_SKY, 0, 0);
     if (room < 0) return key;
     const bool xpos = dv[0] > 0, xnz = dv[0] != 0, zpos = dv[2] > 0, znz = dv[2] != 0, ypos = dv[1] > 0, yneg = dv[1] < 0;
