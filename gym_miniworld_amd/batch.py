@@ -193,7 +193,12 @@ class BatchedMiniWorld:
         return self.obs
 
     # ---------------------------------------------------------------------------- introspection
+    def check(self):
+        """Synchronous: raises if world generation ever flagged a failure (see mwb_check)."""
+        _lib.check(self.L.mwb_check(self.h))
+
     def get_state(self, first=0, count=None):
+        self.check()
         count = self.num_envs - first if count is None else count
         shapes = {"agent_pos": (count, 3), "agent_dir": (count,), "box_pos": (count, 3), "box_dir": (count,),
                   "box_color": (count, 3), "cam": (count, 4), "sky_color": (count, 3), "light_pos": (count, 3),

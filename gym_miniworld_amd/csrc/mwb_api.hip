@@ -209,7 +209,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     else if (d.task == MWB_TASK_FOURROOMS) { d.R_max = 8; d.S_max = 32; }
     else {
         int rows = (int)d.task_args[0], cols = (int)d.task_args[1];
-        if (rows < 1 || cols < 1 || rows * cols > 160) { delete h; return set_err(MWB_EINVAL, "Maze: 1 <= rows*cols <= 160"); }
+        if (rows < 1 || cols < 1 || rows * cols > 4096) { delete h; return set_err(MWB_EINVAL, "Maze: bad num_rows / num_cols"); }
         d.R_max = 2 * rows * cols - 1; d.S_max = 4 * rows * cols;
         if (d.S_max < 8) d.S_max = 8;
     }
@@ -225,6 +225,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     A(d.reward, N); A(d.reward64, N); A(d.done, N); A(d.ep_steps, N);
     A(h->tex_desc_dev, (size_t)MWB_MAX_TEX);
     A(h->scratch_int_dev, (size_t)4);
+    A(d.error_flag, (size_t)1);
 #undef A
     if (rc != MWB_OK) { mwb_destroy(h); return rc; }
     d.tex_desc = h->tex_desc_dev;
@@ -241,9 +242,10 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
         return set_err(MWB_EHIP, "mwb_create: could not create the side stream / events");
     }
     for (int i = 0; i < MWB_MAX_TEX; i++) { h->tex_w[i] = 0; h->tex_h[i] = 0; }
-    if (mwb_reset_lds_bytes(d) > 64 * 1024 || mwb_render_lds_bytes(d) > 64 * 1024) {
+    if (int prc = mwb_prepare_kernels(d)) {
         mwb_destroy(h);
-        return set_err(MWB_EINVAL, "mwb_create: world too large for the LDS staging buffers");
+        return set_err(prc == -1 ? MWB_EINVAL : MWB_EHIP, prc == -1 ? "mwb_create: world too large for the 160 KB LDS staging buffers"
+                                                                   : "mwb_create: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     }
     *out = h;
     return MWB_OK;
@@ -456,6 +458,16 @@ extern "C" int mwb_get_outputs(mwb_handle *h, mwb_outputs *out) {
     out->obs_bytes = (size_t)d.N * d.W * d.H * 3;
     out->depth_bytes = d.want_depth ? (size_t)d.N * d.W * d.H * 4 : 0;
     out->stack = h->stack; out->stack_bytes = h->stack_bytes;
+    return MWB_OK;
+}
+
+extern "C" int mwb_check(mwb_handle *h) {
+    if (!h) return set_err(MWB_EINVAL, "mwb_check: null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    int32_t flag = 0;
+    HIP_TRY(hipMemcpy(&flag, h->dev.error_flag, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag) return set_err(MWB_ESTATE, "world generation failed for env " + std::to_string(flag - 1) + " (portal / placement condition the reference asserts on)");
     return MWB_OK;
 }
 

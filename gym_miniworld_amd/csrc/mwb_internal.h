@@ -82,6 +82,7 @@ struct MwbDev {
     double *cam;            // [N][4] height, fwd_disp, pitch, fov_y
     double *sky_color, *light_pos, *light_color, *light_ambient;   // [N][3]
     int32_t *step_count, *n_rooms, *n_segs;
+    int32_t *error_flag;    // [1] set by reset_kernel when world generation hits a condition the reference asserts on
     uint8_t *need_reset;    // set by step / mark_reset, consumed and cleared by reset_kernel
     uint8_t *reset_set;     // the same flags, kept until the next step: which envs were (re)generated this pass
     uint32_t *rng;          // [N][625]
@@ -107,5 +108,6 @@ void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s);
 void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s);
 void mwb_launch_stack(const MwbDev &d, void *stack, int nstack, int dtype, int after_reset, hipStream_t s);
 void mwb_launch_intersect(const MwbDev &d, int env, double x, double z, double radius, int *result_dev, hipStream_t s);
+int mwb_prepare_kernels(const MwbDev &d);   // 0 ok, -1 world too large for LDS, -2 HIP error
 size_t mwb_reset_lds_bytes(const MwbDev &d);
 size_t mwb_render_lds_bytes(const MwbDev &d);

@@ -609,6 +609,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         for (int k = 0; k < 4; k++) d.cam[e * 4 + k] = cam[k];
         d.step_count[e] = 0;
         d.n_rooms[e] = w.fail ? -1 : w.n_rooms;
+        if (w.fail) atomicExch(d.error_flag, e + 1);
         d.n_segs[e] = w.n_segs;
         d.need_reset[e] = 0;
     }
@@ -1314,6 +1315,20 @@ void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *ski
 void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s) {
     hipLaunchKernelGGL(mark_reset_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d, mask);
 }
+int mwb_prepare_kernels(const MwbDev &d) {
+    // opt in to more than the default 64 KB of dynamic LDS where a large world needs it (160 KB per CU)
+    size_t r = mwb_reset_lds_bytes(d), q = mwb_render_lds_bytes(d);
+    if (r > 160 * 1024 || q > 160 * 1024) return -1;
+    if (r > 64 * 1024 && hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r) != hipSuccess) return -2;
+    if (q > 64 * 1024) {
+        if (hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess ||
+            hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess ||
+            hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess)
+            return -2;
+    }
+    return 0;
+}
+
 void mwb_launch_reset(const MwbDev &d, hipStream_t s) {
     hipLaunchKernelGGL(reset_kernel, dim3(d.N), dim3(WAVE), mwb_reset_lds_bytes(d), s, d);
 }

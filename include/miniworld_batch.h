@@ -133,6 +133,12 @@ int mwb_get_outputs(mwb_handle *h, mwb_outputs *out);
 int mwb_stack_enable(mwb_handle *h, int nstack, int dtype);
 int mwb_stack_update(mwb_handle *h, int after_reset, void *stream);
 
+/* World generation cannot fail for the four tasks with sane arguments; if it ever does (a portal outside
+ * its wall, more than one portal on an edge, a placement that finds no free spot in 100000 draws - the
+ * reference would assert or spin) the kernel flags it. Synchronous: returns MWB_ESTATE if any env of the
+ * handle hit such a condition since creation. */
+int mwb_check(mwb_handle *h);
+
 /* ---- introspection (tests, Gym single-env view) ------------------------------------------- */
 int mwb_get_state(mwb_handle *h, int first_env, int count, mwb_state *out);          /* synchronous */
 /* overwrite pose / step counter of env range (NULL = leave); used to inject oracle states */

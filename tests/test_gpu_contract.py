@@ -33,7 +33,7 @@ def test_abi_refuses_misuse_loudly():
     h = ctypes.c_void_p()
     cfg = _lib.MwbConfig()
     cfg.abi_version, cfg.task, cfg.num_envs, cfg.obs_width, cfg.obs_height, cfg.use_default_params = 1, 3, 4, 80, 60, 1
-    cfg.task_args[0], cfg.task_args[1] = 30, 30                      # 900 cells: beyond the LDS staging limit
+    cfg.task_args[0], cfg.task_args[1] = 30, 30                      # 900 cells: beyond the 160 KB LDS staging limit
     assert L.mwb_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
 
 

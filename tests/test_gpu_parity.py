@@ -274,6 +274,7 @@ def test_fast_path_equals_full_sample_path(env_id, n, steps, dr, monkeypatch):
     ("MiniWorld-MazeS2-v0", {}, "Maze", [2, 2, 3], 0),                # envs/maze.py:115-117
     ("MiniWorld-Hallway-v0", {"task_args": [6]}, "Hallway", [6], 0),  # Hallway(length=6), hallway.py:13
     ("MiniWorld-Maze-v0", {"task_args": [2, 4, 2.5], "max_episode_steps": 200}, "Maze", [2, 4, 2.5], 200),
+    ("MiniWorld-Maze-v0", {"task_args": [10, 11, 3]}, "Maze", [10, 11, 3], 0),   # 219 rooms: > 64 KB of LDS in reset
 ])
 def test_constructor_variants_match_oracle(oracle_mod, env_id, kwargs, task, args, mes):
     """Constructor parameters of the task classes and custom DomainParams tables reach the kernels:
