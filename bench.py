@@ -54,6 +54,28 @@ def make_actions(steps, first_env, n_envs, device):
     return (((v >> 33) & ((1 << 31) - 1)) % 3).to(torch.int32).contiguous()
 
 
+def host_cores(cap=64):
+    """CPU cores this process may actually use: the affinity mask, clipped by the cgroup CPU quota
+    (a GPU box hands each job a share of the host, e.g. 16 of 256 cores) and by `cap`."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                        n = min(n, max(1, int(q / int(fh.read()) + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(env_id, depth, dr, budget_s=10.0):
     """Oracle (CPU restatement, scalar C) timed on this host on a bounded sample of the same workload:
     one env per thread on every host core (the reference's own parallelism is one process per env,
@@ -71,7 +93,7 @@ def cpu_baseline(env_id, depth, dr, budget_s=10.0):
     n1 = max(200, min(6000, int(200 * 4.0 / max(dt, 1e-6))))
     dt1 = env0.bench_loop(n1, ACTION_SEED, 0, want_depth=depth)
     single = n1 / dt1
-    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    cores = host_cores()
     envs = [make(i) for i in range(cores)]
     n = max(100, min(6000, int(single * budget_s)))
     times = [0.0] * cores
