@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmwbatch.so")
 
 NPARAM = 13
-ROOM_WORDS = 40
+ROOM_WORDS = 24
 ABI_VERSION = 1
 
 TASK_IDS = {"Hallway": 0, "OneRoom": 1, "FourRooms": 2, "Maze": 3}

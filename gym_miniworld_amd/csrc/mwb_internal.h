@@ -3,7 +3,7 @@
 // HBM layout (one handle = one GPU's shard of N environments), structure-of-arrays:
 //   sim  : per-env f64 pose / episode parameters (arrays of N), i32 counters, u8 flags
 //   rng  : per-env MT19937 state, N x 625 u32 (624 key words + position), env-major
-//   rooms: per-env room table, N x R_max x MWB_ROOM_WORDS f32 words (render kernel stages it in LDS)
+//   rooms: per-env room table, N x R_max x MWB_ROOM_WORDS (24) f32 words (render kernel stages it in LDS)
 //   segs : collision segments, S_max x 4 x N f64 (a.x a.z b.x b.z; segment-major, env-minor so that
 //          one-env-per-lane reads coalesce), reference order per env
 //   frame: per-env render constants (camera basis, lit colours, box frame), N x FRAME_WORDS f32
@@ -20,21 +20,28 @@
 #define MWB_MAX_LEVELS 12
 #define MWB_FRAME_WORDS 80
 
-// room table word offsets (f32 words; ints stored as bit patterns)
+// room table: 24 f32 words (96 B) per room; ints stored as bit patterns
+//   0-3  min_x max_x min_z max_z
+//   4    wall height          5  textures wall | floor << 8 | ceil << 16, bits 24-27: wall-u runs backwards on side s
+//   6    neighbour room behind the portal of side 0 | side 1 << 16 (0xFFFF = no portal)     7  sides 2 | 3 << 16
+//   8+4s lo hi max_y u_org of side s (0:+x east, 1:-z north, 2:-x west, 3:+z south): portal extent along the
+//        side's axis and in y (min_y is 0 in every supported task - enforced by reset_kernel), origin of
+//        the wall texture's u coordinate
 #define RW_MINX 0
 #define RW_MAXX 1
 #define RW_MINZ 2
 #define RW_MAXZ 3
 #define RW_HEIGHT 4
-#define RW_TEX 5     // wall | floor << 8 | ceil << 16
-#define RW_SIDE0 8   // 8 words per side: lo hi min_y max_y | nbr u_org u_sgn pad
+#define RW_TEX 5
+#define RW_NBR01 6
+#define RW_NBR23 7
+#define RW_SIDE0 8
+#define RW_SIDE_WORDS 4
 #define RS_LO 0
 #define RS_HI 1
-#define RS_MINY 2
-#define RS_MAXY 3
-#define RS_NBR 4
-#define RS_UORG 5
-#define RS_USGN 6
+#define RS_MAXY 2
+#define RS_UORG 3
+#define RW_NO_NBR 0xFFFFu
 
 // frame-constant word offsets
 #define FC_EYE 0

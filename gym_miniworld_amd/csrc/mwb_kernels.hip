@@ -620,12 +620,11 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         float *o = grooms + (size_t)ri * MWB_ROOM_WORDS;
         o[RW_MINX] = (float)r.min_x; o[RW_MAXX] = (float)r.max_x; o[RW_MINZ] = (float)r.min_z; o[RW_MAXZ] = (float)r.max_z;
         o[RW_HEIGHT] = (float)r.height;
-        o[RW_TEX] = __int_as_float(r.tex_id[0] | (r.tex_id[1] << 8) | (r.tex_id[2] << 16));
-        o[6] = 0; o[7] = 0;
+        uint32_t texw = (uint32_t)(r.tex_id[0] | (r.tex_id[1] << 8) | (r.tex_id[2] << 16));
+        uint32_t nbrs[4] = {RW_NO_NBR, RW_NO_NBR, RW_NO_NBR, RW_NO_NBR};
         for (int s = 0; s < 4; s++) {
-            float *sd = o + RW_SIDE0 + 8 * s;
-            sd[RS_LO] = 0; sd[RS_HI] = 0; sd[RS_MINY] = 0; sd[RS_MAXY] = 0; sd[RS_NBR] = __int_as_float(-1);
-            sd[RS_UORG] = 0; sd[RS_USGN] = 0; sd[7] = 0;
+            float *sd = o + RW_SIDE0 + RW_SIDE_WORDS * s;
+            sd[RS_LO] = 0; sd[RS_HI] = 0; sd[RS_MAXY] = 0; sd[RS_UORG] = 0;
         }
         for (int ed = 0; ed < 4; ed++) {
             double dx, dz, len;
@@ -634,15 +633,19 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             int s = (nx == -1 && nz == 0) ? 0 : (nx == 0 && nz == 1) ? 1 : (nx == 1 && nz == 0) ? 2 : 3;
             bool along_z = (s == 0 || s == 2);
             double p0c = along_z ? r.oz[ed] : r.ox[ed], dirc = along_z ? dz : dx;
-            float *sd = o + RW_SIDE0 + 8 * s;
-            sd[RS_UORG] = (float)p0c; sd[RS_USGN] = (float)dirc;
+            float *sd = o + RW_SIDE0 + RW_SIDE_WORDS * s;
+            sd[RS_UORG] = (float)p0c;
+            if (dirc < 0) texw |= 1u << (24 + s);
             if (r.n_port[ed]) {
                 double c0 = p0c + dirc * r.p_start[ed], c1 = p0c + dirc * r.p_end[ed];
                 sd[RS_LO] = (float)(c0 < c1 ? c0 : c1); sd[RS_HI] = (float)(c0 < c1 ? c1 : c0);
-                sd[RS_MINY] = 0.0f; sd[RS_MAXY] = (float)r.p_maxy[ed];
-                sd[RS_NBR] = __int_as_float(r.nbr[ed]);
+                sd[RS_MAXY] = (float)r.p_maxy[ed];
+                nbrs[s] = (uint32_t)r.nbr[ed] & 0xFFFFu;
             }
         }
+        o[RW_TEX] = __int_as_float((int)texw);
+        o[RW_NBR01] = __int_as_float((int)(nbrs[0] | (nbrs[1] << 16)));
+        o[RW_NBR23] = __int_as_float((int)(nbrs[2] | (nbrs[3] << 16)));
     }
 }
 
@@ -790,9 +793,11 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
         const float *r = rooms + room * MWB_ROOM_WORDS;
         const float4 rect = *(const float4 *)(r + RW_MINX);   // min_x max_x min_z max_z
         const float height = r[RW_HEIGHT];
-        const float *sdx = r + RW_SIDE0 + 8 * sx, *sdz = r + RW_SIDE0 + 8 * sz;
-        const float4 portx = *(const float4 *)(sdx), portz = *(const float4 *)(sdz);   // lo hi min_y max_y
-        const int nbrx = __float_as_int(sdx[RS_NBR]), nbrz = __float_as_int(sdz[RS_NBR]);
+        const float4 portx = *(const float4 *)(r + RW_SIDE0 + RW_SIDE_WORDS * sx);   // lo hi max_y u_org
+        const float4 portz = *(const float4 *)(r + RW_SIDE0 + RW_SIDE_WORDS * sz);
+        const uint32_t n01 = (uint32_t)__float_as_int(r[RW_NBR01]), n23 = (uint32_t)__float_as_int(r[RW_NBR23]);
+        const uint32_t nbrx = xpos ? (n01 & 0xFFFFu) : (n23 & 0xFFFFu);   // sides 0 / 2
+        const uint32_t nbrz = zpos ? (n23 >> 16) : (n01 >> 16);             // sides 3 / 1
         const float tx = xnz ? ((xpos ? rect.y : rect.x) - o[0]) * ix : INFINITY;
         const float tz = znz ? ((zpos ? rect.w : rect.z) - o[2]) * iz : INFINITY;
         const bool usex = tx <= tz;
@@ -803,10 +808,10 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
         const bool hit_ceil = tc <= ts;
         const bool escaped = !(ts < INFINITY);
         const float4 port = usex ? portx : portz;
-        const int nbr = usex ? nbrx : nbrz;
+        const uint32_t nbr = usex ? nbrx : nbrz;
         const float hc = usex ? fmaf(ts, dv[2], o[2]) : fmaf(ts, dv[0], o[0]);
         const float y = fmaf(ts, dv[1], o[1]);
-        const bool pass = nbr >= 0 && port.x < hc && hc < port.y && port.z < y && y < port.w;
+        const bool pass = nbr != RW_NO_NBR && port.x < hc && hc < port.y && 0.0f < y && y < port.z;   // portal min_y = 0
         if (hit_floor || hit_ceil || escaped || !pass) {
             // same precedence as the sequential tests of the spec: floor, ceiling, escape, wall
             if (hit_floor) { t_hit = tfloor; key = MAKE_KEY(KIND_FLOOR, 0, room); }
@@ -815,12 +820,12 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
                 t_hit = ts; key = MAKE_KEY(KIND_WALL, s, room);
                 // a wall with a portal is not convex: tag the convex piece (left / right / above / below the
                 // opening) so that the corner-ray classification never spans the opening
-                if (PATH && nbr >= 0) key |= (hc <= port.x ? 1u : hc >= port.y ? 2u : y >= port.w ? 3u : 0u) << 28;
+                if (PATH && nbr != RW_NO_NBR) key |= (hc <= port.x ? 1u : hc >= port.y ? 2u : y >= port.z ? 3u : 0u) << 28;
             }
             break;
         }
         if (PATH) { path = (path << 2) | (uint32_t)s; steps++; }
-        room = nbr;
+        room = (int)nbr;
     }
     if (PATH && steps > 15) path = 0x80000000u | (uint32_t)steps;
     return key;
@@ -950,7 +955,7 @@ struct RenderCtx {
         const TexLds &T = tex[tex_id];
         const float *lit = kind == KIND_FLOOR ? fc + FC_LIT_FLOOR : kind == KIND_CEIL ? fc + FC_LIT_CEIL : fc + FC_LIT_WALL + 3 * side;
         const bool wall = kind == KIND_WALL;
-        const float *sd = r + RW_SIDE0 + 8 * side;
+        const float *sd = r + RW_SIDE0 + RW_SIDE_WORDS * side;
         // plane of the surface: axis (0 x, 1 y, 2 z) and coordinate, selected without control flow
         const float4 rect = *(const float4 *)(r + RW_MINX);   // min_x max_x min_z max_z
         const float height = r[RW_HEIGHT];
@@ -959,7 +964,8 @@ struct RenderCtx {
         const int axis = is_x ? 0 : (is_z ? 2 : 1);
         const float plane = wall ? wall_plane : (kind == KIND_CEIL ? height : 0.0f);
         // s = (a - u_org) * u_sgn * sc_s for walls, a * sc_s for floor / ceiling
-        const float u_org = wall ? sd[RS_UORG] : 0.0f, u_scale = (wall ? sd[RS_USGN] : 1.0f) * T.sc_s;
+        const float u_org = wall ? sd[RS_UORG] : 0.0f;
+        const float u_scale = (wall && ((texw >> (24 + side)) & 1u)) ? -T.sc_s : T.sc_s;
         // centre ray and the rays through the +1 pixel neighbours, recomputed here rather than kept live
         // across the sample loop (registers are what limits occupancy)
         float dc[3], dx[3], dy[3];
@@ -1020,7 +1026,7 @@ struct RenderCtx {
         // distinct surfaces among the 8 coverage samples, in order of first appearance:
         // up to 4 slots (key, count, first sample); a 5th distinct surface is shaded on the spot
         uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0, firsts = 0;
+        uint32_t meta = 0;   // four 4-bit sample counts (bits 0-15) and four 3-bit first-sample indices (bits 16-27)
         uint32_t key_s0 = 0;
         float t_s0 = INFINITY;
         float acc[3] = {0, 0, 0};
@@ -1039,13 +1045,14 @@ struct RenderCtx {
                 if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, 0); th = tb; }
             }
             if (k == 0) { key_s0 = key; t_s0 = th; }
-            const bool h0 = c0 > 0 && key == k0, h1 = c1 > 0 && key == k1, h2 = c2 > 0 && key == k2, h3 = c3 > 0 && key == k3;
-            c0 += h0; c1 += h1; c2 += h2; c3 += h3;
+            const bool h0 = (meta & 0xFu) && key == k0, h1 = (meta & 0xF0u) && key == k1;
+            const bool h2 = (meta & 0xF00u) && key == k2, h3 = (meta & 0xF000u) && key == k3;
+            meta += (h0 ? 1u : 0u) + (h1 ? 0x10u : 0u) + (h2 ? 0x100u : 0u) + (h3 ? 0x1000u : 0u);
             if (!(h0 || h1 || h2 || h3)) {
-                if (c0 == 0) { k0 = key; c0 = 1; firsts |= k; }
-                else if (c1 == 0) { k1 = key; c1 = 1; firsts |= k << 3; }
-                else if (c2 == 0) { k2 = key; c2 = 1; firsts |= k << 6; }
-                else if (c3 == 0) { k3 = key; c3 = 1; firsts |= k << 9; }
+                if (!(meta & 0xFu)) { k0 = key; meta |= 1u | ((uint32_t)k << 16); }
+                else if (!(meta & 0xF0u)) { k1 = key; meta |= 0x10u | ((uint32_t)k << 19); }
+                else if (!(meta & 0xF00u)) { k2 = key; meta |= 0x100u | ((uint32_t)k << 22); }
+                else if (!(meta & 0xF000u)) { k3 = key; meta |= 0x1000u | ((uint32_t)k << 25); }
                 else {
                     float col[3];
                     shade(key, k, cx, cy, col);
@@ -1054,13 +1061,14 @@ struct RenderCtx {
             }
         }
 #pragma unroll 1
-        for (int it = 0; it < 4 && c0 > 0; it++) {
+        for (int it = 0; it < 4 && (meta & 0xFu); it++) {
             float col[3];
-            shade(k0, firsts & 7, cx, cy, col);
-            const float cnt = (float)c0;
+            shade(k0, (meta >> 16) & 7u, cx, cy, col);
+            const float cnt = (float)(meta & 0xFu);
 #pragma unroll
             for (int q = 0; q < 3; q++) acc[q] += cnt * col[q];
-            k0 = k1; c0 = c1; k1 = k2; c1 = c2; k2 = k3; c2 = c3; c3 = 0; firsts >>= 3;
+            k0 = k1; k1 = k2; k2 = k3;
+            meta = ((meta & 0xFFFFu) >> 4) | ((meta >> 19) << 16);
         }
         write_pixel(px, py, acc, (key_s0 & 7u) != KIND_SKY, t_s0);
     }
@@ -1114,7 +1122,7 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     uint16_t *queues = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
     uint32_t *ikeys = (uint32_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint32_t);
     uint16_t *ipix = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
-    uint8_t *fb = d.obs + (size_t)e * W * H * 3;   // straight to HBM; the XCD's L2 merges a frame's byte stores
+    uint8_t *fb = smem + off;   // the frame is assembled in LDS and leaves as 16-byte coalesced stores
 
     {   // stage the room table, the frame constants and the texture descriptors
         const float4 *src = (const float4 *)(d.rooms + (size_t)e * d.R_max * MWB_ROOM_WORDS);
@@ -1233,8 +1241,20 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
         ctx.pixel_interior(p % W, p / W, iq_key[lane]);
     }
     if (lane < q_count && !(d.debug_flags & 2)) {
-        const int p = queue[lane];
-        ctx.pixel_full(p % W, p / W);
+        const int q = queue[lane];
+        ctx.pixel_full(q % W, q / W);
+    }
+    __syncthreads();
+    {   // framebuffer LDS -> HBM, 16 bytes per lane
+        const int nbytes = W * H * 3;
+        uint8_t *dst = d.obs + (size_t)e * nbytes;
+        if ((nbytes & 15) == 0) {
+            const uint4 *s4 = (const uint4 *)fb;
+            uint4 *d4 = (uint4 *)dst;
+            for (int i = tid; i < nbytes / 16; i += THREADS) d4[i] = s4[i];
+        } else {
+            for (int i = tid; i < nbytes; i += THREADS) dst[i] = fb[i];
+        }
     }
 }
 
@@ -1304,7 +1324,7 @@ size_t mwb_reset_lds_bytes(const MwbDev &d) {
 }
 size_t mwb_render_lds_bytes(const MwbDev &d) {
     size_t b = (((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15) + MWB_FRAME_WORDS * 4 + sizeof(TexLds) * MWB_MAX_TEX + 16 +
-               (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t));
+               (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)d.W * d.H * 3;
     b += (size_t)(d.debug_flags >> 8) * 1024;   // MWB_DEBUG bits 8+: KiB of LDS padding (occupancy experiments)
     return (b + 15) & ~(size_t)15;
 }

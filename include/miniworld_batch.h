@@ -148,7 +148,7 @@ int mwb_set_agent(mwb_handle *h, int first_env, int count, const double *pos_xz,
  * 0 none, 1 wall, 2 box. Synchronous. */
 int mwb_intersect(mwb_handle *h, int env, double x, double z, double radius, int *result);
 /* geometry of one env as the kernels see it: n_rooms x MWB_ROOM_WORDS f32 words and n_segs x 4 f64 */
-#define MWB_ROOM_WORDS 40
+#define MWB_ROOM_WORDS 24
 int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_rooms, double *segs, int max_segs,
                      int *n_rooms, int *n_segs);
 
