@@ -930,7 +930,7 @@ struct RenderCtx {
     uint8_t *fb;
     float *depth;   // this env's depth map or null
     Cam cam;
-    int n_rooms, cam_room, W, H, layout, dbg;
+    int n_rooms, cam_room, W, H, layout;
     float cull_cc, cull_oc[3], zA, zB;
 
     // rays through the +1 pixel neighbours (for the LOD differences): the ray is affine in the window
@@ -1139,7 +1139,7 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     RenderCtx ctx;
     ctx.rooms = rooms; ctx.fc = fc; ctx.tex = tex; ctx.texels = d.texels; ctx.fb = fb;
     ctx.depth = d.want_depth ? d.depth + (size_t)e * W * H : nullptr;
-    ctx.n_rooms = n_rooms; ctx.W = W; ctx.H = H; ctx.layout = d.layout; ctx.dbg = d.debug_flags;
+    ctx.n_rooms = n_rooms; ctx.W = W; ctx.H = H; ctx.layout = d.layout;
     Cam &cam = ctx.cam;
     // frame constants are workgroup-uniform: pin them to scalar registers
     auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };

@@ -1,4 +1,6 @@
-"""A/B timing of render-kernel phases via MWB_DEBUG (read at mwb_create)."""
+"""A/B timing of the render kernel's phases in one process via MWB_DEBUG (read at mwb_create):
+1 = every pixel through the 8-sample path, 2 = skip the 8-sample path, 4 = skip interior shading,
+6 = corner passes + prologue only; bits 8+ = KiB of LDS padding (occupancy experiments)."""
 import sys, os, time
 sys.path.insert(0, '.')
 import torch
@@ -6,7 +8,7 @@ from gym_miniworld_amd.batch import BatchedMiniWorld
 wl = sys.argv[1] if len(sys.argv) > 1 else "MiniWorld-Maze-v0"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 envs = {}
-for dbg in ("0", "32", "6", "2", "4"):
+for dbg in ("0", "1", "2", "4", "6"):
     os.environ["MWB_DEBUG"] = dbg
     envs[dbg] = BatchedMiniWorld(wl, num_envs=n, seed=1)
     envs[dbg].reset()
@@ -19,4 +21,3 @@ for rnd in range(3):
         for a in acts: b.step(a)
         t = b.timing_read()
         print(rnd, "dbg", dbg, {k: round(v, 4) for k, v in t.items() if k != 'n'})
-# edge fraction: count pixels that differ between dbg=2 (edges skipped -> stale fb) is messy; instead use obs zeros
