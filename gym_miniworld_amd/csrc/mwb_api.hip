@@ -218,7 +218,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
 #define A(ptr, n) if (rc == MWB_OK) rc = dev_alloc(h, &(ptr), (n))
     A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N); A(d.box_z, N); A(d.box_dir, N);
     A(d.box_color, N * 3); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
-    A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.need_reset, N); A(d.reset_set, N);
+    A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.reset_set, N); A(d.reset_list, N); A(d.reset_count, (size_t)1);
     A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * MWB_ROOM_WORDS); A(d.segs, N * d.S_max * 4); A(d.frame, N * MWB_FRAME_WORDS);
     A(d.obs, N * d.W * d.H * 3);
     if (d.want_depth) { A(d.depth, N * d.W * d.H); }
@@ -235,7 +235,9 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     { const char *no = getenv("MWB_NO_OVERLAP"); h->overlap_reset = !(no && atoi(no)); }
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
     h->stack = nullptr; h->stack_n = 0; h->stack_dtype = 0; h->stack_bytes = 0;
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // numerically lowest = highest priority
+    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
         mwb_destroy(h);
@@ -402,10 +404,12 @@ extern "C" int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream) {
     mwb_launch_mark_reset(h->dev, mask_dev, s);
     rc = check_launch("mark_reset_kernel"); if (rc) return rc;
     TMARK(1); TMARK(5);
-    mwb_launch_reset(h->dev, s);
+    mwb_launch_reset(h->dev, 4096, s);   // possibly every env: many blocks
     rc = check_launch("reset_kernel"); if (rc) return rc;
     TMARK(6); TMARK(2);
-    return render_tail(h, 0, s);
+    rc = render_tail(h, 0, s); if (rc) return rc;
+    mwb_launch_clear_list(h->dev, s);
+    return check_launch("clear_list_kernel");
 }
 
 extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask_dev, void *stream) {
@@ -418,23 +422,26 @@ extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t
     TMARK(1);
     if (!h->overlap_reset) {
         TMARK(5);
-        mwb_launch_reset(h->dev, s);
+        mwb_launch_reset(h->dev, 128, s);
         rc = check_launch("reset_kernel"); if (rc) return rc;
         TMARK(6); TMARK(2);
-        return render_tail(h, 0, s);
+        rc = render_tail(h, 0, s); if (rc) return rc;
+        mwb_launch_clear_list(h->dev, s);
+        return check_launch("clear_list_kernel");
     }
     // fork: the few envs that ended are regenerated, prepared and rendered on the side stream while the
     // caller's stream renders everybody else; join before returning control of the outputs
     HIP_TRY(hipEventRecord(h->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->side));
-    mwb_launch_reset(h->dev, h->side);
+    mwb_launch_reset(h->dev, 128, h->side);   // a handful of envs end per step: few blocks, started ahead of the bulk render
     rc = check_launch("reset_kernel"); if (rc) return rc;
     if (h->timing) HIP_TRY(hipEventRecord(h->ev[6], h->side));
     mwb_launch_prep(h->dev, 1, h->side);
     rc = check_launch("prep_kernel"); if (rc) return rc;
     mwb_launch_render(h->dev, 1, h->side);
     rc = check_launch("render_kernel"); if (rc) return rc;
+    mwb_launch_clear_list(h->dev, h->side);   // the list is consumed; off the critical path
     HIP_TRY(hipEventRecord(h->ev_join, h->side));
     TMARK(2);
     rc = render_tail(h, 2, s); if (rc) return rc;

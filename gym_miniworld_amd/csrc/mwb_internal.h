@@ -90,8 +90,9 @@ struct MwbDev {
     double *sky_color, *light_pos, *light_color, *light_ambient;   // [N][3]
     int32_t *step_count, *n_rooms, *n_segs;
     int32_t *error_flag;    // [1] set by reset_kernel when world generation hits a condition the reference asserts on
-    uint8_t *need_reset;    // set by step / mark_reset, consumed and cleared by reset_kernel
-    uint8_t *reset_set;     // the same flags, kept until the next step: which envs were (re)generated this pass
+    uint8_t *reset_set;     // which envs are (re)generated in the current pass (set by step / mark_reset)
+    int32_t *reset_list;    // [N] the same envs as a compact list (order arbitrary) ...
+    int32_t *reset_count;   // [1] ... and its length; zeroed by clear_list_kernel at the end of every pass
     uint32_t *rng;          // [N][625]
     float *rooms;           // [N][R_max][MWB_ROOM_WORDS]
     double *segs;           // [S_max][4][N]
@@ -108,8 +109,9 @@ struct MwbDev {
 
 // launch wrappers implemented in mwb_kernels.hip
 void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *skip_mask, hipStream_t s);
+void mwb_launch_clear_list(const MwbDev &d, hipStream_t s);
 void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s);
-void mwb_launch_reset(const MwbDev &d, hipStream_t s);
+void mwb_launch_reset(const MwbDev &d, int max_blocks, hipStream_t s);   // grid-strides over reset_list
 // mode 0: every env; 1: only envs with reset_set; 2: only envs without (lets reset overlap the bulk render)
 void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s);
 void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s);

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(64) step_kernel(MwbDev d, const int32_t *__res
     if (e >= d.N) return;
     if (skip && skip[e]) {   // the fork's 'dummy' command, vec_env/subproc_vec_env.py:26-31
         d.reward[e] = -99.0f; d.reward64[e] = -99.0; d.done[e] = 0; d.ep_steps[e] = d.step_count[e];
-        d.need_reset[e] = 0; d.reset_set[e] = 0;
+        d.reset_set[e] = 0;
         return;
     }
     int sc = d.step_count[e] + 1;   // miniworld.py:663
@@ -193,15 +193,17 @@ __global__ void __launch_bounds__(64) step_kernel(MwbDev d, const int32_t *__res
         }
     }
     d.reward64[e] = r; d.reward[e] = (float)r; d.done[e] = (uint8_t)done; d.ep_steps[e] = sc;
-    d.need_reset[e] = (uint8_t)(done && d.auto_reset);   // worker auto-reset, vec_env/subproc_vec_env.py:10-13
-    d.reset_set[e] = (uint8_t)(done && d.auto_reset);
+    const bool regen = done && d.auto_reset;   // worker auto-reset, vec_env/subproc_vec_env.py:10-13
+    d.reset_set[e] = (uint8_t)regen;
+    if (regen) d.reset_list[atomicAdd(d.reset_count, 1)] = e;
 }
 
 __global__ void mark_reset_kernel(MwbDev d, const uint8_t *__restrict__ mask) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= d.N) return;
-    d.need_reset[e] = mask ? (mask[e] ? 1 : 0) : 1;
-    d.reset_set[e] = d.need_reset[e];
+    const bool regen = mask ? (mask[e] != 0) : true;
+    d.reset_set[e] = (uint8_t)regen;
+    if (regen) d.reset_list[atomicAdd(d.reset_count, 1)] = e;
 }
 
 // ================================================================================= reset kernel
@@ -479,9 +481,11 @@ __device__ __forceinline__ void sample_param(MtWave &g, const MwbParam &p, int n
 }
 
 __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
-    int e = blockIdx.x;
-    if (!d.need_reset[e]) return;
-    int lane = threadIdx.x;
+    const int count = d.reset_count[0];
+    const int lane = threadIdx.x;
+    for (int li = blockIdx.x; li < count; li += gridDim.x) {
+    const int e = d.reset_list[li];
+    __syncthreads();   // LDS is reused from the previous env of this block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WRoom *rooms = (WRoom *)smem;
     size_t off = (size_t)d.R_max * sizeof(WRoom);
@@ -611,7 +615,6 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         d.n_rooms[e] = w.fail ? -1 : w.n_rooms;
         if (w.fail) atomicExch(d.error_flag, e + 1);
         d.n_segs[e] = w.n_segs;
-        d.need_reset[e] = 0;
     }
     for (int i = lane; i < w.n_segs * 4; i += WAVE) d.segs[(size_t)i * d.N + e] = segs[i];   // transposed, see step_kernel
     float *grooms = d.rooms + (size_t)e * d.R_max * MWB_ROOM_WORDS;
@@ -647,6 +650,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         o[RW_NBR01] = __int_as_float((int)(nbrs[0] | (nbrs[1] << 16)));
         o[RW_NBR23] = __int_as_float((int)(nbrs[2] | (nbrs[3] << 16)));
     }
+    }   // env loop
 }
 
 // ================================================================================== prep kernel
@@ -675,10 +679,7 @@ __device__ __forceinline__ void lit_color(const float *L, const float *amb, cons
     }
 }
 
-__global__ void __launch_bounds__(256) prep_kernel(MwbDev d, int mode) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= d.N) return;
-    if (mode && (d.reset_set[e] != 0) != (mode == 1)) return;
+__device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     float *fc = d.frame + (size_t)e * MWB_FRAME_WORDS;
     double adir = d.agent_dir[e];
     double cam_h = d.cam[e * 4 + 0], cam_fd = d.cam[e * 4 + 1], cam_pitch = d.cam[e * 4 + 2], fov = d.cam[e * 4 + 3];
@@ -743,6 +744,18 @@ __global__ void __launch_bounds__(256) prep_kernel(MwbDev d, int mode) {
     float rho = 1.5f * 2.0f * sqrtf(tw * tw + thh * thh);
     float Rp = R + rho * (sqrtf(oc2) + R);
     fc[FC_CULL_CC_PIXEL] = oc2 - Rp * Rp;
+}
+
+__global__ void __launch_bounds__(256) prep_kernel(MwbDev d, int mode) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode == 1) {   // the regenerated envs, through the compact list
+        const int count = d.reset_count[0];
+        for (int li = e; li < count; li += gridDim.x * blockDim.x) prep_env(d, d.reset_list[li]);
+        return;
+    }
+    if (e >= d.N) return;
+    if (mode == 2 && d.reset_set[e]) return;
+    prep_env(d, e);
 }
 
 // ================================================================================ render kernel
@@ -1107,9 +1120,12 @@ struct RenderCtx {
 // A template parameter so that the three launches carry distinct kernel names in profiles.
 template <int THREADS, int MODE>
 __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
-    const int e = blockIdx.x;
     const int tid = threadIdx.x;
-    if (MODE && (d.reset_set[e] != 0) != (MODE == 1)) return;   // block-uniform
+    const int list_count = MODE == 1 ? d.reset_count[0] : 1;
+    for (int li = (MODE == 1 ? (int)blockIdx.x : 0); li < list_count; li += (MODE == 1 ? (int)gridDim.x : 1)) {   // MODE 1: the compact list
+    const int e = MODE == 1 ? d.reset_list[li] : (int)blockIdx.x;
+    if (MODE == 2 && d.reset_set[e]) return;   // block-uniform
+    if (MODE == 1) __syncthreads();   // LDS is reused from the previous env of this block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = d.W, H = d.H;
     int n_rooms = d.n_rooms[e];
@@ -1256,6 +1272,7 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
             for (int i = tid; i < nbytes; i += THREADS) dst[i] = fb[i];
         }
     }
+    }   // env loop (MODE 1)
 }
 
 // ================================================================================== frame stack
@@ -1332,6 +1349,8 @@ size_t mwb_render_lds_bytes(const MwbDev &d) {
 void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *skip, hipStream_t s) {
     hipLaunchKernelGGL(step_kernel, dim3((d.N + 63) / 64), dim3(64), 0, s, d, actions, skip);
 }
+__global__ void clear_list_kernel(MwbDev d) { d.reset_count[0] = 0; }
+void mwb_launch_clear_list(const MwbDev &d, hipStream_t s) { hipLaunchKernelGGL(clear_list_kernel, dim3(1), dim3(1), 0, s, d); }
 void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s) {
     hipLaunchKernelGGL(mark_reset_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d, mask);
 }
@@ -1349,16 +1368,18 @@ int mwb_prepare_kernels(const MwbDev &d) {
     return 0;
 }
 
-void mwb_launch_reset(const MwbDev &d, hipStream_t s) {
-    hipLaunchKernelGGL(reset_kernel, dim3(d.N), dim3(WAVE), mwb_reset_lds_bytes(d), s, d);
+#define LIST_GRID 128   // blocks that walk the compact list of regenerated envs (a handful per step)
+void mwb_launch_reset(const MwbDev &d, int max_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(reset_kernel, dim3(d.N < max_blocks ? d.N : max_blocks), dim3(WAVE), mwb_reset_lds_bytes(d), s, d);
 }
 void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s) {
-    hipLaunchKernelGGL(prep_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d, mode);
+    const int blocks = mode == 1 ? 8 : (d.N + 255) / 256;
+    hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, s, d, mode);
 }
 void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
     const dim3 g(d.N), b(RENDER_THREADS);
     const size_t lds = mwb_render_lds_bytes(d);
-    if (mode == 1) render_kernel<RENDER_THREADS, 1><<<g, b, lds, s>>>(d);
+    if (mode == 1) render_kernel<RENDER_THREADS, 1><<<dim3(d.N < LIST_GRID ? d.N : LIST_GRID), b, lds, s>>>(d);
     else if (mode == 2) render_kernel<RENDER_THREADS, 2><<<g, b, lds, s>>>(d);
     else render_kernel<RENDER_THREADS, 0><<<g, b, lds, s>>>(d);
 }
