@@ -1112,21 +1112,14 @@ struct RenderCtx {
     }
 };
 
-#define TILE_CX 16   // corner grid of one wave pass: 16 x 4 corners -> 15 x 3 pixels
+#define TILE_CX 16   // corner grid of one wave pass: 16 x 4 corners; marching down a strip it classifies 15 x 4 pixels
 #define TILE_CY 4
 #define QUEUE_CAP 128
 
-// MODE 0: every env; 1: only the envs regenerated this step (side stream); 2: all the others (bulk).
-// A template parameter so that the three launches carry distinct kernel names in profiles.
-template <int THREADS, int MODE>
-__global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
+// Renders one env with the whole workgroup (called once per workgroup, or per list entry on the side stream).
+template <int THREADS>
+__device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigned char *smem) {
     const int tid = threadIdx.x;
-    const int list_count = MODE == 1 ? d.reset_count[0] : 1;
-    for (int li = (MODE == 1 ? (int)blockIdx.x : 0); li < list_count; li += (MODE == 1 ? (int)gridDim.x : 1)) {   // MODE 1: the compact list
-    const int e = MODE == 1 ? d.reset_list[li] : (int)blockIdx.x;
-    if (MODE == 2 && d.reset_set[e]) return;   // block-uniform
-    if (MODE == 1) __syncthreads();   // LDS is reused from the previous env of this block
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = d.W, H = d.H;
     int n_rooms = d.n_rooms[e];
     if (n_rooms < 0) n_rooms = 0;
@@ -1272,7 +1265,25 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
             for (int i = tid; i < nbytes; i += THREADS) dst[i] = fb[i];
         }
     }
-    }   // env loop (MODE 1)
+}
+
+// MODE 0: every env; 1: only the envs regenerated this step (side stream, through the compact list);
+// 2: all the others (bulk).  A template parameter so that the three launches carry distinct kernel names
+// in profiles.
+template <int THREADS, int MODE>
+__global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (MODE == 1) {
+        const int count = d.reset_count[0];
+        for (int li = blockIdx.x; li < count; li += gridDim.x) {
+            render_env<THREADS>(d, d.reset_list[li], smem);
+            __syncthreads();   // LDS is reused by the next env of this block
+        }
+    } else {
+        const int e = blockIdx.x;
+        if (MODE == 2 && d.reset_set[e]) return;   // block-uniform
+        render_env<THREADS>(d, e, smem);
+    }
 }
 
 // ================================================================================== frame stack
