@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the obs all-gather for N > 1")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo (+ --no-gather) only to rehearse the multi-rank flow on one GPU")
     ap.add_argument("--force-gather", action="store_true", help="run the staging + exchange path even at N = 1 (self-test)")
     ap.add_argument("--gather", default="auto", choices=["auto", "ring", "direct"],
                     help="exchange method of the obs all-gather (auto: time both in the warm-up, keep the faster)")
@@ -157,13 +159,18 @@ def main():
         per_gpu = args.envs_per_gpu
     total = per_gpu * world
     first, count = shard_range(total, rank, world)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count())   # one rank per GPU; wraps only in gloo rehearsals
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+            args.no_gather = True
 
-    env = BatchedMiniWorld(env_id, num_envs=count, seed=1, domain_rand=dr, want_depth=depth, device=local_rank,
+    env = BatchedMiniWorld(env_id, num_envs=count, seed=1, domain_rand=dr, want_depth=depth, device=dev_index,
                            first_env_index=first)
     K, Wm = args.steps, args.warmup
     actions = make_actions(K + Wm, first, count, device)
@@ -198,7 +205,7 @@ def main():
     kt = env.timing_read()
     env.timing_enable(False)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -305,3 +305,20 @@ def test_constructor_variants_match_oracle(oracle_mod, env_id, kwargs, task, arg
                 e.reset(render=False)
     assert_state_equal(b.get_state(), oracle_states(envs), exact_pose=False, tag=env_id + " end")
     b.close()
+
+
+def test_shard_offset_reproduces_the_global_batch():
+    """Multi-GPU sharding contract: a handle created with first_env_index = k owns envs k.. of the global
+    batch (seed base + global index), so its results equal the corresponding slice of one big handle."""
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    big = BatchedMiniWorld("MiniWorld-FourRooms-v0", num_envs=48, seed=5, domain_rand=True)
+    shard = BatchedMiniWorld("MiniWorld-FourRooms-v0", num_envs=16, seed=5, domain_rand=True, first_env_index=32)
+    assert torch.equal(big.reset()[32:], shard.reset())
+    g = torch.Generator().manual_seed(9)
+    for _ in range(50):
+        a = torch.randint(0, 3, (48,), generator=g, dtype=torch.int32)
+        big.step(a); shard.step(a[32:])
+        assert torch.equal(big.obs[32:], shard.obs) and torch.equal(big.reward64[32:], shard.reward64)
+        assert torch.equal(big.done[32:], shard.done)
+    big.close(); shard.close()
