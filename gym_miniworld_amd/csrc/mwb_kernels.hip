@@ -904,6 +904,9 @@ __device__ __forceinline__ void sample_texture(const uint32_t *__restrict__ texe
         if (rho2 < INFINITY) lambda = rho2 <= 1.0f ? 0.0f : 0.5f * __log2f(rho2);
     }
     float ws = s - floorf(s), wt = t - floorf(t);   // GL_REPEAT
+    // non-finite coordinates (a plane seen exactly edge-on) must not become texel addresses
+    if (!(ws >= 0.0f && ws < 1.0f)) ws = 0.0f;
+    if (!(wt >= 0.0f && wt < 1.0f)) wt = 0.0f;
     float fl = floorf(lambda);
     int l0 = (int)fl; if (l0 > maxl) l0 = maxl;
     int l1 = l0 + 1 > maxl ? maxl : l0 + 1;

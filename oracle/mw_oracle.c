@@ -975,6 +975,8 @@ static void sample_texture(int tex_id, float s, float t, float sx, float tx, flo
         else lambda = 0.5f * log2f(rho2);
     }
     float ws = s - floorf(s), wt = t - floorf(t); /* REPEAT */
+    if (!(ws >= 0.0f && ws < 1.0f)) ws = 0.0f; /* non-finite coordinates must not become texel addresses */
+    if (!(wt >= 0.0f && wt < 1.0f)) wt = 0.0f;
     int maxl = T->n_levels - 1;
     if (lambda <= 0.0f) { bilinear(T, 0, ws, wt, rgb); return; }
     float fl = floorf(lambda);
