@@ -47,7 +47,7 @@ class MwbState(ctypes.Structure):
 EXPORTS = [
     "mwb_create", "mwb_destroy", "mwb_last_error", "mwb_abi_version", "mwb_set_texture", "mwb_seed", "mwb_reset",
     "mwb_step", "mwb_render", "mwb_get_outputs", "mwb_get_state", "mwb_set_agent", "mwb_intersect",
-    "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read", "mwb_stack_enable", "mwb_stack_update", "mwb_check",
+    "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read", "mwb_stack_enable", "mwb_stack_update", "mwb_check", "mwb_seed_key",
 ]
 
 _lib = None
@@ -86,6 +86,7 @@ def load():
     L.mwb_timing_enable.argtypes = [vp, i32]
     L.mwb_stack_enable.argtypes = [vp, i32, i32]
     L.mwb_check.argtypes = [vp]
+    L.mwb_seed_key.argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
     L.mwb_stack_update.argtypes = [vp, i32, vp]
     L.mwb_timing_read.argtypes = [vp] + [ctypes.POINTER(ctypes.c_double)] * 4 + [ctypes.POINTER(i32)]
     if L.mwb_abi_version() != ABI_VERSION:

@@ -122,6 +122,8 @@ static int seed_to_key(uint64_t seed, uint32_t key[2]) {
     return hi != 0 ? 2 : 1;   // _int_list_from_bigint drops the high limb when it is zero ([0] for 0)
 }
 
+extern "C" int mwb_seed_key(uint64_t seed, uint32_t key[2]) { return seed_to_key(seed, key); }
+
 // numpy RandomState.seed(list) == MT19937 init_by_array
 static void mt_init_by_array(uint32_t *mt, const uint32_t *init_key, int key_length) {
     mt[0] = 19650218u;

@@ -111,6 +111,9 @@ int mwb_set_texture(mwb_handle *h, int tex_id, int width, int height, const uint
 /* replaces: env.seed(seed + rank) per worker (envs.py:35-36, miniworld.py:528-530, random.py:9-10).
  * seeds: host array [num_envs]. Synchronous (host-side key hashing + upload). */
 int mwb_seed(mwb_handle *h, const uint64_t *seeds);
+/* the seed -> MT19937 init_by_array key of gym<=0.21's seeding.np_random (hash_seed: first 8 bytes of
+ * sha512(str(seed)) as little-endian 32-bit limbs), host-only helper; returns the key length (1 or 2) */
+int mwb_seed_key(uint64_t seed, uint32_t key[2]);
 /* replaces: VecEnv.reset (vec_env/subproc_vec_env.py:77-80 -> MiniWorldEnv.reset miniworld.py:532-592)
  * mask: device u8[num_envs] or NULL; NULL or mask[i]!=0 resets env i. Renders the first observation. */
 int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream);

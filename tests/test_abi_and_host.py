@@ -119,3 +119,18 @@ def test_shard_range_partitions_exactly():
 def test_oracle_is_marked_as_test_infrastructure():
     for f in ("mw_oracle.h", "mw_oracle.c", "oracle.py"):
         assert "TEST INFRASTRUCTURE ONLY" in open(os.path.join(ROOT, "oracle", f)).read()
+
+
+def test_native_seed_hash_matches_hashlib_and_fixture(built, oracle_mod):
+    """The library's own SHA-512 based seed -> MT19937 key (mwb_api.hip) against hashlib (oracle side) and
+    the committed seed_keys.json, without a GPU."""
+    import json
+    L = built.load()
+    keys = json.load(open(os.path.join(ROOT, "tests", "golden", "seed_keys.json")))
+    seeds = [int(s) for s in keys] + [5, 99, 123456789, 2 ** 64 - 1, 18446744073709551557]
+    for s in seeds:
+        k = (ctypes.c_uint32 * 2)()
+        n = L.mwb_seed_key(ctypes.c_uint64(s), k)
+        assert list(k)[:n] == oracle_mod.seed_to_mt_key(s), s
+        if str(s) in keys:
+            assert list(k)[:n] == keys[str(s)]
