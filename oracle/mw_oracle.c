@@ -192,9 +192,14 @@ struct MwoEnv {
     int n_segs;
     double (*wall_segs)[2][3];
     double room_probs[MWO_MAX_ROOMS], room_cdf[MWO_MAX_ROOMS];
-    Ent box, agent;
-    int n_ents; /* placement order: box(0), agent(1) */
-    double box_size[3], box_color[3];
+    Ent box, box2, agent;
+    int n_boxes; /* 1, or 2 for the two-box T-maze (red = box, blue = box2) */
+    int n_ents; /* placement order: box(0), [box2(1)], agent(last) */
+    double box_size[3], box_color[3], box2_color[3];
+    /* T-maze family (envs/tmaze.py): goal alternation state */
+    long long episode_count, task_step_count;
+    int goal_idx;
+    double feature[2];
     double cam_height, cam_fwd_disp, cam_pitch, cam_fov_y;
     double sky_color[3], light_pos[3], light_color[3], light_ambient[3];
     double max_forward_step;
@@ -256,13 +261,16 @@ static void sample_param(MwoEnv *e, int use_rng, int name, double *out) {
 MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int domain_rand, const double *params) {
     MwoEnv *e = (MwoEnv *)calloc(1, sizeof(MwoEnv));
     e->task = task;
-    static const double dflt[4][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}};
+    static const double dflt[6][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}};
+    if (task < 0 || task > MWO_TMAZE_TWOBOX) fail("unknown task");
     for (int i = 0; i < 4; i++) e->task_args[i] = task_args ? task_args[i] : dflt[task][i];
+    e->n_boxes = task == MWO_TMAZE_TWOBOX ? 2 : 1;
     if (max_episode_steps <= 0) {
         /* hallway.py:18, oneroom.py:14, fourrooms.py:15, maze.py:27 */
         if (task == MWO_HALLWAY) max_episode_steps = 250;
         else if (task == MWO_ONEROOM) max_episode_steps = 180;
         else if (task == MWO_FOURROOMS) max_episode_steps = 250;
+        else if (task == MWO_TMAZE || task == MWO_TMAZE_TWOBOX) max_episode_steps = 280; /* tmaze.py:20,142 */
         else max_episode_steps = (int)e->task_args[0] * (int)e->task_args[1] * 24;
     }
     e->max_episode_steps = max_episode_steps;
@@ -277,6 +285,9 @@ MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int
             }
     uint32_t k0 = 0;
     mt_init_by_array(&e->rng, &k0, 1);
+    /* MiniWorldEnv.__init__ ends with self.reset() (miniworld.py:523): the episode counters of the T-maze
+     * family have seen one reset when the caller gets the env */
+    if ((task == MWO_TMAZE && e->task_args[3] > 0) || (task == MWO_TMAZE_TWOBOX && e->task_args[0] == 0)) e->episode_count = 1;
     return e;
 }
 
@@ -520,8 +531,12 @@ int mwo_intersect_circle_segs(const double *point, double radius, const double *
 static int intersect(MwoEnv *e, const Ent *self, const double *pos, double radius) {
     double p[3] = {pos[0], 0, pos[2]};
     if (mwo_intersect_circle_segs(p, radius, &e->wall_segs[0][0][0], e->n_segs)) return 1;
-    const Ent *ents[2] = {&e->box, &e->agent};
-    for (int k = 0; k < e->n_ents; k++) {
+    const Ent *ents[3];
+    int ne = 0;
+    ents[ne++] = &e->box;
+    if (e->n_boxes == 2) ents[ne++] = &e->box2;
+    ents[ne++] = &e->agent;
+    for (int k = 0; k < e->n_ents && k < ne; k++) {
         const Ent *o = ents[k];
         if (o == self) continue;
         double d3[3] = {o->pos[0] - p[0], 0 - p[1], o->pos[2] - p[2]};
@@ -533,7 +548,7 @@ static int intersect(MwoEnv *e, const Ent *self, const double *pos, double radiu
 
 int mwo_intersect(MwoEnv *e, int ent, double x, double z, double radius) {
     double p[3] = {x, 0, z};
-    return intersect(e, ent == 0 ? &e->box : &e->agent, p, radius);
+    return intersect(e, ent == 0 ? &e->box : ent == 2 ? &e->box2 : &e->agent, p, radius);
 }
 
 /* Room.point_inside, miniworld.py:220-232 */
@@ -549,11 +564,11 @@ static int point_inside(const Room *r, const double *p) {
 
 #define NOVAL (-1e300)
 /* place_entity, miniworld.py:845-907 (pos=None path) */
-static void place_entity(MwoEnv *e, Ent *ent, int has_dir, double dir, double min_x, double max_x, double min_z, double max_z) {
+static void place_entity_in(MwoEnv *e, Ent *ent, int room, int has_dir, double dir, double min_x, double max_x, double min_z, double max_z) {
     if (e->n_rooms <= 0) fail("create rooms before calling place_entity");
     if (!e->static_done) gen_static_data(e);
     for (;;) {
-        Room *r = &e->rooms[rs_choice_cdf(&e->rng, e->room_cdf, e->n_rooms)];
+        Room *r = room >= 0 ? &e->rooms[room] : &e->rooms[rs_choice_cdf(&e->rng, e->room_cdf, e->n_rooms)];
         double lx = min_x == NOVAL ? r->min_x : min_x, hx = max_x == NOVAL ? r->max_x : max_x;
         double lz = min_z == NOVAL ? r->min_z : min_z, hz = max_z == NOVAL ? r->max_z : max_z;
         double pos[3];
@@ -570,12 +585,17 @@ static void place_entity(MwoEnv *e, Ent *ent, int has_dir, double dir, double mi
     e->n_ents++;
 }
 
+static void place_entity(MwoEnv *e, Ent *ent, int has_dir, double dir, double min_x, double max_x, double min_z, double max_z) {
+    place_entity_in(e, ent, -1, has_dir, dir, min_x, max_x, min_z, max_z);
+}
+
 static void new_box(MwoEnv *e) {
     /* entity.py:362-379 Box(color='red', size=0.8) */
     double sx = 0.8, sy = 0.8, sz = 0.8;
     e->box_size[0] = sx; e->box_size[1] = sy; e->box_size[2] = sz;
     e->box.radius = sqrt(sx * sx + sz * sz) / 2;
     e->box.height = sy;
+    e->box2.radius = e->box.radius; e->box2.height = sy;
 }
 
 /* envs/maze.py:34-104 */
@@ -657,12 +677,46 @@ static void gen_world(MwoEnv *e) {
         break;
     }
     case MWO_MAZE: gen_maze(e); break;
+    case MWO_TMAZE:          /* envs/tmaze.py:27-61 (TMaze, TMazeLeft/Right, TMazeDynamic) */
+    case MWO_TMAZE_TWOBOX: { /* envs/tmaze.py:151-194 and the *Features* copies */
+        add_rect_room(e, -1, 8, -2, 2, TEXF_CONCRETE);
+        Room *room2 = add_rect_room(e, 8, 12, -8, 8, TEXF_CONCRETE);
+        double r2min = room2->min_z, r2max = room2->max_z;
+        connect_rooms(e, 0, 1, 2, -2, 2, 0, 0);
+        new_box(e);
+        if (e->task == MWO_TMAZE_TWOBOX) {
+            place_entity(e, &e->box, 0, 0, 10, 10, -6, -6);
+            place_entity(e, &e->box2, 0, 0, 10, 10, 6, 6);
+        } else if (e->task_args[0] != 0) { /* goal_pos given */
+            double gx = e->task_args[1], gz = e->task_args[2];
+            if (e->task_args[3] > 0) { gx = 10; gz = e->goal_idx ? 6 : -6; } /* TMazeDynamic.goals, tmaze.py:88 */
+            place_entity(e, &e->box, 0, 0, gx, gx, gz, gz);
+        } else if (rs_randint(&e->rng, 0, 2) == 0) /* RandGen.bool, random.py:26-31 */
+            place_entity_in(e, &e->box, 1, 0, 0, NOVAL, NOVAL, NOVAL, r2min + 2);
+        else
+            place_entity_in(e, &e->box, 1, 0, 0, NOVAL, NOVAL, r2max - 2, NOVAL);
+        double dir = rs_uniform(&e->rng, -M_PI / 4, M_PI / 4);
+        place_entity_in(e, &e->agent, 0, 1, dir, NOVAL, NOVAL, NOVAL, NOVAL);
+        break;
+    }
     default: fail("unknown task");
     }
 }
 
 /* MiniWorldEnv.reset, miniworld.py:532-592 */
 void mwo_reset(MwoEnv *e) {
+    /* reset() overrides of the T-maze family run before MiniWorldEnv.reset */
+    if (e->task == MWO_TMAZE && e->task_args[3] > 0) { /* TMazeDynamic.reset, tmaze.py:98-105 */
+        e->episode_count += 1;
+        if (e->episode_count % (long long)e->task_args[3] == 0) e->goal_idx = (e->goal_idx + 1) % 2;
+    } else if (e->task == MWO_TMAZE_TWOBOX) {
+        if (e->task_args[0] == 0) { /* TMazeTwoBoxDynamic.reset, tmaze.py:210-217 */
+            e->episode_count += 1;
+            if (e->episode_count % (long long)e->task_args[3] == 0) e->goal_idx = (e->goal_idx + 1) % 2;
+        } else if ((double)e->task_step_count > e->task_args[3]) /* *Features*.reset, tmaze.py:322-330: the counter */
+            e->goal_idx = (e->goal_idx + 1) % 2;                   /* is never cleared (the reference assigns a misspelt name) */
+    }
+    e->feature[0] = e->feature[1] = 0;
     e->step_count = 0;
     free_rooms(e);
     e->n_ents = 0;
@@ -680,6 +734,11 @@ void mwo_reset(MwoEnv *e) {
     sample_param(e, dr, MWO_P_OBJ_COLOR_BIAS, bias);
     const double red[3] = {1.0, 0.0, 0.0};
     for (int k = 0; k < 3; k++) { double v = red[k] + bias[k]; e->box_color[k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
+    if (e->n_boxes == 2) { /* entities are randomized in list order: red box, blue box, agent */
+        const double blue[3] = {0.0, 0.0, 1.0};
+        sample_param(e, dr, MWO_P_OBJ_COLOR_BIAS, bias);
+        for (int k = 0; k < 3; k++) { double v = blue[k] + bias[k]; e->box2_color[k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
+    }
     /* Agent.randomize, entity.py:486-492 */
     sample_param(e, dr, MWO_P_CAM_HEIGHT, &e->cam_height);
     sample_param(e, dr, MWO_P_CAM_FWD_DISP, &e->cam_fwd_disp);
@@ -689,11 +748,12 @@ void mwo_reset(MwoEnv *e) {
 }
 
 /* MiniWorldEnv.near, miniworld.py:961-971 */
-static int near_box(MwoEnv *e) {
-    double d[3] = {e->box.pos[0] - e->agent.pos[0], e->box.pos[1] - e->agent.pos[1], e->box.pos[2] - e->agent.pos[2]};
+static int near_ent(MwoEnv *e, const Ent *b) {
+    double d[3] = {b->pos[0] - e->agent.pos[0], b->pos[1] - e->agent.pos[1], b->pos[2] - e->agent.pos[2]};
     double dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    return dist < e->box.radius + e->agent.radius + 1.1 * e->max_forward_step;
+    return dist < b->radius + e->agent.radius + 1.1 * e->max_forward_step;
 }
+static int near_box(MwoEnv *e) { return near_ent(e, &e->box); }
 
 /* MiniWorldEnv.step miniworld.py:658-716 + task rule (e.g. envs/maze.py:106-113) */
 void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
@@ -717,7 +777,17 @@ void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
     }
     double r = 0; int d = 0;
     if (e->step_count >= e->max_episode_steps) { d = 1; r = 0; }
-    if (near_box(e)) { r += 1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps); d = 1; }
+    if (e->task == MWO_TMAZE_TWOBOX) { /* tmaze.py:196-208 / 299-320: goal box, then penalty box */
+        const Ent *boxes[2] = {&e->box, &e->box2};
+        if (near_ent(e, boxes[e->goal_idx])) { r += 1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps); d = 1; }
+        if (near_ent(e, boxes[1 - e->goal_idx])) { r += -1 * (1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps)); d = 1; }
+        e->feature[0] = e->feature[1] = 0;
+        if (e->task_args[0] != 0) { /* feature = [near(blue), near(red)], tmaze.py:311-318 */
+            e->feature[0] = near_ent(e, &e->box2) ? 1 : 0;
+            e->feature[1] = near_ent(e, &e->box) ? 1 : 0;
+            e->task_step_count += 1;
+        }
+    } else if (near_box(e)) { r += 1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps); d = 1; }
     *reward = r; *done = d;
 }
 
@@ -764,6 +834,13 @@ void mwo_get_state(MwoEnv *e, MwoState *s) {
     s->rng_pos = e->rng.pos; s->rng_key0 = e->rng.key[0]; s->rng_key1 = e->rng.key[1]; s->rng_key623 = e->rng.key[623];
     uint64_t sum = 0; for (int i = 0; i < 624; i++) sum += e->rng.key[i];
     s->rng_keysum = (uint32_t)(sum & 0xFFFFFFFFu);
+    s->n_boxes = e->n_boxes; s->goal_idx = e->goal_idx;
+    memcpy(s->box2_pos, e->box2.pos, 24); s->box2_dir = e->box2.dir; memcpy(s->box2_color, e->box2_color, 24);
+    s->episode_count = e->episode_count; s->task_step_count = e->task_step_count;
+    s->feature[0] = e->feature[0]; s->feature[1] = e->feature[1];
+}
+void mwo_set_counters(MwoEnv *e, long long episode_count, long long task_step_count, int goal_idx) {
+    e->episode_count = episode_count; e->task_step_count = task_step_count; e->goal_idx = goal_idx;
 }
 
 void mwo_set_agent(MwoEnv *e, double x, double z, double dir) { e->agent.pos[0] = x; e->agent.pos[1] = 0; e->agent.pos[2] = z; e->agent.dir = dir; }
@@ -1056,21 +1133,28 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
         L.sky[k] = (float)e->sky_color[k]; L.box_color[k] = (float)e->box_color[k];
     }
     const float white[3] = {1, 1, 1};
-    float lit_floor[3], lit_ceil[3], lit_wall[4][3], lit_box[6][3];
+    float lit_floor[3], lit_ceil[3], lit_wall[4][3];
     { float n[3] = {0, 1, 0}; lit_color(&L, n, white, lit_floor); }
     { float n[3] = {0, -1, 0}; lit_color(&L, n, white, lit_ceil); }
     { static const float wn[4][3] = {{-1, 0, 0}, {0, 0, 1}, {1, 0, 0}, {0, 0, -1}};
       for (int k = 0; k < 4; k++) lit_color(&L, wn[k], white, lit_wall[k]); }
-    RBox bx;
-    for (int k = 0; k < 3; k++) bx.pos[k] = (float)e->box.pos[k];
-    bx.c = (float)cos(e->box.dir); bx.s = (float)sin(e->box.dir);
-    bx.half[0] = (float)(e->box_size[0] / 2); bx.half[2] = (float)(e->box_size[2] / 2); bx.half[1] = 0; bx.sy = (float)e->box_size[1];
-    { /* world normal of local normal n: R_y(dir) n = (nx c + nz s, ny, -nx s + nz c) */
-      static const float ln[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
-      for (int k = 0; k < 6; k++) {
-          float n[3] = {ln[k][0] * bx.c + ln[k][2] * bx.s, ln[k][1], -ln[k][0] * bx.s + ln[k][2] * bx.c};
-          lit_color(&L, n, L.box_color, lit_box[k]);
-      } }
+    RBox bxs[2];
+    float lit_boxes[2][6][3];
+    for (int b = 0; b < e->n_boxes; b++) {
+        const Ent *be = b ? &e->box2 : &e->box;
+        RBox bx;
+        float bcol[3];
+        for (int k = 0; k < 3; k++) { bx.pos[k] = (float)be->pos[k]; bcol[k] = b ? (float)e->box2_color[k] : L.box_color[k]; }
+        bx.c = (float)cos(be->dir); bx.s = (float)sin(be->dir);
+        bx.half[0] = (float)(e->box_size[0] / 2); bx.half[2] = (float)(e->box_size[2] / 2); bx.half[1] = 0; bx.sy = (float)e->box_size[1];
+        /* world normal of local normal n: R_y(dir) n = (nx c + nz s, ny, -nx s + nz c) */
+        static const float ln[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+        for (int k = 0; k < 6; k++) {
+            float n[3] = {ln[k][0] * bx.c + ln[k][2] * bx.s, ln[k][1], -ln[k][0] * bx.s + ln[k][2] * bx.c};
+            lit_color(&L, n, bcol, lit_boxes[b][k]);
+        }
+        bxs[b] = bx;
+    }
     /* room containing the eye */
     int cam_room = -1;
     for (int i = 0; i < n_rooms && cam_room < 0; i++)
@@ -1085,8 +1169,10 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
                 float d[3];
                 make_ray(&c, cx + SAMPLE_X[k] * 0.0625f, cy + SAMPLE_Y[k] * 0.0625f, d);
                 hits[k] = trace_rooms(rr, n_rooms, cam_room, c.eye, d);
-                float tb; int fc = trace_box(&bx, c.eye, d, &tb);
-                if (fc >= 0 && tb < hits[k].t) { hits[k].kind = 4; hits[k].t = tb; hits[k].room = -1; hits[k].side = fc; }
+                for (int b = 0; b < e->n_boxes; b++) { /* entity order; a later box wins only when strictly nearer */
+                    float tb; int fc = trace_box(&bxs[b], c.eye, d, &tb);
+                    if (fc >= 0 && tb < hits[k].t) { hits[k].kind = 4; hits[k].t = tb; hits[k].room = b; hits[k].side = fc; }
+                }
             }
             float dc[3], dx[3], dy[3];
             make_ray(&c, cx, cy, dc); make_ray(&c, cx + 1.0f, cy, dx); make_ray(&c, cx, cy + 1.0f, dy);
@@ -1100,7 +1186,7 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
                 float col[3];
                 const Hit *h = &hits[k];
                 if (h->kind == 0) { col[0] = L.sky[0]; col[1] = L.sky[1]; col[2] = L.sky[2]; }
-                else if (h->kind == 4) { col[0] = lit_box[h->side][0]; col[1] = lit_box[h->side][1]; col[2] = lit_box[h->side][2]; }
+                else if (h->kind == 4) { const float *lb = lit_boxes[h->room][h->side]; col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2]; }
                 else {
                     float s0, t0, s1, t1, s2, t2;
                     int tex = h->kind == 1 ? rr[h->room].floor_tex : h->kind == 2 ? rr[h->room].ceil_tex : rr[h->room].wall_tex;

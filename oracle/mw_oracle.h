@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-enum { MWO_HALLWAY = 0, MWO_ONEROOM = 1, MWO_FOURROOMS = 2, MWO_MAZE = 3 };
+enum { MWO_HALLWAY = 0, MWO_ONEROOM = 1, MWO_FOURROOMS = 2, MWO_MAZE = 3, MWO_TMAZE = 4, MWO_TMAZE_TWOBOX = 5 };
 
 /* domain parameters, reference params.py:110-123, same order */
 enum {
@@ -44,7 +44,9 @@ typedef struct MwoEnv MwoEnv;
  * level l at data + level_off[l], dims max(1, w>>l) (floor halving) */
 int mwo_set_texture(int tex_id, int width, int height, int n_levels, const uint8_t *rgba_all_levels);
 
-/* task_args: Hallway {length}, OneRoom {size}, FourRooms {}, Maze {num_rows, num_cols, room_size}.
+/* task_args: Hallway {length}, OneRoom {size}, FourRooms {}, Maze {num_rows, num_cols, room_size},
+ * TMaze {goal_pos given?, goal x, goal z, sub_task_length (> 0: TMazeDynamic)},
+ * TMazeTwoBox {rule: 0 episode count (TMazeTwoBoxDynamic) / 1 step count + features (*Features*), -, -, sub_task_length}.
  * params: MWO_NPARAM x 9 doubles (default[3], min[3], max[3]); NULL = reference defaults. */
 MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int domain_rand,
                    const double *params);
@@ -64,10 +66,16 @@ typedef struct {
     int step_count, max_episode_steps, n_rooms, n_segs, n_quads;
     int rng_pos;
     uint32_t rng_key0, rng_key1, rng_key623, rng_keysum;
+    /* T-maze family */
+    int n_boxes, goal_idx;
+    double box2_pos[3], box2_dir, box2_color[3];
+    long long episode_count, task_step_count;
+    double feature[2]; /* info['feature'] of the last step (zeros for tasks without) */
 } MwoState;
 void mwo_get_state(MwoEnv *e, MwoState *out);
 void mwo_set_agent(MwoEnv *e, double x, double z, double dir); /* test hook */
 void mwo_set_step_count(MwoEnv *e, int step_count);
+void mwo_set_counters(MwoEnv *e, long long episode_count, long long task_step_count, int goal_idx); /* test hook */
 /* geometry dumps (sizes from MwoState): outline R*4*2, heights R, portals R*4*MAXP*4 (nan pad),
  * portal_count R*4, segs S*4 (a.x a.z b.x b.z), room_probs R, quad verts Q*4*3, norms Q*4*3,
  * texcs Q*4*2 (float), quad_offsets R+1, floor_texcs R*4*2, ceil_texcs R*4*2, tex ids R*3 */
@@ -75,7 +83,7 @@ void mwo_get_geometry(MwoEnv *e, double *outline, double *heights, double *porta
                       double *segs, double *room_probs, double *quad_verts, double *quad_norms,
                       float *quad_texcs, int *quad_offsets, double *floor_texcs, double *ceil_texcs,
                       int *tex_ids);
-int mwo_intersect(MwoEnv *e, int ent /*0=box,1=agent*/, double x, double z, double radius);
+int mwo_intersect(MwoEnv *e, int ent /*0=box,1=agent,2=box2*/, double x, double z, double radius);
 
 /* render the agent's view (reference render_obs / render_depth); rgb: H*W*3 row 0 = top,
  * depth: H*W float metres or NULL */

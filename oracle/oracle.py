@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmw_oracle.so")
 TEX_DIR = os.path.join(os.path.dirname(HERE), "gym_miniworld_amd", "textures")
 
-TASKS = {"Hallway": 0, "OneRoom": 1, "FourRooms": 2, "Maze": 3}
+TASKS = {"Hallway": 0, "OneRoom": 1, "FourRooms": 2, "Maze": 3, "TMaze": 4, "TMazeTwoBox": 5}
 # texture id table (family -> files), reference opengl.py:40-69 picks <name>_<i>.png
 TEX_FILES = ["floor_tiles_bw_1", "concrete_1", "concrete_2", "concrete_3", "concrete_4",
              "concrete_tiles_1", "brick_wall_1"]
@@ -44,6 +44,10 @@ class MwoState(ctypes.Structure):
         ("n_segs", ctypes.c_int), ("n_quads", ctypes.c_int), ("rng_pos", ctypes.c_int),
         ("rng_key0", ctypes.c_uint32), ("rng_key1", ctypes.c_uint32), ("rng_key623", ctypes.c_uint32),
         ("rng_keysum", ctypes.c_uint32),
+        ("n_boxes", ctypes.c_int), ("goal_idx", ctypes.c_int),
+        ("box2_pos", ctypes.c_double * 3), ("box2_dir", ctypes.c_double), ("box2_color", ctypes.c_double * 3),
+        ("episode_count", ctypes.c_longlong), ("task_step_count", ctypes.c_longlong),
+        ("feature", ctypes.c_double * 2),
     ]
 
 
@@ -65,6 +69,7 @@ def lib():
         L.mwo_get_state.argtypes = [vp, ctypes.POINTER(MwoState)]
         L.mwo_set_agent.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         L.mwo_set_step_count.argtypes = [vp, ctypes.c_int]
+        L.mwo_set_counters.argtypes = [vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int]
         L.mwo_get_geometry.argtypes = [vp] + [vp] * 13
         L.mwo_intersect.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         L.mwo_render.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp]
@@ -204,6 +209,9 @@ class OracleEnv:
 
     def set_step_count(self, n):
         self.L.mwo_set_step_count(self.h, n)
+
+    def set_counters(self, episode_count, task_step_count, goal_idx):
+        self.L.mwo_set_counters(self.h, int(episode_count), int(task_step_count), int(goal_idx))
 
     def intersect_agent(self, x, z, radius=0.4):
         return self.L.mwo_intersect(self.h, 1, x, z, radius)

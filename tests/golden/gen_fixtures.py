@@ -25,6 +25,8 @@ deps.install("/root/reference")
 
 import gym_miniworld  # noqa: E402,F401
 from gym_miniworld.envs import FourRooms, Hallway, Maze, OneRoom  # noqa: E402
+from gym_miniworld.envs import (TMaze, TMazeDynamic, TMazeLeft, TMazeRight, TMazeTwoBoxDynamic,  # noqa: E402
+                                TMazeTwoBoxDynamicFeatures100K, TMazeTwoBoxDynamicFeaturesDebug)
 from gym_miniworld.opengl import Texture  # noqa: E402
 from gym_miniworld import math as ref_math  # noqa: E402
 
@@ -36,7 +38,15 @@ TASKS = {
     "MazeR2C4": (Maze, {"num_rows": 2, "num_cols": 4, "room_size": 2.5, "max_episode_steps": 200}),
     "OneRoomS6": (OneRoom, {"size": 6, "max_episode_steps": 100}),
     "Hallway6": (Hallway, {"length": 6}),
+    # the T-maze family (envs/tmaze.py); small sub_task_length so that the goal alternation
+    # rules fire within the recorded trajectories
+    "TMaze": (TMaze, {}), "TMazeLeft": (TMazeLeft, {}), "TMazeRight": (TMazeRight, {}),
+    "TMazeDynamic3": (TMazeDynamic, {"sub_task_length": 3}),
+    "TMazeTwoBoxDynamic2": (TMazeTwoBoxDynamic, {"sub_task_length": 2}),
+    "TMazeTwoBoxFeatures": (TMazeTwoBoxDynamicFeatures100K, {"sub_task_length": 150}),
+    "TMazeTwoBoxFeaturesDebug": (TMazeTwoBoxDynamicFeaturesDebug, {}),
 }
+NO_KWARGS = {"TMazeLeft", "TMazeRight", "TMazeDynamic3"}   # constructors without **kwargs: no domain_rand
 
 # (seed, domain_rand, policy, n_steps)
 PLAN = {
@@ -52,6 +62,13 @@ PLAN = {
     "MazeR2C4": [(0, 0, "greedy", 450), (1, 1, "forward", 450)],
     "OneRoomS6": [(0, 0, "random", 250), (1, 1, "greedy", 150)],
     "Hallway6": [(0, 0, "random", 300), (1, 1, "greedy", 100)],
+    "TMaze": [(0, 0, "random", 700), (1, 0, "greedy", 400), (2, 1, "greedy", 400), (3, 1, "forward", 400)],
+    "TMazeLeft": [(0, 0, "greedy", 300), (1, 0, "random", 600)],
+    "TMazeRight": [(0, 0, "greedy", 300), (1, 0, "forward", 400)],
+    "TMazeDynamic3": [(0, 0, "greedy", 1200), (1, 0, "forward", 900)],
+    "TMazeTwoBoxDynamic2": [(0, 0, "greedy", 700), (1, 1, "greedy_red", 700), (2, 0, "random", 600)],
+    "TMazeTwoBoxFeatures": [(0, 0, "greedy", 600), (1, 1, "greedy_blue", 600), (2, 1, "forward", 500)],
+    "TMazeTwoBoxFeaturesDebug": [(0, 0, "greedy_blue", 300), (1, 1, "greedy", 300)],
 }
 
 
@@ -102,11 +119,25 @@ def snapshot_world(env):
     return d
 
 
+def first_box(env):
+    return env.box if hasattr(env, "box") else env.red_box
+
+
 def snapshot_entities(env):
     a = env.agent
+    box = first_box(env)
+    extra = {}
+    if hasattr(env, "blue_box"):
+        b2 = env.blue_box
+        extra = {"box2_pos": np.array(b2.pos, dtype=float), "box2_dir": np.array(float(b2.dir)),
+                 "box2_color": np.array(b2.color_vec, dtype=float),
+                 "goal_idx": np.array(int(env.goal_box_idx))}
+    elif hasattr(env, "current_goal"):
+        extra = {"goal_idx": np.array(int(env.current_goal))}
     return {
-        "box_pos": np.array(env.box.pos, dtype=float), "box_dir": np.array(float(env.box.dir)),
-        "box_color": np.array(env.box.color_vec, dtype=float),
+        **extra,
+        "box_pos": np.array(box.pos, dtype=float), "box_dir": np.array(float(box.dir)),
+        "box_color": np.array(box.color_vec, dtype=float),
         "agent_pos": np.array(a.pos, dtype=float), "agent_dir": np.array(float(a.dir)),
         "cam": np.array([a.cam_height, a.cam_fwd_disp, a.cam_pitch, a.cam_fov_y], dtype=float),
         "sky_color": np.array(env.sky_color, dtype=float), "light_pos": np.array(env.light_pos, dtype=float),
@@ -122,16 +153,33 @@ def choose_action(env, policy, arng):
     if policy == "forward":
         return 2 if arng.random() < 0.9 else int(arng.integers(0, 2))
     # greedy: turn toward the box, then walk
-    a, b = env.agent, env.box
-    want = math.atan2(-(b.pos[2] - a.pos[2]), b.pos[0] - a.pos[0])
+    a = env.agent
+    if policy == "greedy_red":
+        b = env.red_box
+    elif policy == "greedy_blue":
+        b = env.blue_box
+    elif hasattr(env, "boxes"):
+        b = env.boxes[env.goal_box_idx]
+    else:
+        b = env.box
+    tgt = b.pos
+    if type(env).__name__.startswith("TMaze") and a.pos[0] < 9.2:
+        tgt = np.array([10.0, 0.0, 0.0])   # leave the stem of the T before heading for the arm
+    want = math.atan2(-(tgt[2] - a.pos[2]), tgt[0] - a.pos[0])
     diff = (want - a.dir + math.pi) % (2 * math.pi) - math.pi
     if abs(diff) > math.radians(10):
         return 0 if diff > 0 else 1
     return 2
 
 
+def construct(cls, kwargs, dr):
+    if dr:
+        return cls(domain_rand=True, **kwargs)
+    return cls(**kwargs)
+
+
 def run_case(cls, kwargs, seed, dr, policy, n_steps):
-    env = cls(domain_rand=bool(dr), **kwargs)
+    env = construct(cls, kwargs, dr)
     env.seed(seed)
     env.reset()
     out = {"reset0/" + k: v for k, v in snapshot_world(env).items()}
@@ -148,11 +196,17 @@ def run_case(cls, kwargs, seed, dr, policy, n_steps):
     # state after the worker's auto-reset (subproc_vec_env.py worker: `if done: ob = env.reset()`)
     post = {k: [] for k in ("step", "agent_pos", "agent_dir", "box_pos", "box_dir", "box_color", "cam",
                             "sky_color", "light_pos", "light_color", "light_ambient", "rng", "n_rooms",
-                            "segs_sum")}
+                            "segs_sum", "box2_pos", "box2_dir", "box2_color", "goal_idx")}
+    feat = np.zeros((n_steps, 2))
+    goal_pos = np.zeros((n_steps, 2))
     for t in range(n_steps):
         a = choose_action(env, policy, arng)
         actions[t] = a
-        _, r, d, _ = env.step(a)
+        _, r, d, info = env.step(a)
+        if "feature" in info:
+            feat[t] = info["feature"]
+        if "goal_pos" in info:
+            goal_pos[t] = np.asarray(info["goal_pos"])[[0, 2]]
         pos[t] = env.agent.pos[[0, 2]]
         dirs[t] = env.agent.dir
         rew[t] = r
@@ -169,6 +223,8 @@ def run_case(cls, kwargs, seed, dr, policy, n_steps):
                 post[k].append(s[k])
             post["n_rooms"].append(len(env.rooms))
             post["segs_sum"].append(float(np.sum(env.wall_segs)))
+    if hasattr(env, "boxes") or hasattr(env, "goal_pos"):
+        out.update({"traj/feature": feat, "traj/goal_pos": goal_pos})
     out.update({"traj/actions": actions, "traj/pos": pos, "traj/dir": dirs, "traj/reward": rew,
                 "traj/done": done, "traj/step_count": stepc, "traj/rng": rngpos,
                 "traj/cam_pos": campos, "traj/cam_dir": camdir})
@@ -180,9 +236,11 @@ def run_case(cls, kwargs, seed, dr, policy, n_steps):
     return out
 
 
-def capture_gl(cls, kwargs, seed, dr):
-    """One reset() under the call recorder -> structured polygon list (renderer *input* parity)."""
-    env = cls(domain_rand=bool(dr), **kwargs)
+def capture_gl(cls, kwargs, seed, dr, pose=None):
+    """One reset() under the call recorder -> structured polygon list (renderer *input* parity).
+    With pose = (x, z, dir) the agent is then moved there and render_obs() is recorded again: the
+    camera calls of that second frame replace the first frame's (the polygons are the same)."""
+    env = construct(cls, kwargs, dr)
     env.seed(seed)
     deps.GL_LOG.clear()
     deps.GL_LOG_ENABLED[0] = True
@@ -190,6 +248,14 @@ def capture_gl(cls, kwargs, seed, dr):
     deps.GL_LOG_ENABLED[0] = False
     log = list(deps.GL_LOG)
     deps.GL_LOG.clear()
+    if pose is not None:
+        env.agent.pos = np.array([pose[0], 0.0, pose[1]])
+        env.agent.dir = pose[2]
+        deps.GL_LOG_ENABLED[0] = True
+        env.render_obs()
+        deps.GL_LOG_ENABLED[0] = False
+        log += [(n, a) for (n, a) in deps.GL_LOG if n in ("gluPerspective", "gluLookAt")]
+        deps.GL_LOG.clear()
     polys, lights, misc = [], {}, {}
     cur = {"color": None, "normal": None, "texc": None, "tex_on": False, "mode": None, "xform": []}
     poly = None
@@ -237,6 +303,8 @@ def capture_gl(cls, kwargs, seed, dr):
         "agent_pos": ents["agent_pos"].tolist(), "agent_dir": float(ents["agent_dir"]),
         "box_pos": ents["box_pos"].tolist(), "box_dir": float(ents["box_dir"]),
         "box_color": ents["box_color"].tolist(), "cam": ents["cam"].tolist(),
+        **({"box2_pos": ents["box2_pos"].tolist(), "box2_dir": float(ents["box2_dir"]),
+            "box2_color": ents["box2_color"].tolist()} if "box2_pos" in ents else {}),
     }
 
 
@@ -256,7 +324,10 @@ def math_kat():
 
 
 def main():
+    only = sys.argv[1:]   # optional task-name prefixes: regenerate just those fixtures
     for task, (cls, kwargs) in TASKS.items():
+        if only and not any(task.startswith(o) for o in only):
+            continue
         blob = {}
         for (seed, dr, policy, n) in PLAN[task]:
             case = run_case(cls, kwargs, seed, dr, policy, n)
@@ -271,9 +342,16 @@ def main():
                 continue
             if task in ("MazeR2C4", "OneRoomS6", "Hallway6"):
                 continue
-            g = capture_gl(cls, kwargs, 1, dr)
+            if task.startswith("TMaze") and not ((task == "TMaze" and dr == 0) or (task == "TMazeTwoBoxFeatures" and dr == 1)):
+                continue
+            # the two-box scene is captured from inside the bar of the T, with both boxes in view
+            pose = (11.5, 7.6, 2.13) if task == "TMazeTwoBoxFeatures" else None
+            g = capture_gl(cls, kwargs, 1, dr, pose)
+            g["posed"] = pose is not None
             with open(os.path.join(HERE, "glstream_%s_dr%d.json" % (task, dr)), "w") as fh:
                 json.dump(g, fh, separators=(",", ":"))
+    if only:
+        return
     np.savez_compressed(os.path.join(HERE, "math_kat.npz"), **math_kat())
     # the assumed gym seed hashing, exposed as data so the product/oracle can be checked without gym
     seeds = [0, 1, 2, 3, 7, 42, 4097, 65535, 2**32 + 5, 2**63 + 11]

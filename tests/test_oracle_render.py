@@ -14,7 +14,16 @@ import pytest
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STREAMS = [("Hallway", "Hallway", None, 0), ("Hallway", "Hallway", None, 1), ("OneRoom", "OneRoom", None, 0),
            ("OneRoom", "OneRoom", None, 1), ("FourRooms", "FourRooms", None, 0), ("FourRooms", "FourRooms", None, 1),
-           ("MazeS3", "Maze", [3, 3, 3], 1), ("Maze", "Maze", None, 0)]
+           ("MazeS3", "Maze", [3, 3, 3], 1), ("Maze", "Maze", None, 0),
+           ("TMaze", "TMaze", [0, 0, 0, 0], 0), ("TMazeTwoBoxFeatures", "TMazeTwoBox", [1, 0, 0, 150], 1)]
+
+
+def posed_env(O, g, task, args, dr):
+    env = O.OracleEnv(task, seed=g["seed"], domain_rand=dr, task_args=args)
+    env.reset(render=False)
+    if g.get("posed"):   # the stream's camera frame was captured after moving the agent (gen_fixtures.capture_gl)
+        env.set_agent(g["agent_pos"][0], g["agent_pos"][2], g["agent_dir"])
+    return env
 
 
 def load_stream(name, dr):
@@ -26,12 +35,11 @@ def load_stream(name, dr):
 def test_scene_inputs_equal_reference_gl_stream(oracle_mod, name, task, args, dr):
     O = oracle_mod
     g = load_stream(name, dr)
-    env = O.OracleEnv(task, seed=g["seed"], domain_rand=dr, task_args=args)
-    env.reset(render=False)
+    env = posed_env(O, g, task, args, dr)
     geo, s = env.geometry(), env.state()
     R = s.n_rooms
     polys = g["polys"]
-    assert len(polys) == 3 * R + 1
+    assert len(polys) == 3 * R + s.n_boxes
     for r in range(R):
         fl, ce, wa = polys[3 * r: 3 * r + 3]
         o = geo["outline"][r]
@@ -47,10 +55,11 @@ def test_scene_inputs_equal_reference_gl_stream(oracle_mod, name, task, args, dr
         assert np.array_equal(np.array(wa["texcs"], dtype=np.float64).reshape(-1, 2), geo["wall_texcs"][q0:q1].astype(np.float64))
         assert fl["color"] == [1.0, 1.0, 1.0] and fl["tex_on"]
         assert [O.TEX_FILES[i] for i in geo["tex_ids"][r]] == g["room_tex"][r]
-    box = polys[-1]
-    assert not box["tex_on"] and box["color"] == pytest.approx(list(s.box_color), abs=0)
-    assert box["xform"][0] == ["translate"] + list(s.box_pos)
-    assert box["xform"][1][0] == "rotate" and box["xform"][1][1] == s.box_dir * (180 / np.pi)
+    boxes = [(s.box_pos, s.box_dir, s.box_color), (s.box2_pos, s.box2_dir, s.box2_color)][:s.n_boxes]
+    for box, (bpos, bdir, bcol) in zip(polys[3 * R:], boxes):   # entity order: red box, blue box
+        assert not box["tex_on"] and box["color"] == pytest.approx(list(bcol), abs=0)
+        assert box["xform"][0] == ["translate"] + list(bpos)
+        assert box["xform"][1][0] == "rotate" and box["xform"][1][1] == bdir * (180 / np.pi)
     # light: (light_pos + 1, w = 0) as float32 ctypes (miniworld.py:1026), ambient / diffuse
     lp = np.array(g["lights"]["GL_POSITION"])
     assert lp[3] == 0.0 and np.array_equal(lp[:3], (np.array(s.light_pos) + 1).astype(np.float32))
@@ -71,8 +80,8 @@ def test_render_equals_bruteforce_rendition_of_gl_stream(oracle_mod, name, task,
     g = load_stream(name, dr)
     tex = O.load_textures()
     textures = {O.TEX_FILES[i]: tex[i][2] for i in tex}
-    env = O.OracleEnv(task, seed=g["seed"], domain_rand=dr, task_args=args)
-    a = env.reset()
+    env = posed_env(O, g, task, args, dr)
+    a = env.render_obs()
     b = SR.render_stream(g, textures)
     d = np.abs(a.astype(int) - b.astype(int))
     # float32 portal traversal vs float64 polygon soup: a sample exactly on an edge may flip (1/8 weight)
