@@ -1,7 +1,8 @@
 """gym_miniworld_amd - MI355X-native batched MiniWorld stepper + renderer.
 
 Drop-in for the hot path of mjsargent/gym-miniworld (MiniWorldEnv.step / render_obs behind the
-Gym and VecEnv protocols) for the Hallway / OneRoom / FourRooms / Maze tasks.  See DESIGN.md.
+Gym and VecEnv protocols) for the Hallway / OneRoom / FourRooms / Maze tasks and the T-maze
+family (TMaze, TMazeLeft / Right, TMazeDynamic, the two-box variants).  See DESIGN.md.
 """
 from .params import DEFAULT_PARAMS, DomainParams  # noqa: F401
 

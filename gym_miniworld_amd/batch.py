@@ -35,7 +35,18 @@ ENV_SPECS = {
     "MiniWorld-MazeS2-v0": ("Maze", [2, 2, 3], 0, None, None),
     "MiniWorld-MazeS3-v0": ("Maze", [3, 3, 3], 0, None, None),
     "MiniWorld-MazeS3Fast-v0": ("Maze", [3, 3, 3], 300, _fast_params, False),
+    # the T-maze family (envs/tmaze.py); task_args as documented at MWB_TASK_TMAZE / MWB_TASK_TMAZE_TWOBOX
+    "MiniWorld-TMaze-v0": ("TMaze", [0, 0, 0, 0], 0, None, None),
+    "MiniWorld-TMazeLeft-v0": ("TMaze", [1, 10, -6, 0], 0, None, None),      # tmaze.py:69-71
+    "MiniWorld-TMazeRight-v0": ("TMaze", [1, 10, 6, 0], 0, None, None),      # tmaze.py:73-75
+    "MiniWorld-TMazeDynamic-v0": ("TMaze", [1, 10, -6, 100], 0, None, None),  # tmaze.py:77-96
+    "MiniWorld-TMazeTwoBoxDynamic-v0": ("TMazeTwoBox", [0, 0, 0, 100], 0, None, None),                  # tmaze.py:108-149
+    "MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0": ("TMazeTwoBox", [1, 0, 0, 100000], 0, None, None),  # tmaze.py:220-251
+    "MiniWorld-TMazeTwoBoxDynamicFeatures1M-v0": ("TMazeTwoBox", [1, 0, 0, 1000000], 0, None, None),
+    "MiniWorld-TMazeTwoBoxDynamicFeatures10M-v0": ("TMazeTwoBox", [1, 0, 0, 10000000], 0, None, None),
+    "MiniWorld-TMazeTwoBoxDynamicFeaturesDebug-v0": ("TMazeTwoBox", [1, 0, 0, 9000000000000], 0, None, None),
 }
+
 
 
 class _DevView:
@@ -120,6 +131,11 @@ class BatchedMiniWorld:
         self.reward64 = as_t(out.reward64, (N,), "<f8")
         self.done = as_t(out.done, (N,), "|u1")
         self.ep_steps = as_t(out.ep_steps, (N,), "<i4")
+        self.feature = as_t(out.feature, (N, 2), "<f4")     # info['feature'] (tmaze.py:311-318); zeros elsewhere
+        self.goal_pos = as_t(out.goal_pos, (N, 3), "<f8")   # info['goal_pos'] of the T-maze family
+        self.n_boxes = 2 if task == "TMazeTwoBox" else 1
+        self.has_features = task == "TMazeTwoBox" and ta[0] != 0
+        self.has_goal_pos = task in ("TMaze", "TMazeTwoBox")
         self.max_episode_steps = self._max_steps(task, ta, max_episode_steps)
         if seed is not None:
             self.seed(seed)
@@ -128,7 +144,7 @@ class BatchedMiniWorld:
     def _max_steps(task, ta, mes):
         if mes:
             return int(mes)
-        return {"Hallway": 250, "OneRoom": 180, "FourRooms": 250}.get(task) or int(ta[0] or 8) * int(ta[1] or 8) * 24
+        return {"Hallway": 250, "OneRoom": 180, "FourRooms": 250, "TMaze": 280, "TMazeTwoBox": 280}.get(task) or int(ta[0] or 8) * int(ta[1] or 8) * 24
 
     def _load_textures(self):
         from PIL import Image
@@ -202,11 +218,13 @@ class BatchedMiniWorld:
         count = self.num_envs - first if count is None else count
         shapes = {"agent_pos": (count, 3), "agent_dir": (count,), "box_pos": (count, 3), "box_dir": (count,),
                   "box_color": (count, 3), "cam": (count, 4), "sky_color": (count, 3), "light_pos": (count, 3),
-                  "light_color": (count, 3), "light_ambient": (count, 3)}
+                  "light_color": (count, 3), "light_ambient": (count, 3),
+                  "box2_pos": (count, 3), "box2_dir": (count,), "box2_color": (count, 3)}
         out = {k: np.zeros(s, np.float64) for k, s in shapes.items()}
         out.update({"step_count": np.zeros(count, np.int32), "rng_pos": np.zeros(count, np.int32),
                     "rng_keysum": np.zeros(count, np.uint32), "n_rooms": np.zeros(count, np.int32),
-                    "n_segs": np.zeros(count, np.int32)})
+                    "n_segs": np.zeros(count, np.int32), "goal_idx": np.zeros(count, np.int32),
+                    "episode_count": np.zeros(count, np.int64), "task_step_count": np.zeros(count, np.int64)})
         st = _lib.MwbState()
         for k, v in out.items():
             setattr(st, k, v.ctypes.data_as(ctypes.c_void_p))
@@ -219,6 +237,14 @@ class BatchedMiniWorld:
         count = next(len(a) if a.ndim else 1 for a in arrs if a is not None)
         ptrs = [None if a is None else a.ctypes.data_as(ctypes.c_void_p) for a in arrs]
         _lib.check(self.L.mwb_set_agent(self.h, first, count, *ptrs))
+
+    def set_task_state(self, first, episode_count=None, task_step_count=None, goal_idx=None):
+        """Overwrite the goal-alternation state of the T-maze family (test hook, mwb_set_task_state)."""
+        arrs = [None if a is None else np.ascontiguousarray(np.atleast_1d(a), dt) for a, dt in
+                ((episode_count, np.int64), (task_step_count, np.int64), (goal_idx, np.int32))]
+        count = next(len(a) for a in arrs if a is not None)
+        ptrs = [None if a is None else a.ctypes.data_as(ctypes.c_void_p) for a in arrs]
+        _lib.check(self.L.mwb_set_task_state(self.h, first, count, *ptrs))
 
     def intersect(self, env, x, z, radius=0.4):
         r = ctypes.c_int()

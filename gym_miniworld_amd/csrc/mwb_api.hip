@@ -174,7 +174,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     if (!cfg || !out) return set_err(MWB_EINVAL, "mwb_create: null argument");
     if (cfg->abi_version != MWB_ABI_VERSION) return set_err(MWB_EINVAL, "mwb_create: abi_version mismatch");
     if (cfg->num_envs <= 0) return set_err(MWB_EINVAL, "mwb_create: num_envs must be > 0");
-    if (cfg->task < 0 || cfg->task > MWB_TASK_MAZE) return set_err(MWB_EINVAL, "mwb_create: unknown task");
+    if (cfg->task < 0 || cfg->task > MWB_TASK_TMAZE_TWOBOX) return set_err(MWB_EINVAL, "mwb_create: unknown task");
     if (cfg->obs_width <= 0 || cfg->obs_height <= 0 || cfg->obs_width > 1024 || cfg->obs_height > 1024)
         return set_err(MWB_EINVAL, "mwb_create: bad observation size");
     if (cfg->layout != MWB_LAYOUT_HWC && cfg->layout != MWB_LAYOUT_CWH) return set_err(MWB_EINVAL, "mwb_create: bad layout");
@@ -192,13 +192,15 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     d.want_depth = cfg->want_depth ? 1 : 0; d.layout = cfg->layout; d.domain_rand = cfg->domain_rand ? 1 : 0;
     d.auto_reset = cfg->no_auto_reset ? 0 : 1;
     { const char *dbg = getenv("MWB_DEBUG"); d.debug_flags = dbg ? atoi(dbg) : 0; }
-    static const double dflt[4][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}};
+    static const double dflt[6][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}};
+    d.n_boxes = cfg->task == MWB_TASK_TMAZE_TWOBOX ? 2 : 1;
     for (int i = 0; i < 4; i++) d.task_args[i] = cfg->task_args[i] != 0 ? cfg->task_args[i] : dflt[cfg->task][i];
     int mes = cfg->max_episode_steps;
     if (mes <= 0) {   // hallway.py:18, oneroom.py:14, fourrooms.py:15, maze.py:27
         if (d.task == MWB_TASK_HALLWAY) mes = 250;
         else if (d.task == MWB_TASK_ONEROOM) mes = 180;
         else if (d.task == MWB_TASK_FOURROOMS) mes = 250;
+        else if (d.task == MWB_TASK_TMAZE || d.task == MWB_TASK_TMAZE_TWOBOX) mes = 280;   // tmaze.py:20,142
         else mes = (int)d.task_args[0] * (int)d.task_args[1] * 24;
     }
     d.max_episode_steps = mes;
@@ -209,7 +211,10 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     if (d.task == MWB_TASK_HALLWAY) { if (!(d.task_args[0] >= 2)) { delete h; return set_err(MWB_EINVAL, "Hallway: length >= 2"); } d.R_max = 1; d.S_max = 4; }
     else if (d.task == MWB_TASK_ONEROOM) { if (!(d.task_args[0] >= 2)) { delete h; return set_err(MWB_EINVAL, "OneRoom: size >= 2"); } d.R_max = 1; d.S_max = 4; }
     else if (d.task == MWB_TASK_FOURROOMS) { d.R_max = 8; d.S_max = 32; }
-    else {
+    else if (d.task == MWB_TASK_TMAZE || d.task == MWB_TASK_TMAZE_TWOBOX) {
+        if (d.task_args[3] < 0 || d.task_args[3] > 9e15) { delete h; return set_err(MWB_EINVAL, "TMaze: bad sub_task_length"); }
+        d.R_max = 2; d.S_max = 8;
+    } else {
         int rows = (int)d.task_args[0], cols = (int)d.task_args[1];
         if (rows < 1 || cols < 1 || rows * cols > 4096) { delete h; return set_err(MWB_EINVAL, "Maze: bad num_rows / num_cols"); }
         d.R_max = 2 * rows * cols - 1; d.S_max = 4 * rows * cols;
@@ -218,8 +223,8 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     size_t N = (size_t)d.N;
     int rc = MWB_OK;
 #define A(ptr, n) if (rc == MWB_OK) rc = dev_alloc(h, &(ptr), (n))
-    A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N); A(d.box_z, N); A(d.box_dir, N);
-    A(d.box_color, N * 3); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
+    A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N * d.n_boxes); A(d.box_z, N * d.n_boxes); A(d.box_dir, N * d.n_boxes);
+    A(d.box_color, N * d.n_boxes * 3); A(d.episode_count, N); A(d.task_step_count, N); A(d.goal_idx, N); A(d.feature, N * 2); A(d.goal_pos, N * 3); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
     A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.reset_set, N); A(d.reset_list, N); A(d.reset_count, (size_t)1);
     A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * MWB_ROOM_WORDS); A(d.segs, N * d.S_max * 4); A(d.frame, N * MWB_FRAME_WORDS);
     A(d.obs, N * d.W * d.H * 3);
@@ -230,6 +235,15 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     A(d.error_flag, (size_t)1);
 #undef A
     if (rc != MWB_OK) { mwb_destroy(h); return rc; }
+    // MiniWorldEnv.__init__ ends with self.reset() (miniworld.py:523): the episode counters of TMazeDynamic /
+    // TMazeTwoBoxDynamic (tmaze.py:80,130) have seen one reset when the caller gets the env
+    if ((d.task == MWB_TASK_TMAZE && d.task_args[3] > 0) || (d.task == MWB_TASK_TMAZE_TWOBOX && d.task_args[0] == 0)) {
+        std::vector<int64_t> ones(N, 1);
+        if (hipMemcpy(d.episode_count, ones.data(), N * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) {
+            mwb_destroy(h);
+            return set_err(MWB_EHIP, "mwb_create: hipMemcpy failed");
+        }
+    }
     d.tex_desc = h->tex_desc_dev;
     h->texels_dev = nullptr; d.texels = nullptr;
     h->seeded = false; h->textures_dirty = false; h->have_textures = false;
@@ -467,6 +481,7 @@ extern "C" int mwb_get_outputs(mwb_handle *h, mwb_outputs *out) {
     out->obs_bytes = (size_t)d.N * d.W * d.H * 3;
     out->depth_bytes = d.want_depth ? (size_t)d.N * d.W * d.H * 4 : 0;
     out->stack = h->stack; out->stack_bytes = h->stack_bytes;
+    out->feature = d.feature; out->goal_pos = d.goal_pos;
     return MWB_OK;
 }
 
@@ -533,6 +548,23 @@ extern "C" int mwb_get_state(mwb_handle *h, int first, int count, mwb_state *o) 
     if ((rc = fetch(o->agent_dir, d.agent_dir, first, count, 1))) return rc;
     if ((rc = fetch(o->box_dir, d.box_dir, first, count, 1))) return rc;
     if ((rc = fetch(o->box_color, d.box_color, first, count, 3))) return rc;
+    if (d.n_boxes == 2) {   // box 1 (blue) lives in the second plane of the box arrays
+        const size_t N = (size_t)d.N;
+        if (o->box2_pos) {
+            if ((rc = fetch(a.data(), d.box_x + N, first, count, 1))) return rc;
+            if ((rc = fetch(b.data(), d.box_z + N, first, count, 1))) return rc;
+            for (int i = 0; i < count; i++) { o->box2_pos[i * 3] = a[i]; o->box2_pos[i * 3 + 1] = 0.0; o->box2_pos[i * 3 + 2] = b[i]; }
+        }
+        if ((rc = fetch(o->box2_dir, d.box_dir + N, first, count, 1))) return rc;
+        if ((rc = fetch(o->box2_color, d.box_color + N * 3, first, count, 3))) return rc;
+    } else {
+        if (o->box2_pos) memset(o->box2_pos, 0, sizeof(double) * 3 * count);
+        if (o->box2_dir) memset(o->box2_dir, 0, sizeof(double) * count);
+        if (o->box2_color) memset(o->box2_color, 0, sizeof(double) * 3 * count);
+    }
+    if ((rc = fetch(o->goal_idx, d.goal_idx, first, count, 1))) return rc;
+    if ((rc = fetch(o->episode_count, d.episode_count, first, count, 1))) return rc;
+    if ((rc = fetch(o->task_step_count, d.task_step_count, first, count, 1))) return rc;
     if ((rc = fetch(o->cam, d.cam, first, count, 4))) return rc;
     if ((rc = fetch(o->sky_color, d.sky_color, first, count, 3))) return rc;
     if ((rc = fetch(o->light_pos, d.light_pos, first, count, 3))) return rc;
@@ -568,6 +600,23 @@ extern "C" int mwb_set_agent(mwb_handle *h, int first, int count, const double *
     }
     if (dir) HIP_TRY(hipMemcpy(d.agent_dir + first, dir, count * sizeof(double), hipMemcpyHostToDevice));
     if (step_count) HIP_TRY(hipMemcpy(d.step_count + first, step_count, count * sizeof(int32_t), hipMemcpyHostToDevice));
+    return MWB_OK;
+}
+
+extern "C" int mwb_set_task_state(mwb_handle *h, int first, int count, const int64_t *episode_count, const int64_t *task_step_count,
+                                  const int32_t *goal_idx) {
+    if (!h) return set_err(MWB_EINVAL, "mwb_set_task_state: null handle");
+    const MwbDev &d = h->dev;
+    if (first < 0 || count < 0 || first + count > d.N) return set_err(MWB_EINVAL, "mwb_set_task_state: env range out of bounds");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (episode_count) HIP_TRY(hipMemcpy(d.episode_count + first, episode_count, count * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (task_step_count) HIP_TRY(hipMemcpy(d.task_step_count + first, task_step_count, count * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (goal_idx) {
+        for (int i = 0; i < count; i++)
+            if (goal_idx[i] < 0 || goal_idx[i] > 1) return set_err(MWB_EINVAL, "mwb_set_task_state: goal_idx must be 0 or 1");
+        HIP_TRY(hipMemcpy(d.goal_idx + first, goal_idx, count * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     return MWB_OK;
 }
 

@@ -18,7 +18,8 @@
 #define MWB_MT_WORDS 625   // 624 key words + pos
 #define MWB_MAX_TEX 7
 #define MWB_MAX_LEVELS 12
-#define MWB_FRAME_WORDS 80
+#define MWB_MAX_BOXES 2
+#define MWB_FRAME_WORDS 104
 
 // room table: 24 f32 words (96 B) per room; ints stored as bit patterns
 //   0-3  min_x max_x min_z max_z
@@ -54,6 +55,8 @@
 #define FC_LIT_FLOOR 17
 #define FC_LIT_CEIL 20
 #define FC_LIT_WALL 23   // 4 x 3
+// per-box block of FC_BOX_STRIDE words starting at FC_LIT_BOX; box b at + b * FC_BOX_STRIDE
+#define FC_BOX_STRIDE 34
 #define FC_LIT_BOX 35    // 6 x 3
 #define FC_BOX_POS 53
 #define FC_BOX_C 56
@@ -79,13 +82,16 @@ struct MwbParam { double def[3], lo[3], hi[3]; };
 struct MwbDev {
     int N, task, W, H, want_depth, layout, domain_rand, max_episode_steps;
     int R_max, S_max, auto_reset;
+    int n_boxes;       // 1, or 2 for MWB_TASK_TMAZE_TWOBOX (box 0 red, box 1 blue)
     int debug_flags;   // MWB_DEBUG env var at mwb_create: bit0 = resolve every pixel with the full 8-sample path
     double task_args[4];
     MwbParam params[MWB_NPARAM];
     // sim state (f64 SoA)
     double *agent_x, *agent_z, *agent_dir;
-    double *box_x, *box_z, *box_dir;
-    double *box_color;      // [N][3]
+    double *box_x, *box_z, *box_dir;   // [n_boxes][N]
+    double *box_color;      // [n_boxes][N][3]
+    int64_t *episode_count, *task_step_count;   // [N] goal-alternation counters of the T-maze family (envs/tmaze.py)
+    int32_t *goal_idx;      // [N]
     double *cam;            // [N][4] height, fwd_disp, pitch, fov_y
     double *sky_color, *light_pos, *light_color, *light_ambient;   // [N][3]
     int32_t *step_count, *n_rooms, *n_segs;
@@ -105,6 +111,8 @@ struct MwbDev {
     double *reward64;
     uint8_t *done;
     int32_t *ep_steps;
+    float *feature;         // [N][2]
+    double *goal_pos;       // [N][3]
 };
 
 // launch wrappers implemented in mwb_kernels.hip

@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(64) step_kernel(MwbDev d, const int32_t *__res
     if (skip && skip[e]) {   // the fork's 'dummy' command, vec_env/subproc_vec_env.py:26-31
         d.reward[e] = -99.0f; d.reward64[e] = -99.0; d.done[e] = 0; d.ep_steps[e] = d.step_count[e];
         d.reset_set[e] = 0;
+        d.feature[e * 2] = 0.0f; d.feature[e * 2 + 1] = 0.0f;   // info = {"feature": [0, 0]}
         return;
     }
     int sc = d.step_count[e] + 1;   // miniworld.py:663
@@ -136,7 +137,10 @@ __global__ void __launch_bounds__(64) step_kernel(MwbDev d, const int32_t *__res
     }
     int a = actions[e];
     double ax = d.agent_x[e], az = d.agent_z[e], adir = d.agent_dir[e];
-    double bx = d.box_x[e], bz = d.box_z[e];
+    const int NB = d.n_boxes;   // 1, or 2 in the two-box T-maze (entity order: red box, blue box, agent)
+    double bx[MWB_MAX_BOXES], bz[MWB_MAX_BOXES];
+    bx[0] = d.box_x[e]; bz[0] = d.box_z[e];
+    bx[1] = NB > 1 ? d.box_x[(size_t)d.N + e] : 0.0; bz[1] = NB > 1 ? d.box_z[(size_t)d.N + e] : 0.0;
     double brad = box_radius();
     if (a == 2 || a == 3) {   // move_agent, miniworld.py:608-633
         double fd = (a == 2) ? fwd_step : -fwd_step;
@@ -168,8 +172,8 @@ __global__ void __launch_bounds__(64) step_kernel(MwbDev d, const int32_t *__res
                 if (nearby) hit = seg_hit(q[k], nx, nz, AGENT_RADIUS) || hit;
             }
         }
-        if (!hit) {   // entity test, miniworld.py:946-957 (the box is the only other entity)
-            double ddx = bx - nx, ddz = bz - nz;
+        for (int b = 0; b < NB && !hit; b++) {   // entity test, miniworld.py:946-957 (boxes are the only other entities)
+            double ddx = bx[b] - nx, ddz = bz[b] - nz;
             double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
             hit = dist < AGENT_RADIUS + brad;
         }
@@ -184,12 +188,29 @@ __global__ void __launch_bounds__(64) step_kernel(MwbDev d, const int32_t *__res
     int done = 0;
     if (sc >= d.max_episode_steps) { done = 1; r = 0.0; }   // miniworld.py:708-711
     {   // near(box), miniworld.py:961-971, then the task rule (e.g. envs/maze.py:106-113)
-        double ddx = bx - ax, ddz = bz - az;
-        double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
-        double max_forward_step = d.params[MWB_P_FORWARD_STEP].hi[0];   // miniworld.py:569
-        if (dist < brad + AGENT_RADIUS + 1.1 * max_forward_step) {
-            r += 1.0 - 0.2 * ((double)sc / d.max_episode_steps);   // _reward, miniworld.py:1012
-            done = 1;
+        const double max_forward_step = d.params[MWB_P_FORWARD_STEP].hi[0];   // miniworld.py:569
+        const double thr = brad + AGENT_RADIUS + 1.1 * max_forward_step;
+        bool near[MWB_MAX_BOXES];
+#pragma unroll
+        for (int b = 0; b < MWB_MAX_BOXES; b++) {
+            double ddx = bx[b] - ax, ddz = bz[b] - az;
+            double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
+            near[b] = b < NB && dist < thr;
+        }
+        const double rw = 1.0 - 0.2 * ((double)sc / d.max_episode_steps);   // _reward, miniworld.py:1012
+        if (d.task == MWB_TASK_TMAZE_TWOBOX) {   // tmaze.py:196-208 / 299-320: goal box first, then the penalty box
+            const int g = d.goal_idx[e];
+            const bool near_goal = g ? near[1] : near[0], near_penalty = g ? near[0] : near[1];
+            if (near_goal) { r += rw; done = 1; }
+            if (near_penalty) { r += -1 * rw; done = 1; }
+            if (d.task_args[0] != 0) {   // the *Features* classes: feature = [near(blue), near(red)], and their step counter
+                d.feature[e * 2] = near[1] ? 1.0f : 0.0f; d.feature[e * 2 + 1] = near[0] ? 1.0f : 0.0f;
+                d.task_step_count[e] += 1;
+            }
+            d.goal_pos[e * 3] = g ? bx[1] : bx[0]; d.goal_pos[e * 3 + 1] = 0.0; d.goal_pos[e * 3 + 2] = g ? bz[1] : bz[0];   // info['goal_pos']
+        } else {
+            if (near[0]) { r += rw; done = 1; }
+            if (d.task == MWB_TASK_TMAZE) { d.goal_pos[e * 3] = bx[0]; d.goal_pos[e * 3 + 1] = 0.0; d.goal_pos[e * 3 + 2] = bz[0]; }
         }
     }
     d.reward64[e] = r; d.reward[e] = (float)r; d.done[e] = (uint8_t)done; d.ep_steps[e] = sc;
@@ -438,17 +459,37 @@ struct WorldGen {
         for (int i = lane; i < n_segs; i += WAVE) h = h || seg_hit(segs + i * 4, px, pz, radius);
         return __any(h);
     }
-    // place_entity, miniworld.py:845-907 (pos=None, room=None path)
+    // place_entity, miniworld.py:845-907 (pos=None path).  opt.room < 0: room=None, i.e. drawn with
+    // choice(rooms, p=room_probs); others: the entities placed before (list order), all of radius other_radius
+    struct PlaceOpt {
+        int room = -1;
+        bool has_dir = false, has_min_x = false, has_max_x = false, has_min_z = false, has_max_z = false;
+        double dir = 0, min_x = 0, max_x = 0, min_z = 0, max_z = 0;
+        int n_others = 0;
+        double other_x[MWB_MAX_BOXES] = {0, 0}, other_z[MWB_MAX_BOXES] = {0, 0}, other_radius = 0;
+    };
     __device__ void place_entity(double radius, bool has_other, double other_x, double other_z, double other_radius,
                                  bool has_dir, double dir_in, bool has_min_x, double min_x, bool has_max_x, double max_x,
                                  double &out_x, double &out_z, double &out_dir) {
+        PlaceOpt o;
+        o.has_dir = has_dir; o.dir = dir_in; o.has_min_x = has_min_x; o.min_x = min_x; o.has_max_x = has_max_x; o.max_x = max_x;
+        o.n_others = has_other ? 1 : 0; o.other_x[0] = other_x; o.other_z[0] = other_z; o.other_radius = other_radius;
+        place_entity_ex(radius, o, out_x, out_z, out_dir);
+    }
+    __device__ void place_entity_ex(double radius, const PlaceOpt &opt, double &out_x, double &out_z, double &out_dir) {
+        const bool has_dir = opt.has_dir;
+        const double dir_in = opt.dir;
         for (int attempt = 0; attempt < 100000; attempt++) {
-            double u = rng.next_double();   // choice(rooms, p=room_probs): searchsorted(cdf, u, 'right')
-            int lo = 0, hi = n_rooms;
-            while (lo < hi) { int mid = (lo + hi) / 2; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+            int lo = opt.room;
+            if (lo < 0) {
+                double u = rng.next_double();   // choice(rooms, p=room_probs): searchsorted(cdf, u, 'right')
+                int hi = n_rooms;
+                lo = 0;
+                while (lo < hi) { int mid = (lo + hi) / 2; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+            }
             const WRoom &r = rooms[lo < n_rooms ? lo : n_rooms - 1];
-            double lx = has_min_x ? min_x : r.min_x, hx = has_max_x ? max_x : r.max_x;
-            double lz = r.min_z, hz = r.max_z;
+            double lx = opt.has_min_x ? opt.min_x : r.min_x, hx = opt.has_max_x ? opt.max_x : r.max_x;
+            double lz = opt.has_min_z ? opt.min_z : r.min_z, hz = opt.has_max_z ? opt.max_z : r.max_z;
             double px = rng.uniform(lx + radius, hx - radius);
             (void)rng.uniform(0.0, 0.0);   // the y component draws too
             double pz = rng.uniform(lz + radius, hz - radius);
@@ -463,11 +504,13 @@ struct WorldGen {
             }
             if (!inside) continue;
             if (walls_hit(px, pz, radius)) continue;
-            if (has_other) {
-                double ddx = other_x - px, ddz = other_z - pz;
+            bool blocked = false;
+            for (int k = 0; k < opt.n_others; k++) {
+                double ddx = opt.other_x[k] - px, ddz = opt.other_z[k] - pz;
                 double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
-                if (dist < radius + other_radius) continue;
+                if (dist < radius + opt.other_radius) blocked = true;
             }
+            if (blocked) continue;
             out_dir = has_dir ? dir_in : rng.uniform(-3.141592653589793, 3.141592653589793);
             out_x = px; out_z = pz;
             return;
@@ -504,8 +547,59 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     bool dr = d.domain_rand != 0;
 
     double box_x = 0, box_z = 0, box_dir = 0, ag_x = 0, ag_z = 0, ag_dir = 0;
+    double box2_x = 0, box2_z = 0, box2_dir = 0;
     double brad = box_radius();
-    if (d.task == MWB_TASK_HALLWAY) {   // envs/hallway.py:25-42
+    // reset() overrides of the T-maze family run before MiniWorldEnv.reset (every lane computes the same)
+    int goal_idx = d.goal_idx[e];
+    long long episode_count = d.episode_count[e];
+    if (d.task == MWB_TASK_TMAZE && d.task_args[3] > 0) {   // TMazeDynamic.reset, tmaze.py:98-105
+        episode_count += 1;
+        if (episode_count % (long long)d.task_args[3] == 0) goal_idx = (goal_idx + 1) % 2;
+    } else if (d.task == MWB_TASK_TMAZE_TWOBOX) {
+        if (d.task_args[0] == 0) {   // TMazeTwoBoxDynamic.reset, tmaze.py:210-217
+            episode_count += 1;
+            if (episode_count % (long long)d.task_args[3] == 0) goal_idx = (goal_idx + 1) % 2;
+        } else if ((double)d.task_step_count[e] > d.task_args[3]) {   // *Features*.reset, tmaze.py:322-330; the counter is
+            goal_idx = (goal_idx + 1) % 2;                               // never cleared (the reference assigns a misspelt name)
+        }
+    }
+    if (d.task == MWB_TASK_TMAZE || d.task == MWB_TASK_TMAZE_TWOBOX) {   // envs/tmaze.py:27-61, 151-194
+        w.add_rect_room(-1, 8, -2, 2, TEXF_CONCRETE);
+        int r2 = w.add_rect_room(8, 12, -8, 8, TEXF_CONCRETE);
+        const double r2min = rooms[r2].min_z, r2max = rooms[r2].max_z;
+        w.connect_rooms(0, 1, 2, -2, 2, false, 0);
+        // `if self.rand.bool():` (tmaze.py:53) is evaluated before the first place_entity, i.e. before the
+        // texture draws of _gen_static_data (miniworld.py:865-866)
+        const bool random_arm = d.task == MWB_TASK_TMAZE && d.task_args[0] == 0;
+        const bool left_arm = random_arm && w.rng.randint(0, 2) == 0;   // RandGen.bool, random.py:26-31
+        w.gen_static_data(dr, d.S_max);
+        WorldGen::PlaceOpt o;
+        if (d.task == MWB_TASK_TMAZE_TWOBOX) {   // red box at (10, -6), blue box at (10, 6): min == max
+            o.has_min_x = o.has_max_x = o.has_min_z = o.has_max_z = true;
+            o.min_x = o.max_x = 10; o.min_z = o.max_z = -6;
+            w.place_entity_ex(brad, o, box_x, box_z, box_dir);
+            o.min_z = o.max_z = 6;
+            o.n_others = 1; o.other_x[0] = box_x; o.other_z[0] = box_z; o.other_radius = brad;
+            w.place_entity_ex(brad, o, box2_x, box2_z, box2_dir);
+        } else if (d.task_args[0] != 0) {   // goal_pos given (TMazeLeft / Right / Dynamic)
+            double gx = d.task_args[1], gz = d.task_args[2];
+            if (d.task_args[3] > 0) { gx = 10; gz = goal_idx ? 6 : -6; }   // TMazeDynamic.goals, tmaze.py:88
+            o.has_min_x = o.has_max_x = o.has_min_z = o.has_max_z = true;
+            o.min_x = o.max_x = gx; o.min_z = o.max_z = gz;
+            w.place_entity_ex(brad, o, box_x, box_z, box_dir);
+        } else {
+            o.room = r2;
+            if (left_arm) { o.has_max_z = true; o.max_z = r2min + 2; }
+            else { o.has_min_z = true; o.min_z = r2max - 2; }
+            w.place_entity_ex(brad, o, box_x, box_z, box_dir);
+        }
+        WorldGen::PlaceOpt a;
+        a.room = 0; a.has_dir = true;
+        a.dir = w.rng.uniform(-3.141592653589793 / 4, 3.141592653589793 / 4);   // drawn before the placement loop
+        a.n_others = d.n_boxes; a.other_radius = brad;
+        a.other_x[0] = box_x; a.other_z[0] = box_z; a.other_x[1] = box2_x; a.other_z[1] = box2_z;
+        w.place_entity_ex(AGENT_RADIUS, a, ag_x, ag_z, ag_dir);
+    } else if (d.task == MWB_TASK_HALLWAY) {   // envs/hallway.py:25-42
         double length = d.task_args[0];
         int r = w.add_rect_room(-1, -1 + length, -2, 2, TEXF_CONCRETE);
         double rmax = rooms[r].max_x;
@@ -591,6 +685,8 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     sample_param(w.rng, d.params[MWB_P_LIGHT_COLOR], 3, dr, lcol);
     sample_param(w.rng, d.params[MWB_P_LIGHT_AMBIENT], 3, dr, lamb);
     sample_param(w.rng, d.params[MWB_P_OBJ_COLOR_BIAS], 3, dr, bias);
+    double bias2[3] = {0, 0, 0};
+    if (d.n_boxes > 1) sample_param(w.rng, d.params[MWB_P_OBJ_COLOR_BIAS], 3, dr, bias2);   // entities randomize in list order
     sample_param(w.rng, d.params[MWB_P_CAM_HEIGHT], 1, dr, &cam[0]);
     sample_param(w.rng, d.params[MWB_P_CAM_FWD_DISP], 1, dr, &cam[1]);
     sample_param(w.rng, d.params[MWB_P_CAM_PITCH], 1, dr, &cam[2]);
@@ -610,6 +706,16 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             d.sky_color[e * 3 + k] = sky[k]; d.light_pos[e * 3 + k] = lpos[k];
             d.light_color[e * 3 + k] = lcol[k]; d.light_ambient[e * 3 + k] = lamb[k];
         }
+        if (d.n_boxes > 1) {   // the blue box, second plane of the box arrays
+            const size_t N = (size_t)d.N;
+            d.box_x[N + e] = box2_x; d.box_z[N + e] = box2_z; d.box_dir[N + e] = box2_dir;
+            const double blue[3] = {0.0, 0.0, 1.0};
+            for (int k = 0; k < 3; k++) {
+                double v = blue[k] + bias2[k];
+                d.box_color[(N + e) * 3 + k] = v < 0 ? 0 : (v > 1 ? 1 : v);
+            }
+        }
+        d.goal_idx[e] = goal_idx; d.episode_count[e] = episode_count;
         for (int k = 0; k < 4; k++) d.cam[e * 4 + k] = cam[k];
         d.step_count[e] = 0;
         d.n_rooms[e] = w.fail ? -1 : w.n_rooms;
@@ -708,10 +814,9 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     // light: GL_POSITION = (light_pos + 1, w = 0) -> directional
     double lp[3] = {d.light_pos[e * 3] + 1, d.light_pos[e * 3 + 1] + 1, d.light_pos[e * 3 + 2] + 1};
     double ll = sqrt(lp[0] * lp[0] + lp[1] * lp[1] + lp[2] * lp[2]);
-    float L[3], amb[3], dif[3], bcol[3];
+    float L[3], amb[3], dif[3];
     for (int k = 0; k < 3; k++) {
         L[k] = (float)(lp[k] / ll); amb[k] = (float)d.light_ambient[e * 3 + k]; dif[k] = (float)d.light_color[e * 3 + k];
-        bcol[k] = (float)d.box_color[e * 3 + k];
         fc[FC_SKY + k] = (float)d.sky_color[e * 3 + k];
     }
     const float white[3] = {1, 1, 1};
@@ -721,12 +826,17 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     lit_color(L, amb, dif, 0, 0, 1, white, fc + FC_LIT_WALL + 3);
     lit_color(L, amb, dif, 1, 0, 0, white, fc + FC_LIT_WALL + 6);
     lit_color(L, amb, dif, 0, 0, -1, white, fc + FC_LIT_WALL + 9);
-    double bdir = d.box_dir[e];
+    for (int bi = 0; bi < d.n_boxes; bi++) {   // one block of FC_BOX_STRIDE words per box
+    const size_t be = (size_t)bi * d.N + e;
+    fc = d.frame + (size_t)e * MWB_FRAME_WORDS + bi * FC_BOX_STRIDE;
+    float bcol[3];
+    for (int k = 0; k < 3; k++) bcol[k] = (float)d.box_color[be * 3 + k];
+    double bdir = d.box_dir[be];
     float bc = (float)cos(bdir), bs = (float)sin(bdir);
     const float ln[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
     for (int k = 0; k < 6; k++)   // world normal = R_y(dir) n_local (glRotatef about +Y)
         lit_color(L, amb, dif, ln[k][0] * bc + ln[k][2] * bs, ln[k][1], -ln[k][0] * bs + ln[k][2] * bc, bcol, fc + FC_LIT_BOX + 3 * k);
-    float bpos[3] = {(float)d.box_x[e], 0.0f, (float)d.box_z[e]};
+    float bpos[3] = {(float)d.box_x[be], 0.0f, (float)d.box_z[be]};
     float hx = (float)(0.8 / 2), hz = (float)(0.8 / 2), sy = (float)0.8;
     fc[FC_BOX_POS] = bpos[0]; fc[FC_BOX_POS + 1] = bpos[1]; fc[FC_BOX_POS + 2] = bpos[2];
     fc[FC_BOX_C] = bc; fc[FC_BOX_S] = bs; fc[FC_BOX_HX] = hx; fc[FC_BOX_HZ] = hz; fc[FC_BOX_SY] = sy;
@@ -744,6 +854,7 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     float rho = 1.5f * 2.0f * sqrtf(tw * tw + thh * thh);
     float Rp = R + rho * (sqrtf(oc2) + R);
     fc[FC_CULL_CC_PIXEL] = oc2 - Rp * Rp;
+    }   // boxes
 }
 
 __global__ void __launch_bounds__(256) prep_kernel(MwbDev d, int mode) {
@@ -939,6 +1050,7 @@ __device__ __forceinline__ bool plane_texcoord(int axis, float plane, float u_or
 }
 #pragma clang fp contract(off)
 
+template <int NBOX>
 struct RenderCtx {
     const float *rooms, *fc;
     const TexLds *tex;
@@ -947,7 +1059,7 @@ struct RenderCtx {
     float *depth;   // this env's depth map or null
     Cam cam;
     int n_rooms, cam_room, W, H, layout;
-    float cull_cc, cull_oc[3], zA, zB;
+    float cull_cc[NBOX], cull_oc[NBOX][3], zA, zB;
 
     // rays through the +1 pixel neighbours (for the LOD differences): the ray is affine in the window
     // coordinates, so they are the centre ray plus a per-frame constant (shading-only, tolerance-bound)
@@ -960,8 +1072,8 @@ struct RenderCtx {
     __device__ __forceinline__ void shade(uint32_t key, int first_k, float cx, float cy, float *col) const {
         const uint32_t kind = key & 7u, side = (key >> 3) & 7u;
         if (kind == KIND_SKY) { col[0] = fc[FC_SKY]; col[1] = fc[FC_SKY + 1]; col[2] = fc[FC_SKY + 2]; return; }
-        if (kind == KIND_BOX) {
-            const float *lb = fc + FC_LIT_BOX + 3 * side;
+        if (kind == KIND_BOX) {   // the key's room field holds the box index
+            const float *lb = fc + FC_LIT_BOX + 3 * side + (NBOX > 1 ? (key >> 6) * FC_BOX_STRIDE : 0u);
             col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2];
             return;
         }
@@ -1052,13 +1164,17 @@ struct RenderCtx {
             uint32_t path;
             make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
             uint32_t key = trace_rooms<false>(rooms, n_rooms, cam_room, cam.eye, dv, th, path);
-            // conservative bounding-sphere cull, then the exact slab test
-            const float b = dv[0] * cull_oc[0] + dv[1] * cull_oc[1] + dv[2] * cull_oc[2];
+            // conservative bounding-sphere cull, then the exact slab test; boxes in entity order, a later
+            // box wins only when strictly nearer
             const float dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
-            if (cull_cc <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc)) {
-                float tb;
-                int face = trace_box(fc, dv, tb);
-                if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, 0); th = tb; }
+#pragma unroll
+            for (int bi = 0; bi < NBOX; bi++) {
+                const float b = dv[0] * cull_oc[bi][0] + dv[1] * cull_oc[bi][1] + dv[2] * cull_oc[bi][2];
+                if (cull_cc[bi] <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc[bi])) {
+                    float tb;
+                    int face = trace_box(fc + bi * FC_BOX_STRIDE, dv, tb);
+                    if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, bi); th = tb; }
+                }
             }
             if (k == 0) { key_s0 = key; t_s0 = th; }
             const bool h0 = (meta & 0xFu) && key == k0, h1 = (meta & 0xF0u) && key == k1;
@@ -1120,7 +1236,7 @@ struct RenderCtx {
 #define QUEUE_CAP 128
 
 // Renders one env with the whole workgroup (called once per workgroup, or per list entry on the side stream).
-template <int THREADS>
+template <int THREADS, int NBOX>
 __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigned char *smem) {
     const int tid = threadIdx.x;
     const int W = d.W, H = d.H;
@@ -1148,7 +1264,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
         if (tid == 0) *cam_room_s = 0x7fffffff;
     }
     __syncthreads();
-    RenderCtx ctx;
+    RenderCtx<NBOX> ctx;
     ctx.rooms = rooms; ctx.fc = fc; ctx.tex = tex; ctx.texels = d.texels; ctx.fb = fb;
     ctx.depth = d.want_depth ? d.depth + (size_t)e * W * H : nullptr;
     ctx.n_rooms = n_rooms; ctx.W = W; ctx.H = H; ctx.layout = d.layout;
@@ -1170,9 +1286,14 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
     if (ctx.cam_room == 0x7fffffff) ctx.cam_room = -1;
     const float zn = 0.04f, zf = 100.0f;   // gluPerspective near / far, miniworld.py:1186-1187
     ctx.zA = (zf + zn) / (zf - zn); ctx.zB = (2.0f * zf * zn) / (zf - zn);
-    ctx.cull_cc = uni(fc[FC_CULL_CC]);
-    ctx.cull_oc[0] = uni(fc[FC_CULL_OC]); ctx.cull_oc[1] = uni(fc[FC_CULL_OC + 1]); ctx.cull_oc[2] = uni(fc[FC_CULL_OC + 2]);
-    const float cull_cc_px = uni(fc[FC_CULL_CC_PIXEL]);   // sphere inflated by a pixel footprint (prep_kernel)
+    float cull_cc_px[NBOX];   // sphere inflated by a pixel footprint (prep_kernel)
+#pragma unroll
+    for (int bi = 0; bi < NBOX; bi++) {
+        const float *fb_ = fc + bi * FC_BOX_STRIDE;
+        ctx.cull_cc[bi] = uni(fb_[FC_CULL_CC]);
+        ctx.cull_oc[bi][0] = uni(fb_[FC_CULL_OC]); ctx.cull_oc[bi][1] = uni(fb_[FC_CULL_OC + 1]); ctx.cull_oc[bi][2] = uni(fb_[FC_CULL_OC + 2]);
+        cull_cc_px[bi] = uni(fb_[FC_CULL_CC_PIXEL]);
+    }
 
     // Pass structure per wave: a 16 x 4 grid of rays through PIXEL CORNERS per pass, marching down a
     // 15-pixel-wide strip; the last corner row of a pass is carried in registers, so a pass classifies
@@ -1219,12 +1340,15 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
             const bool is_pixel = ci < TILE_CX - 1 && px < W && py >= row0 && py < row0 + rows && !(p == 0 && cj == 0);
             bool interior = !(d.debug_flags & 1) && is_pixel && ok && key == k_br && key == k_tl && key == k_tr &&
                             path == p_br && path == p_tl && path == p_tr;
-            if (interior) {   // may the box intrude?  centre ray against the footprint-inflated bounding sphere
+            if (interior) {   // may a box intrude?  centre ray against the footprint-inflated bounding spheres
                 float dc[3];
                 make_ray(cam, (float)px + 0.5f, (float)(H - 1 - py) + 0.5f, dc);
-                const float b = dc[0] * ctx.cull_oc[0] + dc[1] * ctx.cull_oc[1] + dc[2] * ctx.cull_oc[2];
                 const float dd = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
-                if (cull_cc_px <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc_px)) interior = false;
+#pragma unroll
+                for (int bi = 0; bi < NBOX; bi++) {
+                    const float b = dc[0] * ctx.cull_oc[bi][0] + dc[1] * ctx.cull_oc[bi][1] + dc[2] * ctx.cull_oc[bi][2];
+                    if (cull_cc_px[bi] <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc_px[bi])) interior = false;
+                }
             }
             const bool edge = is_pixel && !interior;
             const unsigned long long em = __ballot(edge);
@@ -1273,19 +1397,19 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
 // MODE 0: every env; 1: only the envs regenerated this step (side stream, through the compact list);
 // 2: all the others (bulk).  A template parameter so that the three launches carry distinct kernel names
 // in profiles.
-template <int THREADS, int MODE>
+template <int THREADS, int MODE, int NBOX>
 __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (MODE == 1) {
         const int count = d.reset_count[0];
         for (int li = blockIdx.x; li < count; li += gridDim.x) {
-            render_env<THREADS>(d, d.reset_list[li], smem);
+            render_env<THREADS, NBOX>(d, d.reset_list[li], smem);
             __syncthreads();   // LDS is reused by the next env of this block
         }
     } else {
         const int e = blockIdx.x;
         if (MODE == 2 && d.reset_set[e]) return;   // block-uniform
-        render_env<THREADS>(d, e, smem);
+        render_env<THREADS, NBOX>(d, e, smem);
     }
 }
 
@@ -1339,9 +1463,9 @@ __global__ void intersect_kernel(MwbDev d, int e, double x, double z, double rad
         for (int c = 0; c < 4; c++) q[c] = d.segs[(size_t)(i * 4 + c) * d.N + e];
         if (seg_hit(q, x, z, radius)) res = 1;
     }
-    if (!res) {
-        double ddx = d.box_x[e] - x, ddz = d.box_z[e] - z;
-        if (sqrt(ddx * ddx + 0.0 + ddz * ddz) < radius + box_radius()) res = 2;
+    for (int b = 0; b < d.n_boxes && !res; b++) {
+        double ddx = d.box_x[(size_t)b * d.N + e] - x, ddz = d.box_z[(size_t)b * d.N + e] - z;
+        if (sqrt(ddx * ddx + 0.0 + ddz * ddz) < radius + box_radius()) res = 2 + b;
     }
     *result = res;
 }
@@ -1373,10 +1497,10 @@ int mwb_prepare_kernels(const MwbDev &d) {
     size_t r = mwb_reset_lds_bytes(d), q = mwb_render_lds_bytes(d);
     if (r > 160 * 1024 || q > 160 * 1024) return -1;
     if (r > 64 * 1024 && hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r) != hipSuccess) return -2;
-    if (q > 64 * 1024) {
-        if (hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess ||
-            hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess ||
-            hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess)
+    if (q > 64 * 1024) {   // only Maze worlds get this large, and they have one box
+        if (hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess ||
+            hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess ||
+            hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess)
             return -2;
     }
     return 0;
@@ -1393,9 +1517,16 @@ void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s) {
 void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
     const dim3 g(d.N), b(RENDER_THREADS);
     const size_t lds = mwb_render_lds_bytes(d);
-    if (mode == 1) render_kernel<RENDER_THREADS, 1><<<dim3(d.N < LIST_GRID ? d.N : LIST_GRID), b, lds, s>>>(d);
-    else if (mode == 2) render_kernel<RENDER_THREADS, 2><<<g, b, lds, s>>>(d);
-    else render_kernel<RENDER_THREADS, 0><<<g, b, lds, s>>>(d);
+    const dim3 gl(d.N < LIST_GRID ? d.N : LIST_GRID);
+    if (d.n_boxes == 2) {   // the two-box T-maze: its own instantiation, so that the one-box kernels stay as they are
+        if (mode == 1) render_kernel<RENDER_THREADS, 1, 2><<<gl, b, lds, s>>>(d);
+        else if (mode == 2) render_kernel<RENDER_THREADS, 2, 2><<<g, b, lds, s>>>(d);
+        else render_kernel<RENDER_THREADS, 0, 2><<<g, b, lds, s>>>(d);
+        return;
+    }
+    if (mode == 1) render_kernel<RENDER_THREADS, 1, 1><<<gl, b, lds, s>>>(d);
+    else if (mode == 2) render_kernel<RENDER_THREADS, 2, 1><<<g, b, lds, s>>>(d);
+    else render_kernel<RENDER_THREADS, 0, 1><<<g, b, lds, s>>>(d);
 }
 void mwb_launch_intersect(const MwbDev &d, int env, double x, double z, double radius, int *result_dev, hipStream_t s) {
     hipLaunchKernelGGL(intersect_kernel, dim3(1), dim3(64), 0, s, d, env, x, z, radius, result_dev);

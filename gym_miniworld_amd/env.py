@@ -54,6 +54,11 @@ class MiniWorldEnv:
         self.params = self._b.params
         self.agent, self.box = _Ent(0.4, 1.6), _Ent(float(np.sqrt(0.8 * 0.8 + 0.8 * 0.8) / 2), 0.8)
         self.entities = [self.box, self.agent]
+        if self._b.n_boxes == 2:   # the two-box T-maze, tmaze.py:166-169
+            self.red_box, self.blue_box = self.box, _Ent(self.box.radius, 0.8)
+            self.boxes = [self.red_box, self.blue_box]
+            self.entities = [self.red_box, self.blue_box, self.agent]
+            self.goal_box_idx, self.penalty_box_idx = 0, 1
         self.rooms, self.step_count = [], 0
         self._seeded = False
         if seed is not None:
@@ -71,6 +76,11 @@ class MiniWorldEnv:
         self.agent.pos, self.agent.dir = st["agent_pos"][0].copy(), float(st["agent_dir"][0])
         self.box.pos, self.box.dir = st["box_pos"][0].copy(), float(st["box_dir"][0])
         self.box.color_vec = st["box_color"][0].copy()
+        if self._b.n_boxes == 2:
+            self.blue_box.pos, self.blue_box.dir = st["box2_pos"][0].copy(), float(st["box2_dir"][0])
+            self.blue_box.color_vec = st["box2_color"][0].copy()
+            self.goal_box_idx = int(st["goal_idx"][0])
+            self.penalty_box_idx = 1 - self.goal_box_idx
         (self.agent.cam_height, self.agent.cam_fwd_disp, self.agent.cam_pitch, self.agent.cam_fov_y) = st["cam"][0]
         self.sky_color, self.light_pos = st["sky_color"][0], st["light_pos"][0]
         self.light_color, self.light_ambient = st["light_color"][0], st["light_ambient"][0]
@@ -91,7 +101,12 @@ class MiniWorldEnv:
         obs = self._b.obs.cpu().numpy()[0]
         reward, done = float(self._b.reward64.cpu()[0]), bool(self._b.done.cpu()[0])
         self._sync()
-        return obs, reward, done, {}
+        info = {}
+        if self._b.has_goal_pos:   # tmaze.py:66,206
+            info["goal_pos"] = self._b.goal_pos.cpu().numpy()[0].copy()
+        if self._b.has_features:   # tmaze.py:311-318
+            info["feature"] = self._b.feature.cpu().numpy()[0].astype(np.float64)
+        return obs, reward, done, info
 
     def render_obs(self):
         return self._b.render().cpu().numpy()[0]
@@ -107,6 +122,8 @@ class MiniWorldEnv:
             return True
         if r == 2 and ent is not self.box:
             return self.box
+        if r == 3 and ent is not self.blue_box:
+            return self.blue_box
         return None
 
     def near(self, ent0, ent1=None):   # miniworld.py:961-971

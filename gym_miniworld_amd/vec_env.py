@@ -137,8 +137,23 @@ class MiniWorldVecEnv(VecEnv):
             rews = b.reward.cpu().unsqueeze(1)       # CPU FloatTensor [N,1], envs.py:129
         else:
             rews = b.reward64.cpu().numpy()
-        if self._skip is not None:
-            sk = self._skip.cpu().numpy()
+        sk = self._skip.cpu().numpy() if self._skip is not None else None
+        if b.has_goal_pos:   # the T-maze family: info['goal_pos'] (tmaze.py:66,206) and, where produced, info['feature']
+            gp = b.goal_pos.cpu().numpy()
+            ft = b.feature.cpu().numpy().astype(np.float64) if b.has_features else None
+            infos = []
+            for i in range(self.num_envs):
+                if sk is not None and sk[i]:
+                    infos.append(_DUMMY_INFO)
+                    continue
+                info = {"goal_pos": gp[i].copy()}
+                if ft is not None:
+                    info["feature"] = ft[i].copy()
+                elif self.feature_info:
+                    info["feature"] = _DUMMY_INFO["feature"]
+                infos.append(info)
+            infos = tuple(infos)
+        elif sk is not None:
             infos = tuple(_DUMMY_INFO if sk[i] else self._infos_plain[i] for i in range(self.num_envs))
         else:
             infos = self._infos_plain

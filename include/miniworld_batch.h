@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MWB_ABI_VERSION 1
+#define MWB_ABI_VERSION 2
 
 enum { MWB_OK = 0, MWB_EINVAL = -1, MWB_EHIP = -2, MWB_ENOMEM = -3, MWB_ESTATE = -4 };
 
@@ -29,7 +29,19 @@ enum { MWB_OK = 0, MWB_EINVAL = -1, MWB_EHIP = -2, MWB_ENOMEM = -3, MWB_ESTATE =
 enum { MWB_TASK_HALLWAY = 0,   /* envs/hallway.py   task_args = {length}                    */
        MWB_TASK_ONEROOM = 1,   /* envs/oneroom.py   task_args = {size}                      */
        MWB_TASK_FOURROOMS = 2, /* envs/fourrooms.py task_args = {}                          */
-       MWB_TASK_MAZE = 3 };    /* envs/maze.py      task_args = {num_rows,num_cols,room_size} */
+       MWB_TASK_MAZE = 3,      /* envs/maze.py      task_args = {num_rows,num_cols,room_size} */
+       /* the T-maze family, envs/tmaze.py:
+        * TMaze (7-74: goal_pos None -> random arm), TMazeLeft / TMazeRight (69-75: goal_pos given),
+        * TMazeDynamic (77-106: the goal alternates between (10,0,-6) and (10,0,6) every sub_task_length-th
+        * reset).  task_args = {goal_pos given (0/1), goal x, goal z, sub_task_length (> 0: TMazeDynamic)} */
+       MWB_TASK_TMAZE = 4,
+       /* TMazeTwoBoxDynamic (108-217) and its *Features* copies (220-650): a red box at (10,0,-6), a blue box
+        * at (10,0,6); reaching the goal box ends the episode with +_reward(), the other with -_reward(), and
+        * goal / penalty swap by the class' rule.  task_args = {rule, -, -, sub_task_length}: rule 0 = every
+        * sub_task_length-th reset (TMazeTwoBoxDynamic.reset 210-217); rule 1 = at every reset once more than
+        * sub_task_length steps have been taken - the counter is never cleared, as in the reference - and
+        * info['feature'] = [near(blue), near(red)] is produced (*Features*.step 299-320, reset 322-330) */
+       MWB_TASK_TMAZE_TWOBOX = 5 };
 
 /* observation layouts */
 enum { MWB_LAYOUT_HWC = 0,  /* [N,H,W,3]  MiniWorldEnv.observation_space, miniworld.py:473-478 */
@@ -73,6 +85,8 @@ typedef struct mwb_outputs {
     size_t obs_bytes, depth_bytes;
     void *stack;        /* frame stack [N, nstack*3, W, H], f32 or u8 (mwb_stack_enable), or NULL              */
     size_t stack_bytes;
+    float *feature;     /* f32 [N][2] info['feature'] of the transition (tmaze.py:311-318); zeros for other tasks */
+    double *goal_pos;   /* f64 [N][3] info['goal_pos'] of the transition, T-maze family (tmaze.py:66,206); else zeros */
 } mwb_outputs;
 
 /* host-side snapshot of the simulator state of a contiguous env range, for tests / debugging;
@@ -90,6 +104,13 @@ typedef struct mwb_state {
     uint32_t *rng_keysum;   /* [count] sum of the 624 key words mod 2^32 */
     int32_t *n_rooms;       /* [count] */
     int32_t *n_segs;        /* [count] */
+    /* T-maze family (NULL-able like the rest; zeros for the other tasks) */
+    double *box2_pos;       /* [count][3] the blue box of the two-box tasks (tmaze.py:168) */
+    double *box2_dir;       /* [count]    */
+    double *box2_color;     /* [count][3] */
+    int32_t *goal_idx;      /* [count] current_goal (tmaze.py:91) / goal_box_idx (tmaze.py:135) */
+    int64_t *episode_count; /* [count] tmaze.py:80,130 (1 after construction: MiniWorldEnv.__init__ resets once) */
+    int64_t *task_step_count; /* [count] tmaze.py:240 */
 } mwb_state;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
@@ -147,8 +168,11 @@ int mwb_get_state(mwb_handle *h, int first_env, int count, mwb_state *out);     
 /* overwrite pose / step counter of env range (NULL = leave); used to inject oracle states */
 int mwb_set_agent(mwb_handle *h, int first_env, int count, const double *pos_xz, const double *dir,
                   const int32_t *step_count);
+/* overwrite the goal-alternation state of the T-maze family for an env range (NULL = leave); test hook */
+int mwb_set_task_state(mwb_handle *h, int first_env, int count, const int64_t *episode_count,
+                       const int64_t *task_step_count, const int32_t *goal_idx);
 /* replaces: MiniWorldEnv.intersect(agent, pos, radius) (miniworld.py:933-959) for one env; result
- * 0 none, 1 wall, 2 box. Synchronous. */
+ * 0 none, 1 wall, 2 box (the red one), 3 the blue box. Synchronous. */
 int mwb_intersect(mwb_handle *h, int env, double x, double z, double radius, int *result);
 /* geometry of one env as the kernels see it: n_rooms x MWB_ROOM_WORDS f32 words and n_segs x 4 f64 */
 #define MWB_ROOM_WORDS 24
