@@ -26,9 +26,13 @@ WORKLOADS = {
     "oneroom4096": ("MiniWorld-OneRoom-v0", 4096, False, False, 14700),       # configs[1]
     "maze8192_depth": ("MiniWorld-Maze-v0", 8192, True, False, 44800),        # configs[2]
     "fourrooms16384_dr": ("MiniWorld-FourRooms-v0", 16384, False, True, 16100),   # configs[3]
+    # the two-box T-maze with info['feature'] the fork's trainer uses;
+    # 14 400 B obs + ~0.2 KB state + 2 rooms x 96 B + 416 B frame constants
+    "tmaze_features8192": ("MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0", 8192, False, False, 15200),
 }
 ORACLE_TASK = {"MiniWorld-Maze-v0": ("Maze", None), "MiniWorld-OneRoom-v0": ("OneRoom", None),
-               "MiniWorld-FourRooms-v0": ("FourRooms", None), "MiniWorld-Hallway-v0": ("Hallway", None)}
+               "MiniWorld-FourRooms-v0": ("FourRooms", None), "MiniWorld-Hallway-v0": ("Hallway", None),
+               "MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0": ("TMazeTwoBox", [1, 0, 0, 100000])}
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ACTION_SEED = 12345
 
