@@ -1167,13 +1167,27 @@ struct RenderCtx {
             // conservative bounding-sphere cull, then the exact slab test; boxes in entity order, a later
             // box wins only when strictly nearer
             const float dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+            if (NBOX == 1) {   // cull constants pinned to scalar registers
 #pragma unroll
-            for (int bi = 0; bi < NBOX; bi++) {
-                const float b = dv[0] * cull_oc[bi][0] + dv[1] * cull_oc[bi][1] + dv[2] * cull_oc[bi][2];
-                if (cull_cc[bi] <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc[bi])) {
-                    float tb;
-                    int face = trace_box(fc + bi * FC_BOX_STRIDE, dv, tb);
-                    if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, bi); th = tb; }
+                for (int bi = 0; bi < NBOX; bi++) {
+                    const float b = dv[0] * cull_oc[bi][0] + dv[1] * cull_oc[bi][1] + dv[2] * cull_oc[bi][2];
+                    if (cull_cc[bi] <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc[bi])) {
+                        float tb;
+                        int face = trace_box(fc + bi * FC_BOX_STRIDE, dv, tb);
+                        if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, bi); th = tb; }
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int bi = 0; bi < NBOX; bi++) {   // a real loop: one copy of the slab test, constants from LDS
+                    const float *fb_ = fc + bi * FC_BOX_STRIDE;
+                    const float cc = fb_[FC_CULL_CC];
+                    const float b = dv[0] * fb_[FC_CULL_OC] + dv[1] * fb_[FC_CULL_OC + 1] + dv[2] * fb_[FC_CULL_OC + 2];
+                    if (cc <= 0.0f || (b > 0.0f && b * b >= dd * cc)) {
+                        float tb;
+                        int face = trace_box(fb_, dv, tb);
+                        if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, bi); th = tb; }
+                    }
                 }
             }
             if (k == 0) { key_s0 = key; t_s0 = th; }
@@ -1294,6 +1308,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
         ctx.cull_oc[bi][0] = uni(fb_[FC_CULL_OC]); ctx.cull_oc[bi][1] = uni(fb_[FC_CULL_OC + 1]); ctx.cull_oc[bi][2] = uni(fb_[FC_CULL_OC + 2]);
         cull_cc_px[bi] = uni(fb_[FC_CULL_CC_PIXEL]);
     }
+    (void)cull_cc_px;
 
     // Pass structure per wave: a 16 x 4 grid of rays through PIXEL CORNERS per pass, marching down a
     // 15-pixel-wide strip; the last corner row of a pass is carried in registers, so a pass classifies

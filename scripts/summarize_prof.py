@@ -40,10 +40,12 @@ def counters(sub):
 
 summary = {"workload": workload, "fetch": counters("pmc_fetch"), "write": counters("pmc_write"), "sq": counters("pmc_sq")}
 def pick_render(keys):
+    import re
     ks = [k for k in keys if "render_kernel" in k]
-    for want in (", 2>", ", 0>"):   # the bulk launch (mode 2) if the run overlapped reset, else mode 0
-        for k in ks:
-            if want in k:
+    for want in ("2", "0"):   # the bulk launch (MODE 2) if the run overlapped reset, else MODE 0
+        for k in ks:   # render_kernel<THREADS, MODE[, NBOX]>
+            m = re.search(r"render_kernel<\s*\d+\s*,\s*(\d+)", k)
+            if m and m.group(1) == want:
                 return k
     return ks[0] if ks else None
 rk = pick_render(summary["fetch"])
