@@ -914,7 +914,7 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
     const int sx = xpos ? 0 : 2, sz = zpos ? 3 : 1;
     int steps = 0;
     for (int iter = 0; iter <= n_rooms; iter++) {
-        const float *r = rooms + room * MWB_ROOM_WORDS;
+        const float *r = rooms + __umul24((uint32_t)room, MWB_ROOM_WORDS);
         const float4 rect = *(const float4 *)(r + RW_MINX);   // min_x max_x min_z max_z
         const float height = r[RW_HEIGHT];
         const float4 portx = *(const float4 *)(r + RW_SIDE0 + RW_SIDE_WORDS * sx);   // lo hi max_y u_org
@@ -992,8 +992,13 @@ __device__ __forceinline__ void bilinear(const uint32_t *__restrict__ texels, ui
     // s,t in [0,1): i0 in [-1, w-1]; wrap with compares instead of integer division
     int i1 = i0 + 1; if (i1 >= w) i1 -= w; if (i0 < 0) i0 += w;
     int j1 = j0 + 1; if (j1 >= h) j1 -= h; if (j0 < 0) j0 += h;
-    const uint32_t *row0 = texels + off + j0 * w, *row1 = texels + off + j1 * w;
-    uint32_t t00 = row0[i0], t10 = row0[i1], t01 = row1[i0], t11 = row1[i1];
+    // unsigned 32-bit texel indices (24-bit multiplies: levels are at most 1024 wide) keep the address math
+    // out of 64-bit VALU arithmetic: the loads use the scalar base + 32-bit offset form
+    // (the pyramids total ~14 MB, so byte offsets fit 32 bits)
+    const uint32_t r0 = off + __umul24((uint32_t)j0, (uint32_t)w), r1 = off + __umul24((uint32_t)j1, (uint32_t)w);
+    const char *tb = (const char *)texels;
+    auto texel = [tb](uint32_t idx) { return *(const uint32_t *)(tb + (size_t)(idx << 2)); };
+    uint32_t t00 = texel(r0 + (uint32_t)i0), t10 = texel(r0 + (uint32_t)i1), t01 = texel(r1 + (uint32_t)i0), t11 = texel(r1 + (uint32_t)i1);
     float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -1077,7 +1082,7 @@ struct RenderCtx {
             col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2];
             return;
         }
-        const float *r = rooms + (key >> 6) * MWB_ROOM_WORDS;
+        const float *r = rooms + __umul24(key >> 6, MWB_ROOM_WORDS);
         const uint32_t texw = (uint32_t)__float_as_int(r[RW_TEX]);
         const int tex_id = kind == KIND_FLOOR ? (texw >> 8) & 255u : kind == KIND_CEIL ? (texw >> 16) & 255u : texw & 255u;
         const TexLds &T = tex[tex_id];
@@ -1231,7 +1236,7 @@ struct RenderCtx {
             float dv[3];
             make_ray(cam, cx + c_sample_x[0], cy + c_sample_y[0], dv);
             const uint32_t kind = key & 7u, side = (key >> 3) & 7u;
-            const float *r = rooms + (key >> 6) * MWB_ROOM_WORDS;
+            const float *r = rooms + __umul24(key >> 6, MWB_ROOM_WORDS);
             const float4 rect = *(const float4 *)(r + RW_MINX);
             const bool wall = kind == KIND_WALL;
             const bool is_x = wall && (side == 0u || side == 2u), is_z = wall && (side == 1u || side == 3u);
@@ -1319,6 +1324,9 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
     // by the full 8-sample path.  Both kinds go through per-wave LDS queues and are processed 64 at a
     // time, so that the shading and the 8-sample path always run with dense lanes.
     const int wave = tid / WAVE, lane = tid % WAVE, n_waves = THREADS / WAVE;
+    // queued pixels are packed as (py << wshift) | px (host checks that it fits 16 bits): no integer division
+    const int wshift = 32 - __builtin_clz((unsigned)(W > 1 ? W - 1 : 1));
+    const int wmask = (1 << wshift) - 1;
     uint16_t *queue = queues + wave * QUEUE_CAP;
     uint32_t *iq_key = ikeys + wave * QUEUE_CAP;
     uint16_t *iq_pix = ipix + wave * QUEUE_CAP;
@@ -1367,33 +1375,33 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
             }
             const bool edge = is_pixel && !interior;
             const unsigned long long em = __ballot(edge);
-            if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)(py * W + px);
+            if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)((py << wshift) | px);
             q_count += __popcll(em);
             const unsigned long long im = __ballot(interior);
             if (interior) {
                 const int slot = iq_count + __popcll(im & ((1ull << lane) - 1ull));
-                iq_key[slot] = key & 0x0FFFFFFFu; iq_pix[slot] = (uint16_t)(py * W + px);
+                iq_key[slot] = key & 0x0FFFFFFFu; iq_pix[slot] = (uint16_t)((py << wshift) | px);
             }
             iq_count += __popcll(im);
             if (iq_count >= WAVE) {
                 iq_count -= WAVE;
                 const int q = iq_pix[iq_count + lane];
-                if (!(d.debug_flags & 4)) ctx.pixel_interior(q % W, q / W, iq_key[iq_count + lane]);
+                if (!(d.debug_flags & 4)) ctx.pixel_interior(q & wmask, q >> wshift, iq_key[iq_count + lane]);
             }
             if (q_count >= WAVE) {
                 q_count -= WAVE;
                 const int q = queue[q_count + lane];
-                if (!(d.debug_flags & 2)) ctx.pixel_full(q % W, q / W);
+                if (!(d.debug_flags & 2)) ctx.pixel_full(q & wmask, q >> wshift);
             }
         }
     }
     if (lane < iq_count && !(d.debug_flags & 4)) {
         const int p = iq_pix[lane];
-        ctx.pixel_interior(p % W, p / W, iq_key[lane]);
+        ctx.pixel_interior(p & wmask, p >> wshift, iq_key[lane]);
     }
     if (lane < q_count && !(d.debug_flags & 2)) {
         const int q = queue[lane];
-        ctx.pixel_full(q % W, q / W);
+        ctx.pixel_full(q & wmask, q >> wshift);
     }
     __syncthreads();
     {   // framebuffer LDS -> HBM, 16 bytes per lane
@@ -1511,6 +1519,11 @@ int mwb_prepare_kernels(const MwbDev &d) {
     // opt in to more than the default 64 KB of dynamic LDS where a large world needs it (160 KB per CU)
     size_t r = mwb_reset_lds_bytes(d), q = mwb_render_lds_bytes(d);
     if (r > 160 * 1024 || q > 160 * 1024) return -1;
+    {   // the render kernel's pixel queues hold (py << ceil(log2 W)) | px in 16 bits
+        int wshift = 0;
+        while ((1 << wshift) < d.W) wshift++;
+        if (((size_t)d.H << wshift) > 65536) return -1;
+    }
     if (r > 64 * 1024 && hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r) != hipSuccess) return -2;
     if (q > 64 * 1024) {   // only Maze worlds get this large, and they have one box
         if (hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess ||
