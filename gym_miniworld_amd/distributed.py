@@ -87,18 +87,23 @@ class ObsGatherer:
         torch, dist = self.torch, self.dist
         times = {}
         for m in ("ring", "direct"):
-            self._wait(self._start(0, m))   # warm up (connection set-up)
-            if self.is_cuda:
-                torch.cuda.synchronize()
-            dist.barrier(group=self.group)
-            t0 = time.perf_counter()
-            for _ in range(iters):
-                self._wait(self._start(0, m))
-            if self.is_cuda:
-                torch.cuda.synchronize()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
-                             device=self.staging[0].device if self.is_cuda else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            try:
+                self._wait(self._start(0, m))   # warm up (connection set-up)
+                if self.is_cuda:
+                    torch.cuda.synchronize()
+                dist.barrier(group=self.group)
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    self._wait(self._start(0, m))
+                if self.is_cuda:
+                    torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            except RuntimeError:   # a backend without batched point-to-point support: keep the collective
+                if m == "ring":
+                    raise
+                dt = float("inf")
+            t = torch.tensor([dt], dtype=torch.float64, device=self.staging[0].device if self.is_cuda else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)   # inf on any rank -> every rank keeps the ring
             times[m] = float(t.item()) / iters
         self.tuned = times
         self.method = min(times, key=times.get)
