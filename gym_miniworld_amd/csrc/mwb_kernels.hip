@@ -112,52 +112,73 @@ __device__ __forceinline__ double box_radius() {
     return sqrt(sx * sx + sz * sz) / 2;
 }
 
-__global__ void __launch_bounds__(64) step_kernel(MwbDev d, const int32_t *__restrict__ actions,
-                                                   const uint8_t *__restrict__ skip) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= d.N) return;
-    if (skip && skip[e]) {   // the fork's 'dummy' command, vec_env/subproc_vec_env.py:26-31
-        d.reward[e] = -99.0f; d.reward64[e] = -99.0; d.done[e] = 0; d.ep_steps[e] = d.step_count[e];
-        d.reset_set[e] = 0;
-        d.feature[e * 2] = 0.0f; d.feature[e * 2 + 1] = 0.0f;   // info = {"feature": [0, 0]}
-        return;
-    }
-    int sc = d.step_count[e] + 1;   // miniworld.py:663
-    d.step_count[e] = sc;
-    double fwd_step = d.params[MWB_P_FORWARD_STEP].def[0];
-    double fwd_drift = d.params[MWB_P_FORWARD_DRIFT].def[0];
-    double turn_step = d.params[MWB_P_TURN_STEP].def[0];
-    if (d.domain_rand) {   // miniworld.py:665-668: three draws every step, whatever the action
-        MtSerial g;
-        g.load(d.rng + (size_t)e * MWB_MT_WORDS);
-        fwd_step = g.uniform(d.params[MWB_P_FORWARD_STEP].lo[0], d.params[MWB_P_FORWARD_STEP].hi[0]);
-        fwd_drift = g.uniform(d.params[MWB_P_FORWARD_DRIFT].lo[0], d.params[MWB_P_FORWARD_DRIFT].hi[0]);
-        turn_step = g.uniform(d.params[MWB_P_TURN_STEP].lo[0], d.params[MWB_P_TURN_STEP].hi[0]);
-        g.store();
-    }
-    int a = actions[e];
-    double ax = d.agent_x[e], az = d.agent_z[e], adir = d.agent_dir[e];
+// One block = 64 environments (lane = env, so every SoA access is a coalesced row) x STEP_PARTS waves.
+// Wave 0 carries the sequential part of MiniWorldEnv.step; the circle-vs-segments test of a forward move -
+// the only loop, up to 256 segments in Maze - is split over all waves (wave p takes the 8-segment batches
+// p, p + STEP_PARTS, ...), which turns one long dependent load chain per env into STEP_PARTS short ones.
+#define STEP_PARTS 8
+__global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const int32_t *__restrict__ actions,
+                                                                const uint8_t *__restrict__ skip) {
+    __shared__ double s_nx[64], s_nz[64];
+    __shared__ int s_move[64], s_hit[64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const bool in_range = e < d.N;
+    const bool dummy = in_range && skip && skip[e];   // the fork's 'dummy' command, vec_env/subproc_vec_env.py:26-31
+    const bool live = in_range && !dummy;
+    int sc = 0, a = -1;
+    double ax = 0, az = 0, adir = 0, nx = 0, nz = 0, turn_step = 0;
     const int NB = d.n_boxes;   // 1, or 2 in the two-box T-maze (entity order: red box, blue box, agent)
-    double bx[MWB_MAX_BOXES], bz[MWB_MAX_BOXES];
-    bx[0] = d.box_x[e]; bz[0] = d.box_z[e];
-    bx[1] = NB > 1 ? d.box_x[(size_t)d.N + e] : 0.0; bz[1] = NB > 1 ? d.box_z[(size_t)d.N + e] : 0.0;
-    double brad = box_radius();
-    if (a == 2 || a == 3) {   // move_agent, miniworld.py:608-633
-        double fd = (a == 2) ? fwd_step : -fwd_step;
-        double c = cos(adir), s = sin(adir);
-        // pos + dir_vec*fwd + right_vec*drift with dir_vec=(cos,0,-sin), right_vec=(sin,0,cos)
-        double nx = (ax + c * fd) + s * fwd_drift;
-        double nz = (az + (-s) * fd) + c * fwd_drift;
+    double bx[MWB_MAX_BOXES] = {0, 0}, bz[MWB_MAX_BOXES] = {0, 0};
+    const double brad = box_radius();
+    if (part == 0) {
+        s_move[lane] = 0; s_hit[lane] = 0;
+        if (dummy) {
+            d.reward[e] = -99.0f; d.reward64[e] = -99.0; d.done[e] = 0; d.ep_steps[e] = d.step_count[e];
+            d.reset_set[e] = 0;
+            d.feature[e * 2] = 0.0f; d.feature[e * 2 + 1] = 0.0f;   // info = {"feature": [0, 0]}
+        }
+        if (live) {
+            sc = d.step_count[e] + 1;   // miniworld.py:663
+            d.step_count[e] = sc;
+            double fwd_step = d.params[MWB_P_FORWARD_STEP].def[0];
+            double fwd_drift = d.params[MWB_P_FORWARD_DRIFT].def[0];
+            turn_step = d.params[MWB_P_TURN_STEP].def[0];
+            if (d.domain_rand) {   // miniworld.py:665-668: three draws every step, whatever the action
+                MtSerial g;
+                g.load(d.rng + (size_t)e * MWB_MT_WORDS);
+                fwd_step = g.uniform(d.params[MWB_P_FORWARD_STEP].lo[0], d.params[MWB_P_FORWARD_STEP].hi[0]);
+                fwd_drift = g.uniform(d.params[MWB_P_FORWARD_DRIFT].lo[0], d.params[MWB_P_FORWARD_DRIFT].hi[0]);
+                turn_step = g.uniform(d.params[MWB_P_TURN_STEP].lo[0], d.params[MWB_P_TURN_STEP].hi[0]);
+                g.store();
+            }
+            a = actions[e];
+            ax = d.agent_x[e]; az = d.agent_z[e]; adir = d.agent_dir[e];
+            bx[0] = d.box_x[e]; bz[0] = d.box_z[e];
+            if (NB > 1) { bx[1] = d.box_x[(size_t)d.N + e]; bz[1] = d.box_z[(size_t)d.N + e]; }
+            if (a == 2 || a == 3) {   // move_agent, miniworld.py:608-633
+                double fd = (a == 2) ? fwd_step : -fwd_step;
+                double c = cos(adir), s = sin(adir);
+                // pos + dir_vec*fwd + right_vec*drift with dir_vec=(cos,0,-sin), right_vec=(sin,0,cos)
+                nx = (ax + c * fd) + s * fwd_drift;
+                nz = (az + (-s) * fd) + c * fwd_drift;
+                s_nx[lane] = nx; s_nz[lane] = nz; s_move[lane] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (live && s_move[lane]) {
         // segments are stored transposed (segment-major, env-minor) so that the lanes of a wave - one
         // env each - read consecutive addresses.  No early exit (keeps the loads independent); a
         // segment whose bounding box grown by the radius (+1e-9 guard) excludes the point cannot be
         // within the radius, so skipping it is exact.
+        const double px = s_nx[lane], pz = s_nz[lane];
         const double *sg = d.segs + e;
         const size_t N = (size_t)d.N;
-        int ns = d.n_segs[e];
+        const int ns = d.n_segs[e];
         bool hit = false;
         const double guard = AGENT_RADIUS + 1e-9;
-        for (int i0 = 0; i0 < ns; i0 += 8) {   // 8 segments (32 coalesced loads) in flight, then the tests
+        for (int i0 = part * 8; i0 < ns; i0 += 8 * STEP_PARTS) {   // 8 segments (32 coalesced loads) in flight, then the tests
             double q[8][4];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -167,11 +188,17 @@ __global__ void __launch_bounds__(64) step_kernel(MwbDev d, const int32_t *__res
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                bool nearby = nx >= fmin(q[k][0], q[k][2]) - guard && nx <= fmax(q[k][0], q[k][2]) + guard &&
-                              nz >= fmin(q[k][1], q[k][3]) - guard && nz <= fmax(q[k][1], q[k][3]) + guard;
-                if (nearby) hit = seg_hit(q[k], nx, nz, AGENT_RADIUS) || hit;
+                bool nearby = px >= fmin(q[k][0], q[k][2]) - guard && px <= fmax(q[k][0], q[k][2]) + guard &&
+                              pz >= fmin(q[k][1], q[k][3]) - guard && pz <= fmax(q[k][1], q[k][3]) + guard;
+                if (nearby) hit = seg_hit(q[k], px, pz, AGENT_RADIUS) || hit;
             }
         }
+        if (hit) s_hit[lane] = 1;   // every writer stores the same value
+    }
+    __syncthreads();
+    if (part != 0 || !live) return;
+    if (a == 2 || a == 3) {
+        bool hit = s_hit[lane] != 0;
         for (int b = 0; b < NB && !hit; b++) {   // entity test, miniworld.py:946-957 (boxes are the only other entities)
             double ddx = bx[b] - nx, ddz = bz[b] - nz;
             double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
@@ -1508,7 +1535,7 @@ size_t mwb_render_lds_bytes(const MwbDev &d) {
 }
 
 void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *skip, hipStream_t s) {
-    hipLaunchKernelGGL(step_kernel, dim3((d.N + 63) / 64), dim3(64), 0, s, d, actions, skip);
+    hipLaunchKernelGGL(step_kernel, dim3((d.N + 63) / 64), dim3(64 * STEP_PARTS), 0, s, d, actions, skip);
 }
 __global__ void clear_list_kernel(MwbDev d) { d.reset_count[0] = 0; }
 void mwb_launch_clear_list(const MwbDev &d, hipStream_t s) { hipLaunchKernelGGL(clear_list_kernel, dim3(1), dim3(1), 0, s, d); }
