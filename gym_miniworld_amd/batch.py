@@ -238,6 +238,11 @@ class BatchedMiniWorld:
         ptrs = [None if a is None else a.ctypes.data_as(ctypes.c_void_p) for a in arrs]
         _lib.check(self.L.mwb_set_agent(self.h, first, count, *ptrs))
 
+    def set_domain_rand(self, flag):
+        """`env.domain_rand = flag` of the reference (run_tests.py:64-66); effective from the next reset / step."""
+        _lib.check(self.L.mwb_set_domain_rand(self.h, int(bool(flag))))
+        self.domain_rand = bool(flag)
+
     def set_task_state(self, first, episode_count=None, task_step_count=None, goal_idx=None):
         """Overwrite the goal-alternation state of the T-maze family (test hook, mwb_set_task_state)."""
         arrs = [None if a is None else np.ascontiguousarray(np.atleast_1d(a), dt) for a, dt in

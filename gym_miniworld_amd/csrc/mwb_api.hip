@@ -603,6 +603,15 @@ extern "C" int mwb_set_agent(mwb_handle *h, int first, int count, const double *
     return MWB_OK;
 }
 
+extern "C" int mwb_set_domain_rand(mwb_handle *h, int domain_rand) {
+    if (!h) return set_err(MWB_EINVAL, "mwb_set_domain_rand: null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());   // kernels in flight took the struct by value; order the change after them
+    h->dev.domain_rand = domain_rand ? 1 : 0;
+    h->cfg.domain_rand = h->dev.domain_rand;
+    return MWB_OK;
+}
+
 extern "C" int mwb_set_task_state(mwb_handle *h, int first, int count, const int64_t *episode_count, const int64_t *task_step_count,
                                   const int32_t *goal_idx) {
     if (!h) return set_err(MWB_EINVAL, "mwb_set_task_state: null handle");

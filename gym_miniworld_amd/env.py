@@ -50,7 +50,6 @@ class MiniWorldEnv:
         self.action_space = Discrete(self.actions.move_forward + 1)   # e.g. envs/hallway.py:23
         self.observation_space = Box(0, 255, (obs_height, obs_width, 3), np.uint8)
         self.max_episode_steps = self._b.max_episode_steps
-        self.domain_rand = bool(self._b.domain_rand)
         self.params = self._b.params
         self.agent, self.box = _Ent(0.4, 1.6), _Ent(float(np.sqrt(0.8 * 0.8 + 0.8 * 0.8) / 2), 0.8)
         self.entities = [self.box, self.agent]
@@ -63,6 +62,14 @@ class MiniWorldEnv:
         self._seeded = False
         if seed is not None:
             self.seed(seed)
+
+    @property
+    def domain_rand(self):
+        return bool(self._b.domain_rand)
+
+    @domain_rand.setter
+    def domain_rand(self, flag):   # run_tests.py:64-66 toggles it after construction
+        self._b.set_domain_rand(flag)
 
     def seed(self, seed=None):
         if seed is None:   # the reference seeds from entropy (miniworld.py:522,528-530)

@@ -168,6 +168,10 @@ int mwb_get_state(mwb_handle *h, int first_env, int count, mwb_state *out);     
 /* overwrite pose / step counter of env range (NULL = leave); used to inject oracle states */
 int mwb_set_agent(mwb_handle *h, int first_env, int count, const double *pos_xz, const double *dir,
                   const int32_t *step_count);
+/* replaces: assigning `env.domain_rand = flag` after construction, as the reference's own smoke test does
+ * for every env (run_tests.py:64-66; read at reset miniworld.py:558 and at every step miniworld.py:665);
+ * takes effect from the next mwb_reset / mwb_step. Synchronous. */
+int mwb_set_domain_rand(mwb_handle *h, int domain_rand);
 /* overwrite the goal-alternation state of the T-maze family for an env range (NULL = leave); test hook */
 int mwb_set_task_state(mwb_handle *h, int first_env, int count, const int64_t *episode_count,
                        const int64_t *task_step_count, const int32_t *goal_idx);

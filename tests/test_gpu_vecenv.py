@@ -136,3 +136,49 @@ def test_fused_stack_u8_and_bandwidth_shape():
         su, ru, du, _ = u.step(a)
         assert su.dtype == torch.uint8 and torch.equal(sf, su.float()) and np.array_equal(df, du)
     f.close(); u.close()
+
+
+def test_domain_rand_toggled_after_construction(oracle_mod):
+    """run_tests.py:64-66 sets `env.domain_rand = True` on a constructed env; from the next reset on it behaves
+    like an env constructed with domain randomisation (draw order, textures, per-step parameter draws)."""
+    from gym_miniworld_amd.env import make
+    O = oracle_mod
+    env = make("MiniWorld-FourRooms-v0", seed=12)
+    assert env.domain_rand is False
+    env.domain_rand = True
+    assert env.domain_rand is True
+    ref = O.OracleEnv("FourRooms", seed=12, domain_rand=True)
+    obs = env.reset()
+    ref.reset(render=False)
+    assert np.array_equal(env.agent.pos, np.array(ref.state().agent_pos)) and list(env.sky_color) == list(ref.state().sky_color)
+    assert np.abs(obs.astype(int) - ref.render_obs().astype(int)).max() <= 1
+    for a in (2, 2, 0, 2, 1, 2, 2):
+        _, r, d, _ = env.step(a)
+        _, rr, dd, _ = ref.step(a)
+        assert (r, d) == (rr, dd)
+    s = ref.state()
+    assert env._b.get_state()["rng_pos"][0] == s.rng_pos   # three draws per step were consumed
+    env.domain_rand = False
+    env.reset(); ref2 = None
+    assert list(env.sky_color) == [0.25, 0.82, 1.0]   # defaults again (params.py:111)
+    env.close()
+
+
+def test_every_covered_env_id_loads_and_steps_like_run_tests():
+    """run_tests.py:61-79: for each registered id (here: the covered ones) - gym.make, domain_rand = True, random
+    restarts, the spawn never intersects anything, random actions, reset on done."""
+    from gym_miniworld_amd.batch import ENV_SPECS
+    from gym_miniworld_amd.env import make
+    rng = np.random.default_rng(0)
+    for env_id in sorted(ENV_SPECS):
+        env = make(env_id, seed=3)
+        env.domain_rand = True
+        for _ in range(4):
+            obs = env.reset()
+            assert obs.shape == env.observation_space.shape and 0 < obs.mean() < 255, env_id
+            assert not env.intersect(env.agent, env.agent.pos, env.agent.radius), env_id
+            for _ in range(20):
+                obs, reward, done, info = env.step(int(rng.integers(0, env.action_space.n)))
+                if done:
+                    env.reset()
+        env.close()
