@@ -1307,7 +1307,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
         const uint32_t *tsrc = (const uint32_t *)d.tex_desc;
         uint32_t *tdst = (uint32_t *)tex;
         for (int i = tid; i < (int)(sizeof(TexLds) * MWB_MAX_TEX / 4); i += THREADS) tdst[i] = tsrc[i];
-        if (tid == 0) *cam_room_s = 0x7fffffff;
+        if (tid == 0) { cam_room_s[0] = 0x7fffffff; cam_room_s[1] = 0; }   // eye room (atomicMin), work-item counter
     }
     __syncthreads();
     RenderCtx<NBOX> ctx;
@@ -1360,13 +1360,22 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
     int q_count = 0, iq_count = 0;   // wave-uniform
     const int ci = lane & (TILE_CX - 1), cj = lane / TILE_CX;
     const int n_strips = (W + TILE_CX - 2) / (TILE_CX - 1);
-    const int half_h = (H + 1) / 2;                       // pixel rows per half strip
-    const int n_items = n_strips * 2;                     // (strip, upper / lower half)
-    const int n_pass = (half_h + 1 + TILE_CY - 1) / TILE_CY;   // corner rows per half: half_h + 1
+    // Work items = (strip, quarter of the rows): 24 at 80 x 60, 15 x 15 pixels each (16 corner rows = 4 passes,
+    // none wasted).  Waves take them from an LDS counter as they become free, so a wave that drew cheap
+    // (uniform) items does not idle while another one works through the edge-rich ones.
+    const int part_h = (H + 3) / 4;                       // pixel rows per item
+    const int n_items = n_strips * 4;
+    const int n_pass = (part_h + 1 + TILE_CY - 1) / TILE_CY;   // corner rows per item: part_h + 1
+    (void)n_waves;
 
-    for (int item = wave; item < n_items; item += n_waves) {
-        const int x0 = (item >> 1) * (TILE_CX - 1), row0 = (item & 1) * half_h;
-        const int rows = (item & 1) ? H - half_h : half_h;   // pixel rows of this half
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(cam_room_s + 1, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const int x0 = (item >> 2) * (TILE_CX - 1), row0 = (item & 3) * part_h;
+        const int rows = (H - row0) < part_h ? (H - row0) : part_h;   // pixel rows of this item
+        if (rows <= 0) continue;
         uint32_t prev_key = 0, prev_path = 0;
         for (int p = 0; p < n_pass; p++) {
             const int crow = row0 + p * TILE_CY + cj;        // corner row (0 .. H), window y (up) = H - crow
