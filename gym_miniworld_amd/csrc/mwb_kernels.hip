@@ -1292,7 +1292,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
     size_t off = ((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15;
     float *fc = (float *)(smem + off); off += MWB_FRAME_WORDS * 4;
     TexLds *tex = (TexLds *)(smem + off); off += sizeof(TexLds) * MWB_MAX_TEX;
-    int *cam_room_s = (int *)(smem + off); off += 16;
+    int *cam_room_s = (int *)(smem + off); off += 16 + 2 * (THREADS / WAVE) * sizeof(int);   // + leftover counts
     uint16_t *queues = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
     uint32_t *ikeys = (uint32_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint32_t);
     uint16_t *ipix = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
@@ -1431,13 +1431,35 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
             }
         }
     }
-    if (lane < iq_count && !(d.debug_flags & 4)) {
-        const int p = iq_pix[lane];
-        ctx.pixel_interior(p & wmask, p >> wshift, iq_key[lane]);
+    // Leftovers (< 64 per wave and queue): pooled over the workgroup and dealt out again in full batches - interior
+    // pixels to the waves from the first up, 8-sample pixels from the last down - instead of every wave
+    // running two partly filled batches.
+    int *left = cam_room_s + 4;
+    if (lane == 0) { left[wave] = iq_count; left[n_waves + wave] = q_count; }
+    __syncthreads();
+    if (!(d.debug_flags & 4)) {
+        int g = tid, owner = -1;
+#pragma unroll
+        for (int w = 0; w < THREADS / WAVE; w++) {
+            const int c = left[w];
+            if (owner < 0) { if (g < c) owner = w; else g -= c; }
+        }
+        if (owner >= 0) {
+            const int p = ipix[owner * QUEUE_CAP + g];
+            ctx.pixel_interior(p & wmask, p >> wshift, ikeys[owner * QUEUE_CAP + g]);
+        }
     }
-    if (lane < q_count && !(d.debug_flags & 2)) {
-        const int q = queue[lane];
-        ctx.pixel_full(q & wmask, q >> wshift);
+    if (!(d.debug_flags & 2)) {
+        int g = THREADS - 1 - tid, owner = -1;
+#pragma unroll
+        for (int w = 0; w < THREADS / WAVE; w++) {
+            const int c = left[n_waves + w];
+            if (owner < 0) { if (g < c) owner = w; else g -= c; }
+        }
+        if (owner >= 0) {
+            const int q = queues[owner * QUEUE_CAP + g];
+            ctx.pixel_full(q & wmask, q >> wshift);
+        }
     }
     __syncthreads();
     {   // framebuffer LDS -> HBM, 16 bytes per lane
@@ -1537,7 +1559,7 @@ size_t mwb_reset_lds_bytes(const MwbDev &d) {
     return (b + 15) & ~(size_t)15;
 }
 size_t mwb_render_lds_bytes(const MwbDev &d) {
-    size_t b = (((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15) + MWB_FRAME_WORDS * 4 + sizeof(TexLds) * MWB_MAX_TEX + 16 +
+    size_t b = (((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15) + MWB_FRAME_WORDS * 4 + sizeof(TexLds) * MWB_MAX_TEX + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
                (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)d.W * d.H * 3;
     b += (size_t)(d.debug_flags >> 8) * 1024;   // MWB_DEBUG bits 8+: KiB of LDS padding (occupancy experiments)
     return (b + 15) & ~(size_t)15;
