@@ -230,7 +230,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
                          "kernel": "render_kernel", "kernel_ms": render_ms,
                          "algorithmic_bytes_per_launch": alg_bytes * count,
-                         "note": "nominally HBM-bound path; practical limiter is VALU/LDS per ray (DESIGN.md)"},
+                         "note": "nominally HBM-bound path; the practical limiter is VALU issue plus LDS / texel latency (VALU pipes ~54 % busy at 5 waves/SIMD, DESIGN.md 4)"},
             "kernel_ms": {k: kt[k] for k in ("step", "reset", "prep", "render")},
         }
         if world == 1 and not args.no_cpu_baseline:
