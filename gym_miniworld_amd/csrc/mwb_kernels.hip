@@ -1150,20 +1150,23 @@ struct RenderCtx {
     }
 
     // acc = sum over the 8 samples of their colour; t_s0 / kind of sample 0 for the depth map
+    // MEAN: acc already holds the mean of the 8 samples (interior pixels: 8 c / 8 == c exactly)
+    template <bool MEAN>
     __device__ __forceinline__ void write_pixel(int px, int py, const float *acc, bool s0_drawn, float t_s0) const {
         uint8_t out[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            float v = acc[q] * 0.125f;
-            v = v < 0 ? 0 : (v > 1 ? 1 : v);
-            out[q] = (uint8_t)(int)floorf(v * 255.0f + 0.5f);   // RGBA32F -> unorm8 resolve
+            float v = MEAN ? acc[q] : acc[q] * 0.125f;
+            v = __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f);              // clamp
+            out[q] = (uint8_t)(unsigned)(v * 255.0f + 0.5f);         // RGBA32F -> unorm8 resolve: floor(255 v + 1/2), v >= 0
         }
         if (layout == MWB_LAYOUT_HWC) {
             uint8_t *p = fb + (py * W + px) * 3;
             p[0] = out[0]; p[1] = out[1]; p[2] = out[2];
         } else {
-#pragma unroll
-            for (int q = 0; q < 3; q++) fb[(q * W + px) * H + py] = out[q];
+            uint8_t *p = fb + (px * H + py);
+            const int plane = W * H;
+            p[0] = out[0]; p[plane] = out[1]; p[2 * plane] = out[2];
         }
         if (depth) {
             int z16 = 65535;   // DEPTH_COMPONENT16 of sample 0; cleared to 1.0 where nothing was drawn
@@ -1248,16 +1251,14 @@ struct RenderCtx {
             k0 = k1; k1 = k2; k2 = k3;
             meta = ((meta & 0xFFFFu) >> 4) | ((meta >> 19) << 16);
         }
-        write_pixel(px, py, acc, (key_s0 & 7u) != KIND_SKY, t_s0);
+        write_pixel<false>(px, py, acc, (key_s0 & 7u) != KIND_SKY, t_s0);
     }
 
     // a pixel whose 8 samples provably see one room surface: one shade, colour x 8 / 8
     __device__ __forceinline__ void pixel_interior(int px, int py, uint32_t key) const {
         const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
-        float col[3], acc[3];
+        float col[3];
         shade(key, 0, cx, cy, col);
-#pragma unroll
-        for (int q = 0; q < 3; q++) acc[q] = 8.0f * col[q];
         float t_s0 = 1.0f;
         if (depth) {   // sample 0's ray meets the known surface at the distance the traversal would report
             float dv[3];
@@ -1273,7 +1274,7 @@ struct RenderCtx {
             const float oo = is_x ? cam.eye[0] : (is_z ? cam.eye[2] : cam.eye[1]);
             t_s0 = (plane - oo) * (1.0f / od);
         }
-        write_pixel(px, py, acc, true, t_s0);
+        write_pixel<true>(px, py, col, true, t_s0);
     }
 };
 
