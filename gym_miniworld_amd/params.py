@@ -73,3 +73,21 @@ DEFAULT_PARAMS.set("cam_pitch", 0, -5, 5)
 DEFAULT_PARAMS.set("cam_fov_y", 60, 55, 65)
 DEFAULT_PARAMS.set("cam_height", 1.5, 1.45, 1.55)
 DEFAULT_PARAMS.set("cam_fwd_disp", 0, -0.05, 0.10)
+
+
+def sim_to_real_params(push=False):
+    """envs/simtorealgoto.py:8-18 / simtorealpush.py:8-18: a robot about 15 cm tall with a Pi camera.  The two
+    files differ only in bot_radius (0.4 +- 0.02, unused, vs 0.11, which SimToRealPush uses to keep boxes off the walls)."""
+    p = DEFAULT_PARAMS.copy()
+    p.set("forward_step", 0.035, 0.028, 0.042)
+    p.set("forward_drift", 0, -0.005, 0.005)
+    p.set("turn_step", 17, 13, 21)
+    if push:
+        p.set("bot_radius", 0.11, 0.11, 0.11)
+    else:
+        p.set("bot_radius", 0.4, 0.38, 0.42)   # FIXME in the reference: not used
+    p.set("cam_pitch", -10, -15, -3)
+    p.set("cam_fov_y", 49, 45, 55)
+    p.set("cam_height", 0.18, 0.17, 0.19)
+    p.set("cam_fwd_disp", 0, -0.02, 0.02)
+    return p

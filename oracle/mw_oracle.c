@@ -165,9 +165,10 @@ typedef struct {
 typedef struct { double pos[3], dir, radius, height; } Ent;
 
 /* texture families (name -> list of <name>_<i>.png, opengl.py:40-69) */
-enum { TEXF_FLOOR_TILES_BW = 0, TEXF_CONCRETE, TEXF_CONCRETE_TILES, TEXF_BRICK_WALL, N_TEXF };
-static const int TEXF_FIRST[N_TEXF] = {0, 1, 5, 6};
-static const int TEXF_COUNT[N_TEXF] = {1, 4, 1, 1};
+enum { TEXF_FLOOR_TILES_BW = 0, TEXF_CONCRETE, TEXF_CONCRETE_TILES, TEXF_BRICK_WALL,
+       TEXF_CARDBOARD, TEXF_WOOD, TEXF_WOOD_PLANKS, TEXF_DRYWALL, TEXF_STUCCO, TEXF_CEILING_TILES, N_TEXF };
+static const int TEXF_FIRST[N_TEXF] = {0, 1, 5, 6, 7, 11, 13, 14, 15, 16};
+static const int TEXF_COUNT[N_TEXF] = {1, 4, 1, 1, 4, 2, 1, 1, 1, 1};
 
 typedef struct {
     int w, h, n_levels;
@@ -195,7 +196,9 @@ struct MwoEnv {
     Ent box, box2, agent;
     int n_boxes; /* 1, or 2 for the two-box T-maze (red = box, blue = box2) */
     int n_ents; /* placement order: box(0), [box2(1)], agent(last) */
-    double box_size[3], box_color[3], box2_color[3];
+    double box_s[2]; /* edge length of each box (Box(size=s), entity.py:366-378) */
+    double box_color[3], box2_color[3];
+    double goal_dist; /* SimToRealPush */
     /* T-maze family (envs/tmaze.py): goal alternation state */
     long long episode_count, task_step_count;
     int goal_idx;
@@ -261,16 +264,18 @@ static void sample_param(MwoEnv *e, int use_rng, int name, double *out) {
 MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int domain_rand, const double *params) {
     MwoEnv *e = (MwoEnv *)calloc(1, sizeof(MwoEnv));
     e->task = task;
-    static const double dflt[6][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}};
-    if (task < 0 || task > MWO_TMAZE_TWOBOX) fail("unknown task");
+    static const double dflt[8][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (task < 0 || task > MWO_SIM2REAL_PUSH) fail("unknown task");
     for (int i = 0; i < 4; i++) e->task_args[i] = task_args ? task_args[i] : dflt[task][i];
-    e->n_boxes = task == MWO_TMAZE_TWOBOX ? 2 : 1;
+    e->n_boxes = (task == MWO_TMAZE_TWOBOX || task == MWO_SIM2REAL_PUSH) ? 2 : 1;
     if (max_episode_steps <= 0) {
         /* hallway.py:18, oneroom.py:14, fourrooms.py:15, maze.py:27 */
         if (task == MWO_HALLWAY) max_episode_steps = 250;
         else if (task == MWO_ONEROOM) max_episode_steps = 180;
         else if (task == MWO_FOURROOMS) max_episode_steps = 250;
         else if (task == MWO_TMAZE || task == MWO_TMAZE_TWOBOX) max_episode_steps = 280; /* tmaze.py:20,142 */
+        else if (task == MWO_SIM2REAL_GOTO) max_episode_steps = 100; /* simtorealgoto.py:30 */
+        else if (task == MWO_SIM2REAL_PUSH) max_episode_steps = 150; /* simtorealpush.py:29 */
         else max_episode_steps = (int)e->task_args[0] * (int)e->task_args[1] * 24;
     }
     e->max_episode_steps = max_episode_steps;
@@ -420,7 +425,10 @@ static int tex_get(MwoEnv *e, int family, int use_rng) {
     return TEXF_FIRST[family] + idx;
 }
 
-static int tex_width(int id) { return g_tex[id].w > 0 ? g_tex[id].w : (id == 3 || id == 5 ? 768 : id == 6 ? 1024 : 512); }
+static int tex_width(int id) { /* fallback when the pixels were not loaded: the sizes of the reference's PNGs */
+    if (g_tex[id].w > 0) return g_tex[id].w;
+    return (id == 3 || id == 5) ? 768 : (id == 6 || id == 9 || id == 13) ? 1024 : id == 10 ? 256 : 512;
+}
 static int tex_height(int id) { return g_tex[id].h > 0 ? g_tex[id].h : tex_width(id); }
 
 typedef struct { Room *r; Quad *q; int nq, capq; double (*s)[2][3]; int ns, caps; } GenCtx;
@@ -589,14 +597,14 @@ static void place_entity(MwoEnv *e, Ent *ent, int has_dir, double dir, double mi
     place_entity_in(e, ent, -1, has_dir, dir, min_x, max_x, min_z, max_z);
 }
 
-static void new_box(MwoEnv *e) {
-    /* entity.py:362-379 Box(color='red', size=0.8) */
-    double sx = 0.8, sy = 0.8, sz = 0.8;
-    e->box_size[0] = sx; e->box_size[1] = sy; e->box_size[2] = sz;
-    e->box.radius = sqrt(sx * sx + sz * sz) / 2;
-    e->box.height = sy;
-    e->box2.radius = e->box.radius; e->box2.height = sy;
+/* entity.py:362-379 Box(color, size=s): radius = sqrt(sx^2 + sz^2) / 2, height = sy */
+static void size_box(MwoEnv *e, int b, double s) {
+    Ent *ent = b ? &e->box2 : &e->box;
+    e->box_s[b] = s;
+    ent->radius = sqrt(s * s + s * s) / 2;
+    ent->height = s;
 }
+static void new_box(MwoEnv *e) { size_box(e, 0, 0.8); size_box(e, 1, 0.8); }
 
 /* envs/maze.py:34-104 */
 typedef struct { int i, j; int order[4][2]; int next; } Frame;
@@ -699,6 +707,38 @@ static void gen_world(MwoEnv *e) {
         place_entity_in(e, &e->agent, 0, 1, dir, NOVAL, NOVAL, NOVAL, NOVAL);
         break;
     }
+    case MWO_SIM2REAL_GOTO:   /* envs/simtorealgoto.py:40-82 */
+    case MWO_SIM2REAL_PUSH: { /* envs/simtorealpush.py:39-107 */
+        const int push = e->task == MWO_SIM2REAL_PUSH;
+        double size = push ? rs_uniform(&e->rng, 1.6, 1.7) : rs_uniform(&e->rng, 1, 2);
+        double wall_height = push ? rs_uniform(&e->rng, 0.42, 0.50) : rs_uniform(&e->rng, 0.20, 0.50);
+        double s1 = push ? rs_uniform(&e->rng, 0.075, 0.090) : rs_uniform(&e->rng, 0.07, 0.12);
+        double s2 = push ? rs_uniform(&e->rng, 0.075, 0.090) : 0.8;
+        e->agent.radius = 0.11;
+        static const int FLOORS[3] = {TEXF_CARDBOARD, TEXF_WOOD, TEXF_WOOD_PLANKS};
+        static const int WALLS_GOTO[5] = {TEXF_DRYWALL, TEXF_STUCCO, TEXF_CARDBOARD, TEXF_CONCRETE_TILES, TEXF_CEILING_TILES};
+        static const int WALLS_PUSH[4] = {TEXF_DRYWALL, TEXF_STUCCO, TEXF_CONCRETE_TILES, TEXF_CEILING_TILES};
+        int floor_tex = FLOORS[rs_randint(&e->rng, 0, 3)]; /* RandGen.choice -> np_random.choice(len) -> randint */
+        int wall_tex = push ? WALLS_PUSH[rs_randint(&e->rng, 0, 4)] : WALLS_GOTO[rs_randint(&e->rng, 0, 5)];
+        double o[4][2] = {{size, size}, {size, 0}, {0, 0}, {0, size}};
+        add_room(e, o, wall_height, wall_tex, floor_tex, TEXF_CONCRETE_TILES, 1);
+        size_box(e, 0, s1); size_box(e, 1, s2);
+        if (push) {
+            e->goal_dist = 1.5 * (s1 + s2);
+            double min_pos = 2 * e->params[MWO_P_BOT_RADIUS].hi[0], max_pos = size - 2 * e->params[MWO_P_BOT_RADIUS].hi[0];
+            for (;;) { /* boxes can't start too close to each other */
+                place_entity(e, &e->box, 0, 0, min_pos, max_pos, min_pos, max_pos);
+                place_entity(e, &e->box2, 0, 0, min_pos, max_pos, min_pos, max_pos);
+                double dx = e->box.pos[0] - e->box2.pos[0], dy = e->box.pos[1] - e->box2.pos[1], dz = e->box.pos[2] - e->box2.pos[2];
+                if (sqrt((dx * dx + dy * dy) + dz * dz) > e->goal_dist) break;
+                e->n_ents = 0; /* entities.remove(box1), entities.remove(box2) */
+            }
+        } else {
+            place_entity(e, &e->box, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        }
+        place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        break;
+    }
     default: fail("unknown task");
     }
 }
@@ -735,9 +775,10 @@ void mwo_reset(MwoEnv *e) {
     const double red[3] = {1.0, 0.0, 0.0};
     for (int k = 0; k < 3; k++) { double v = red[k] + bias[k]; e->box_color[k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
     if (e->n_boxes == 2) { /* entities are randomized in list order: red box, blue box, agent */
-        const double blue[3] = {0.0, 0.0, 1.0};
+        const double blue[3] = {0.0, 0.0, 1.0}, yellow[3] = {1.0, 1.0, 0.0}; /* COLORS, entity.py:8-15 */
+        const double *c2 = e->task == MWO_SIM2REAL_PUSH ? yellow : blue;
         sample_param(e, dr, MWO_P_OBJ_COLOR_BIAS, bias);
-        for (int k = 0; k < 3; k++) { double v = blue[k] + bias[k]; e->box2_color[k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
+        for (int k = 0; k < 3; k++) { double v = c2[k] + bias[k]; e->box2_color[k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
     }
     /* Agent.randomize, entity.py:486-492 */
     sample_param(e, dr, MWO_P_CAM_HEIGHT, &e->cam_height);
@@ -757,6 +798,25 @@ static int near_box(MwoEnv *e) { return near_ent(e, &e->box); }
 
 /* MiniWorldEnv.step miniworld.py:658-716 + task rule (e.g. envs/maze.py:106-113) */
 void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
+    if (e->task == MWO_SIM2REAL_PUSH && action == 2) { /* simtorealpush.py:109-125, before MiniWorldEnv.step */
+        double fwd_dist = e->params[MWO_P_FORWARD_STEP].hi[0];
+        double dv[3] = {cos(e->agent.dir), 0, -sin(e->agent.dir)};
+        double next_pos[3];
+        for (int k = 0; k < 3; k++) next_pos[k] = e->agent.pos[k] + dv[k] * fwd_dist;
+        Ent *boxes[2] = {&e->box, &e->box2};
+        for (int b = 0; b < 2; b++) {
+            Ent *box = boxes[b];
+            double vec[3] = {box->pos[0] - next_pos[0], box->pos[1] - next_pos[1], box->pos[2] - next_pos[2]};
+            double dist = sqrt((vec[0] * vec[0] + vec[1] * vec[1]) + vec[2] * vec[2]);
+            if (dist < e->agent.radius + box->radius) {
+                double nb[3] = {box->pos[0] + vec[0], box->pos[1] + vec[1], box->pos[2] + vec[2]};
+                if (!intersect(e, box, nb, box->radius)) {
+                    memcpy(box->pos, nb, sizeof(nb));
+                    box->dir += rs_uniform(&e->rng, -M_PI / 5, M_PI / 5);
+                }
+            }
+        }
+    }
     e->step_count += 1;
     int dr = e->domain_rand;
     double fwd_step, fwd_drift, turn_step;
@@ -787,6 +847,9 @@ void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
             e->feature[1] = near_ent(e, &e->box) ? 1 : 0;
             e->task_step_count += 1;
         }
+    } else if (e->task == MWO_SIM2REAL_PUSH) { /* simtorealpush.py:129-133 */
+        double dx = e->box.pos[0] - e->box2.pos[0], dy = e->box.pos[1] - e->box2.pos[1], dz = e->box.pos[2] - e->box2.pos[2];
+        if (sqrt((dx * dx + dy * dy) + dz * dz) < e->goal_dist) { r = 1; d = 1; }
     } else if (near_box(e)) { r += 1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps); d = 1; }
     *reward = r; *done = d;
 }
@@ -838,6 +901,7 @@ void mwo_get_state(MwoEnv *e, MwoState *s) {
     memcpy(s->box2_pos, e->box2.pos, 24); s->box2_dir = e->box2.dir; memcpy(s->box2_color, e->box2_color, 24);
     s->episode_count = e->episode_count; s->task_step_count = e->task_step_count;
     s->feature[0] = e->feature[0]; s->feature[1] = e->feature[1];
+    s->box_size = e->box_s[0]; s->box2_size = e->box_s[1]; s->agent_radius = e->agent.radius; s->goal_dist = e->goal_dist;
 }
 void mwo_set_counters(MwoEnv *e, long long episode_count, long long task_step_count, int goal_idx) {
     e->episode_count = episode_count; e->task_step_count = task_step_count; e->goal_idx = goal_idx;
@@ -903,7 +967,7 @@ typedef struct {
 } RSide;
 typedef struct {
     float min_x, max_x, min_z, max_z, height;
-    int wall_tex, floor_tex, ceil_tex;
+    int wall_tex, floor_tex, ceil_tex, no_ceiling;
     RSide side[4]; /* 0:+x (east) 1:-z (north) 2:-x (west) 3:+z (south) */
 } RRoom;
 
@@ -930,7 +994,7 @@ static int build_rrooms(MwoEnv *e, RRoom *rr) {
         Room *r = &e->rooms[i]; RRoom *o = &rr[i];
         o->min_x = (float)r->min_x; o->max_x = (float)r->max_x; o->min_z = (float)r->min_z; o->max_z = (float)r->max_z;
         o->height = (float)r->wall_height;
-        o->wall_tex = r->wall_tex; o->floor_tex = r->floor_tex; o->ceil_tex = r->ceil_tex;
+        o->wall_tex = r->wall_tex; o->floor_tex = r->floor_tex; o->ceil_tex = r->ceil_tex; o->no_ceiling = r->no_ceiling;
         for (int s = 0; s < 4; s++) { o->side[s].nbr = -1; o->side[s].lo = o->side[s].hi = o->side[s].min_y = o->side[s].max_y = 0; }
         for (int ed = 0; ed < 4; ed++) {
             const double *nrm = r->edge_norms[ed];
@@ -982,12 +1046,13 @@ static Hit trace_rooms(const RRoom *rr, int n_rooms, int room, const float *o, c
         float ts; int s;
         if (tx <= tz) { ts = tx; s = sx; } else { ts = tz; s = sz; }
         if (d[1] < 0) { float tf = (0.0f - o[1]) * iy; if (tf <= ts) { h.kind = 1; h.room = room; h.t = tf; return h; } }
-        if (d[1] > 0) { float tc = (r->height - o[1]) * iy; if (tc <= ts) { h.kind = 2; h.room = room; h.t = tc; return h; } }
+        if (d[1] > 0 && !r->no_ceiling) { float tc = (r->height - o[1]) * iy; if (tc <= ts) { h.kind = 2; h.room = room; h.t = tc; return h; } }
         if (!(ts < INFINITY)) return h;
         const RSide *sd = &r->side[s];
         float hc = (s == 0 || s == 2) ? fmaf(ts, d[2], o[2]) : fmaf(ts, d[0], o[0]);
         float y = fmaf(ts, d[1], o[1]);
         if (sd->nbr >= 0 && sd->lo < hc && hc < sd->hi && sd->min_y < y && y < sd->max_y) { room = sd->nbr; continue; }
+        if (r->no_ceiling && !(y < r->height)) return h; /* Room._render draws no ceiling (miniworld.py:406): over the wall = sky */
         h.kind = 3; h.room = room; h.side = s; h.t = ts; return h;
     }
     return h;
@@ -1146,7 +1211,7 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
         float bcol[3];
         for (int k = 0; k < 3; k++) { bx.pos[k] = (float)be->pos[k]; bcol[k] = b ? (float)e->box2_color[k] : L.box_color[k]; }
         bx.c = (float)cos(be->dir); bx.s = (float)sin(be->dir);
-        bx.half[0] = (float)(e->box_size[0] / 2); bx.half[2] = (float)(e->box_size[2] / 2); bx.half[1] = 0; bx.sy = (float)e->box_size[1];
+        bx.half[0] = (float)(e->box_s[b] / 2); bx.half[2] = (float)(e->box_s[b] / 2); bx.half[1] = 0; bx.sy = (float)e->box_s[b];
         /* world normal of local normal n: R_y(dir) n = (nx c + nz s, ny, -nx s + nz c) */
         static const float ln[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
         for (int k = 0; k < 6; k++) {

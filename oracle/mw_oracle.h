@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-enum { MWO_HALLWAY = 0, MWO_ONEROOM = 1, MWO_FOURROOMS = 2, MWO_MAZE = 3, MWO_TMAZE = 4, MWO_TMAZE_TWOBOX = 5 };
+enum { MWO_HALLWAY = 0, MWO_ONEROOM = 1, MWO_FOURROOMS = 2, MWO_MAZE = 3, MWO_TMAZE = 4, MWO_TMAZE_TWOBOX = 5,
+       MWO_SIM2REAL_GOTO = 6, MWO_SIM2REAL_PUSH = 7 };
 
 /* domain parameters, reference params.py:110-123, same order */
 enum {
@@ -35,7 +36,7 @@ enum {
 
 #define MWO_MAX_ROOMS 512
 #define MWO_MAX_PORTALS 2 /* per edge */
-#define MWO_MAX_TEX 16
+#define MWO_MAX_TEX 32
 #define MWO_MAX_LEVELS 12
 
 typedef struct MwoEnv MwoEnv;
@@ -46,7 +47,8 @@ int mwo_set_texture(int tex_id, int width, int height, int n_levels, const uint8
 
 /* task_args: Hallway {length}, OneRoom {size}, FourRooms {}, Maze {num_rows, num_cols, room_size},
  * TMaze {goal_pos given?, goal x, goal z, sub_task_length (> 0: TMazeDynamic)},
- * TMazeTwoBox {rule: 0 episode count (TMazeTwoBoxDynamic) / 1 step count + features (*Features*), -, -, sub_task_length}.
+ * TMazeTwoBox {rule: 0 episode count (TMazeTwoBoxDynamic) / 1 step count + features (*Features*), -, -, sub_task_length},
+ * SimToRealGoTo {} / SimToRealPush {} (envs/simtorealgoto.py, simtorealpush.py: pass their sim_params table and domain_rand = 1).
  * params: MWO_NPARAM x 9 doubles (default[3], min[3], max[3]); NULL = reference defaults. */
 MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int domain_rand,
                    const double *params);
@@ -71,6 +73,8 @@ typedef struct {
     double box2_pos[3], box2_dir, box2_color[3];
     long long episode_count, task_step_count;
     double feature[2]; /* info['feature'] of the last step (zeros for tasks without) */
+    /* sim-to-real tasks: per-episode sizes */
+    double box_size, box2_size, agent_radius, goal_dist;
 } MwoState;
 void mwo_get_state(MwoEnv *e, MwoState *out);
 void mwo_set_agent(MwoEnv *e, double x, double z, double dir); /* test hook */

@@ -16,10 +16,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmw_oracle.so")
 TEX_DIR = os.path.join(os.path.dirname(HERE), "gym_miniworld_amd", "textures")
 
-TASKS = {"Hallway": 0, "OneRoom": 1, "FourRooms": 2, "Maze": 3, "TMaze": 4, "TMazeTwoBox": 5}
+TASKS = {"Hallway": 0, "OneRoom": 1, "FourRooms": 2, "Maze": 3, "TMaze": 4, "TMazeTwoBox": 5,
+         "SimToRealGoTo": 6, "SimToRealPush": 7}
 # texture id table (family -> files), reference opengl.py:40-69 picks <name>_<i>.png
 TEX_FILES = ["floor_tiles_bw_1", "concrete_1", "concrete_2", "concrete_3", "concrete_4",
-             "concrete_tiles_1", "brick_wall_1"]
+             "concrete_tiles_1", "brick_wall_1",
+             # the sim-to-real tasks' choices (envs/simtorealgoto.py:52-66)
+             "cardboard_1", "cardboard_2", "cardboard_3", "cardboard_4", "wood_1", "wood_2", "wood_planks_1",
+             "drywall_1", "stucco_1", "ceiling_tiles_1"]
 MAX_PORTALS = 2
 NPARAM = 13
 
@@ -48,6 +52,8 @@ class MwoState(ctypes.Structure):
         ("box2_pos", ctypes.c_double * 3), ("box2_dir", ctypes.c_double), ("box2_color", ctypes.c_double * 3),
         ("episode_count", ctypes.c_longlong), ("task_step_count", ctypes.c_longlong),
         ("feature", ctypes.c_double * 2),
+        ("box_size", ctypes.c_double), ("box2_size", ctypes.c_double), ("agent_radius", ctypes.c_double),
+        ("goal_dist", ctypes.c_double),
     ]
 
 

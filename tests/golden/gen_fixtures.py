@@ -27,6 +27,7 @@ import gym_miniworld  # noqa: E402,F401
 from gym_miniworld.envs import FourRooms, Hallway, Maze, OneRoom  # noqa: E402
 from gym_miniworld.envs import (TMaze, TMazeDynamic, TMazeLeft, TMazeRight, TMazeTwoBoxDynamic,  # noqa: E402
                                 TMazeTwoBoxDynamicFeatures100K, TMazeTwoBoxDynamicFeaturesDebug)
+from gym_miniworld.envs import SimToRealGoTo, SimToRealPush  # noqa: E402
 from gym_miniworld.opengl import Texture  # noqa: E402
 from gym_miniworld import math as ref_math  # noqa: E402
 
@@ -46,6 +47,7 @@ TASKS = {
     "TMazeTwoBoxFeatures": (TMazeTwoBoxDynamicFeatures100K, {"sub_task_length": 150}),
     "TMazeTwoBoxFeaturesDebug": (TMazeTwoBoxDynamicFeaturesDebug, {}),
 }
+TASKS.update({"SimToRealGoTo": (SimToRealGoTo, {}), "SimToRealPush": (SimToRealPush, {})})   # no-ceiling rinks, own params
 NO_KWARGS = {"TMazeLeft", "TMazeRight", "TMazeDynamic3"}   # constructors without **kwargs: no domain_rand
 
 # (seed, domain_rand, policy, n_steps)
@@ -69,6 +71,9 @@ PLAN = {
     "TMazeTwoBoxDynamic2": [(0, 0, "greedy", 700), (1, 1, "greedy_red", 700), (2, 0, "random", 600)],
     "TMazeTwoBoxFeatures": [(0, 0, "greedy", 600), (1, 1, "greedy_blue", 600), (2, 1, "forward", 500)],
     "TMazeTwoBoxFeaturesDebug": [(0, 0, "greedy_blue", 300), (1, 1, "greedy", 300)],
+    # these two classes force domain_rand=True themselves (simtorealgoto.py:31, simtorealpush.py:30)
+    "SimToRealGoTo": [(0, 1, "random", 400), (1, 1, "greedy", 400), (2, 1, "forward", 300)],
+    "SimToRealPush": [(0, 1, "random", 500), (1, 1, "push", 900), (2, 1, "greedy", 600), (3, 1, "push", 900)],
 }
 
 
@@ -120,6 +125,8 @@ def snapshot_world(env):
 
 
 def first_box(env):
+    if hasattr(env, "box1"):
+        return env.box1
     return env.box if hasattr(env, "box") else env.red_box
 
 
@@ -134,6 +141,13 @@ def snapshot_entities(env):
                  "goal_idx": np.array(int(env.goal_box_idx))}
     elif hasattr(env, "current_goal"):
         extra = {"goal_idx": np.array(int(env.current_goal))}
+    if hasattr(env, "box2"):   # SimToRealPush: the yellow box
+        b2 = env.box2
+        extra = {"box2_pos": np.array(b2.pos, dtype=float), "box2_dir": np.array(float(b2.dir)),
+                 "box2_color": np.array(b2.color_vec, dtype=float), "box2_size": np.array(float(b2.size[0])),
+                 "goal_dist": np.array(float(env.goal_dist))}
+    if type(env).__name__.startswith("SimToReal"):
+        extra.update({"box_size": np.array(float(box.size[0])), "agent_radius": np.array(float(a.radius))})
     return {
         **extra,
         "box_pos": np.array(box.pos, dtype=float), "box_dir": np.array(float(box.dir)),
@@ -149,7 +163,19 @@ def snapshot_entities(env):
 
 def choose_action(env, policy, arng):
     if policy == "random":
-        return int(arng.integers(0, 3))
+        return int(arng.integers(0, env.action_space.n))
+    if policy == "push":   # SimToRealPush: get behind the red box as seen from the yellow one, then drive at it
+        b1, b2, a = env.box1.pos, env.box2.pos, env.agent
+        away = (b1 - b2) / max(np.linalg.norm(b1 - b2), 1e-9)
+        stage = b1 + away * 0.3
+        tgt = b1 if np.linalg.norm(a.pos - stage) < 0.12 or np.dot(a.pos - b1, away) > 0.2 else stage
+        want = math.atan2(-(tgt[2] - a.pos[2]), tgt[0] - a.pos[0])
+        diff = (want - a.dir + math.pi) % (2 * math.pi) - math.pi
+        if arng.random() < 0.05:
+            return int(arng.integers(0, 4))
+        if abs(diff) > math.radians(12):
+            return 0 if diff > 0 else 1
+        return 2
     if policy == "forward":
         return 2 if arng.random() < 0.9 else int(arng.integers(0, 2))
     # greedy: turn toward the box, then walk
@@ -161,7 +187,7 @@ def choose_action(env, policy, arng):
     elif hasattr(env, "boxes"):
         b = env.boxes[env.goal_box_idx]
     else:
-        b = env.box
+        b = first_box(env)
     tgt = b.pos
     if type(env).__name__.startswith("TMaze") and a.pos[0] < 9.2:
         tgt = np.array([10.0, 0.0, 0.0])   # leave the stem of the T before heading for the arm
@@ -173,6 +199,8 @@ def choose_action(env, policy, arng):
 
 
 def construct(cls, kwargs, dr):
+    if cls.__name__.startswith("SimToReal"):
+        return cls(**kwargs)
     if dr:
         return cls(domain_rand=True, **kwargs)
     return cls(**kwargs)
@@ -196,7 +224,9 @@ def run_case(cls, kwargs, seed, dr, policy, n_steps):
     # state after the worker's auto-reset (subproc_vec_env.py worker: `if done: ob = env.reset()`)
     post = {k: [] for k in ("step", "agent_pos", "agent_dir", "box_pos", "box_dir", "box_color", "cam",
                             "sky_color", "light_pos", "light_color", "light_ambient", "rng", "n_rooms",
-                            "segs_sum", "box2_pos", "box2_dir", "box2_color", "goal_idx")}
+                            "segs_sum", "box2_pos", "box2_dir", "box2_color", "goal_idx", "box_size", "box2_size",
+                            "agent_radius", "goal_dist")}
+    boxes_t = np.zeros((n_steps, 2, 3))   # per-step (x, z, dir) of both boxes: SimToRealPush moves them
     feat = np.zeros((n_steps, 2))
     goal_pos = np.zeros((n_steps, 2))
     for t in range(n_steps):
@@ -207,6 +237,10 @@ def run_case(cls, kwargs, seed, dr, policy, n_steps):
             feat[t] = info["feature"]
         if "goal_pos" in info:
             goal_pos[t] = np.asarray(info["goal_pos"])[[0, 2]]
+        fb = first_box(env)
+        boxes_t[t, 0] = [fb.pos[0], fb.pos[2], fb.dir]
+        if hasattr(env, "box2"):
+            boxes_t[t, 1] = [env.box2.pos[0], env.box2.pos[2], env.box2.dir]
         pos[t] = env.agent.pos[[0, 2]]
         dirs[t] = env.agent.dir
         rew[t] = r
@@ -225,6 +259,8 @@ def run_case(cls, kwargs, seed, dr, policy, n_steps):
             post["segs_sum"].append(float(np.sum(env.wall_segs)))
     if hasattr(env, "boxes") or hasattr(env, "goal_pos"):
         out.update({"traj/feature": feat, "traj/goal_pos": goal_pos})
+    if type(env).__name__.startswith("SimToReal"):
+        out["traj/boxes"] = boxes_t
     out.update({"traj/actions": actions, "traj/pos": pos, "traj/dir": dirs, "traj/reward": rew,
                 "traj/done": done, "traj/step_count": stepc, "traj/rng": rngpos,
                 "traj/cam_pos": campos, "traj/cam_dir": camdir})
@@ -343,6 +379,8 @@ def main():
             if task in ("MazeR2C4", "OneRoomS6", "Hallway6"):
                 continue
             if task.startswith("TMaze") and not ((task == "TMaze" and dr == 0) or (task == "TMazeTwoBoxFeatures" and dr == 1)):
+                continue
+            if task.startswith("SimToReal") and dr == 0:
                 continue
             # the two-box scene is captured from inside the bar of the T, with both boxes in view
             pose = (11.5, 7.6, 2.13) if task == "TMazeTwoBoxFeatures" else None

@@ -27,7 +27,7 @@ def _roty(deg):
 def polygons_from_stream(g):
     """-> list of dicts: verts (n,3) world, texcs (n,2) or None, normal (3,), color (3,), tex (name or None)"""
     out = []
-    room_i, slot = 0, 0  # per room the reference draws floor, ceiling, walls (miniworld.py:390-423)
+    room_i = 0  # per room the reference draws floor, ceiling, walls (miniworld.py:390-423)
     for p in g["polys"]:
         verts = np.array(p["verts"], float)
         texcs = np.array(p["texcs"], float)
@@ -41,11 +41,12 @@ def polygons_from_stream(g):
                 R = R @ _roty(op[1])
         verts = verts @ R.T + T
         norms = norms @ R.T
-        if p["tex_on"]:
-            tex = g["room_tex"][room_i][{0: 1, 1: 2, 2: 0}[slot]]
-            slot += 1
-            if slot == 3:
-                slot, room_i = 0, room_i + 1
+        if p["tex_on"]:   # floor polygon (N = +Y), ceiling polygon (N = -Y, absent with no_ceiling), then the wall quads
+            if p["mode"] == "GL_QUADS":
+                tex = g["room_tex"][room_i][0]
+                room_i += 1
+            else:
+                tex = g["room_tex"][room_i][1 if p["norms"][0][1] > 0 else 2]
         else:
             tex = None
         n_per = {"GL_QUADS": 4, "GL_POLYGON": len(verts)}[p["mode"]]

@@ -15,11 +15,16 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 STREAMS = [("Hallway", "Hallway", None, 0), ("Hallway", "Hallway", None, 1), ("OneRoom", "OneRoom", None, 0),
            ("OneRoom", "OneRoom", None, 1), ("FourRooms", "FourRooms", None, 0), ("FourRooms", "FourRooms", None, 1),
            ("MazeS3", "Maze", [3, 3, 3], 1), ("Maze", "Maze", None, 0),
-           ("TMaze", "TMaze", [0, 0, 0, 0], 0), ("TMazeTwoBoxFeatures", "TMazeTwoBox", [1, 0, 0, 150], 1)]
+           ("TMaze", "TMaze", [0, 0, 0, 0], 0), ("TMazeTwoBoxFeatures", "TMazeTwoBox", [1, 0, 0, 150], 1),
+           ("SimToRealGoTo", "SimToRealGoTo", None, 1), ("SimToRealPush", "SimToRealPush", None, 1)]
 
 
 def posed_env(O, g, task, args, dr):
-    env = O.OracleEnv(task, seed=g["seed"], domain_rand=dr, task_args=args)
+    params = None
+    if task.startswith("SimToReal"):
+        from gym_miniworld_amd.params import sim_to_real_params
+        params = sim_to_real_params(push=task.endswith("Push")).to_table()
+    env = O.OracleEnv(task, seed=g["seed"], domain_rand=dr, task_args=args, params=params)
     env.reset(render=False)
     if g.get("posed"):   # the stream's camera frame was captured after moving the agent (gen_fixtures.capture_gl)
         env.set_agent(g["agent_pos"][0], g["agent_pos"][2], g["agent_dir"])
@@ -39,16 +44,22 @@ def test_scene_inputs_equal_reference_gl_stream(oracle_mod, name, task, args, dr
     geo, s = env.geometry(), env.state()
     R = s.n_rooms
     polys = g["polys"]
-    assert len(polys) == 3 * R + s.n_boxes
+    no_ceiling = task.startswith("SimToReal")   # Room._render skips the ceiling polygon (miniworld.py:406)
+    per_room = 2 if no_ceiling else 3
+    assert len(polys) == per_room * R + s.n_boxes
     for r in range(R):
-        fl, ce, wa = polys[3 * r: 3 * r + 3]
+        if no_ceiling:
+            (fl, wa), ce = polys[2 * r: 2 * r + 2], None
+        else:
+            fl, ce, wa = polys[3 * r: 3 * r + 3]
         o = geo["outline"][r]
         floor_v = np.stack([o[:, 0], np.zeros(4), o[:, 1]], axis=1)
         assert np.array_equal(np.array(fl["verts"]), floor_v) and fl["norms"][0] == [0.0, 1.0, 0.0]
         assert np.array_equal(np.array(fl["texcs"]), geo["floor_texcs"][r])
-        ceil_v = np.stack([o[::-1, 0], np.full(4, geo["wall_height"][r]), o[::-1, 1]], axis=1)
-        assert np.array_equal(np.array(ce["verts"]), ceil_v) and ce["norms"][0] == [0.0, -1.0, 0.0]
-        assert np.array_equal(np.array(ce["texcs"]), geo["ceil_texcs"][r])
+        if ce is not None:
+            ceil_v = np.stack([o[::-1, 0], np.full(4, geo["wall_height"][r]), o[::-1, 1]], axis=1)
+            assert np.array_equal(np.array(ce["verts"]), ceil_v) and ce["norms"][0] == [0.0, -1.0, 0.0]
+            assert np.array_equal(np.array(ce["texcs"]), geo["ceil_texcs"][r])
         q0, q1 = geo["quad_offsets"][r] * 4, geo["quad_offsets"][r + 1] * 4
         assert np.array_equal(np.array(wa["verts"]).reshape(-1, 3), geo["wall_verts"][q0:q1])
         assert np.array_equal(np.array(wa["norms"]).reshape(-1, 3), geo["wall_norms"][q0:q1])
@@ -56,7 +67,7 @@ def test_scene_inputs_equal_reference_gl_stream(oracle_mod, name, task, args, dr
         assert fl["color"] == [1.0, 1.0, 1.0] and fl["tex_on"]
         assert [O.TEX_FILES[i] for i in geo["tex_ids"][r]] == g["room_tex"][r]
     boxes = [(s.box_pos, s.box_dir, s.box_color), (s.box2_pos, s.box2_dir, s.box2_color)][:s.n_boxes]
-    for box, (bpos, bdir, bcol) in zip(polys[3 * R:], boxes):   # entity order: red box, blue box
+    for box, (bpos, bdir, bcol) in zip(polys[per_room * R:], boxes):   # entity order: red box, blue / yellow box
         assert not box["tex_on"] and box["color"] == pytest.approx(list(bcol), abs=0)
         assert box["xform"][0] == ["translate"] + list(bpos)
         assert box["xform"][1][0] == "rotate" and box["xform"][1][1] == bdir * (180 / np.pi)
