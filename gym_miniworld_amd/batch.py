@@ -10,10 +10,13 @@ import os
 import numpy as np
 
 from . import _lib
-from .params import DEFAULT_PARAMS
+from .params import DEFAULT_PARAMS, sim_to_real_params
 
 TEX_FILES = ["floor_tiles_bw_1", "concrete_1", "concrete_2", "concrete_3", "concrete_4", "concrete_tiles_1",
-             "brick_wall_1"]
+             "brick_wall_1",
+             # the sim-to-real rinks' choices (envs/simtorealgoto.py:52-66); uploaded only for those tasks
+             "cardboard_1", "cardboard_2", "cardboard_3", "cardboard_4", "wood_1", "wood_2", "wood_planks_1",
+             "drywall_1", "stucco_1", "ceiling_tiles_1"]
 TEX_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "textures")
 
 # registered ids of the reference (envs/__init__.py:43-49) that this package covers:
@@ -45,6 +48,9 @@ ENV_SPECS = {
     "MiniWorld-TMazeTwoBoxDynamicFeatures1M-v0": ("TMazeTwoBox", [1, 0, 0, 1000000], 0, None, None),
     "MiniWorld-TMazeTwoBoxDynamicFeatures10M-v0": ("TMazeTwoBox", [1, 0, 0, 10000000], 0, None, None),
     "MiniWorld-TMazeTwoBoxDynamicFeaturesDebug-v0": ("TMazeTwoBox", [1, 0, 0, 9000000000000], 0, None, None),
+    # the sim-to-real rinks: own parameter table, domain randomisation forced on (simtorealgoto.py:27-33)
+    "MiniWorld-SimToRealGoTo-v0": ("SimToRealGoTo", [], 0, sim_to_real_params, True),
+    "MiniWorld-SimToRealPush-v0": ("SimToRealPush", [], 0, lambda: sim_to_real_params(push=True), True),
 }
 
 
@@ -133,7 +139,9 @@ class BatchedMiniWorld:
         self.ep_steps = as_t(out.ep_steps, (N,), "<i4")
         self.feature = as_t(out.feature, (N, 2), "<f4")     # info['feature'] (tmaze.py:311-318); zeros elsewhere
         self.goal_pos = as_t(out.goal_pos, (N, 3), "<f8")   # info['goal_pos'] of the T-maze family
-        self.n_boxes = 2 if task == "TMazeTwoBox" else 1
+        self.n_boxes = 2 if task in ("TMazeTwoBox", "SimToRealPush") else 1
+        self.agent_radius = 0.11 if task.startswith("SimToReal") else 0.4
+        self.n_actions = 4 if task == "SimToRealPush" else 3   # Discrete(move_back + 1), simtorealpush.py:37
         self.has_features = task == "TMazeTwoBox" and ta[0] != 0
         self.has_goal_pos = task in ("TMaze", "TMazeTwoBox")
         self.max_episode_steps = self._max_steps(task, ta, max_episode_steps)
@@ -144,11 +152,12 @@ class BatchedMiniWorld:
     def _max_steps(task, ta, mes):
         if mes:
             return int(mes)
-        return {"Hallway": 250, "OneRoom": 180, "FourRooms": 250, "TMaze": 280, "TMazeTwoBox": 280}.get(task) or int(ta[0] or 8) * int(ta[1] or 8) * 24
+        return {"Hallway": 250, "OneRoom": 180, "FourRooms": 250, "TMaze": 280, "TMazeTwoBox": 280,
+                "SimToRealGoTo": 100, "SimToRealPush": 150}.get(task) or int(ta[0] or 8) * int(ta[1] or 8) * 24
 
     def _load_textures(self):
         from PIL import Image
-        for tid, name in enumerate(TEX_FILES):
+        for tid, name in enumerate(TEX_FILES[:self.L.mwb_num_textures(self.h)]):
             with Image.open(os.path.join(TEX_DIR, name + ".png")) as im:
                 img = np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
             _lib.check(self.L.mwb_set_texture(self.h, tid, img.shape[1], img.shape[0],
@@ -219,7 +228,8 @@ class BatchedMiniWorld:
         shapes = {"agent_pos": (count, 3), "agent_dir": (count,), "box_pos": (count, 3), "box_dir": (count,),
                   "box_color": (count, 3), "cam": (count, 4), "sky_color": (count, 3), "light_pos": (count, 3),
                   "light_color": (count, 3), "light_ambient": (count, 3),
-                  "box2_pos": (count, 3), "box2_dir": (count,), "box2_color": (count, 3)}
+                  "box2_pos": (count, 3), "box2_dir": (count,), "box2_color": (count, 3),
+                  "box_size": (count,), "box2_size": (count,), "goal_dist": (count,)}
         out = {k: np.zeros(s, np.float64) for k, s in shapes.items()}
         out.update({"step_count": np.zeros(count, np.int32), "rng_pos": np.zeros(count, np.int32),
                     "rng_keysum": np.zeros(count, np.uint32), "n_rooms": np.zeros(count, np.int32),

@@ -174,7 +174,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     if (!cfg || !out) return set_err(MWB_EINVAL, "mwb_create: null argument");
     if (cfg->abi_version != MWB_ABI_VERSION) return set_err(MWB_EINVAL, "mwb_create: abi_version mismatch");
     if (cfg->num_envs <= 0) return set_err(MWB_EINVAL, "mwb_create: num_envs must be > 0");
-    if (cfg->task < 0 || cfg->task > MWB_TASK_TMAZE_TWOBOX) return set_err(MWB_EINVAL, "mwb_create: unknown task");
+    if (cfg->task < 0 || cfg->task > MWB_TASK_SIM2REAL_PUSH) return set_err(MWB_EINVAL, "mwb_create: unknown task");
     if (cfg->obs_width <= 0 || cfg->obs_height <= 0 || cfg->obs_width > 1024 || cfg->obs_height > 1024)
         return set_err(MWB_EINVAL, "mwb_create: bad observation size");
     if (cfg->layout != MWB_LAYOUT_HWC && cfg->layout != MWB_LAYOUT_CWH) return set_err(MWB_EINVAL, "mwb_create: bad layout");
@@ -192,8 +192,12 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     d.want_depth = cfg->want_depth ? 1 : 0; d.layout = cfg->layout; d.domain_rand = cfg->domain_rand ? 1 : 0;
     d.auto_reset = cfg->no_auto_reset ? 0 : 1;
     { const char *dbg = getenv("MWB_DEBUG"); d.debug_flags = dbg ? atoi(dbg) : 0; }
-    static const double dflt[6][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}};
-    d.n_boxes = cfg->task == MWB_TASK_TMAZE_TWOBOX ? 2 : 1;
+    static const double dflt[8][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    const bool sim2real = cfg->task == MWB_TASK_SIM2REAL_GOTO || cfg->task == MWB_TASK_SIM2REAL_PUSH;
+    d.n_boxes = (cfg->task == MWB_TASK_TMAZE_TWOBOX || cfg->task == MWB_TASK_SIM2REAL_PUSH) ? 2 : 1;
+    d.n_tex = sim2real ? MWB_NUM_TEXTURES : 7;
+    d.no_ceiling = sim2real ? 1 : 0;
+    d.agent_radius = sim2real ? 0.11 : 0.4;   // simtorealgoto.py:50 / entity.py:451
     for (int i = 0; i < 4; i++) d.task_args[i] = cfg->task_args[i] != 0 ? cfg->task_args[i] : dflt[cfg->task][i];
     int mes = cfg->max_episode_steps;
     if (mes <= 0) {   // hallway.py:18, oneroom.py:14, fourrooms.py:15, maze.py:27
@@ -201,6 +205,8 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
         else if (d.task == MWB_TASK_ONEROOM) mes = 180;
         else if (d.task == MWB_TASK_FOURROOMS) mes = 250;
         else if (d.task == MWB_TASK_TMAZE || d.task == MWB_TASK_TMAZE_TWOBOX) mes = 280;   // tmaze.py:20,142
+        else if (d.task == MWB_TASK_SIM2REAL_GOTO) mes = 100;   // simtorealgoto.py:30
+        else if (d.task == MWB_TASK_SIM2REAL_PUSH) mes = 150;   // simtorealpush.py:29
         else mes = (int)d.task_args[0] * (int)d.task_args[1] * 24;
     }
     d.max_episode_steps = mes;
@@ -214,7 +220,8 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     else if (d.task == MWB_TASK_TMAZE || d.task == MWB_TASK_TMAZE_TWOBOX) {
         if (d.task_args[3] < 0 || d.task_args[3] > 9e15) { delete h; return set_err(MWB_EINVAL, "TMaze: bad sub_task_length"); }
         d.R_max = 2; d.S_max = 8;
-    } else {
+    } else if (sim2real) { d.R_max = 1; d.S_max = 4; }
+    else {
         int rows = (int)d.task_args[0], cols = (int)d.task_args[1];
         if (rows < 1 || cols < 1 || rows * cols > 4096) { delete h; return set_err(MWB_EINVAL, "Maze: bad num_rows / num_cols"); }
         d.R_max = 2 * rows * cols - 1; d.S_max = 4 * rows * cols;
@@ -224,7 +231,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     int rc = MWB_OK;
 #define A(ptr, n) if (rc == MWB_OK) rc = dev_alloc(h, &(ptr), (n))
     A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N * d.n_boxes); A(d.box_z, N * d.n_boxes); A(d.box_dir, N * d.n_boxes);
-    A(d.box_color, N * d.n_boxes * 3); A(d.episode_count, N); A(d.task_step_count, N); A(d.goal_idx, N); A(d.feature, N * 2); A(d.goal_pos, N * 3); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
+    A(d.box_color, N * d.n_boxes * 3); A(d.box_size, N * d.n_boxes); A(d.goal_dist, N); A(d.episode_count, N); A(d.task_step_count, N); A(d.goal_idx, N); A(d.feature, N * 2); A(d.goal_pos, N * 3); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
     A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.reset_set, N); A(d.reset_list, N); A(d.reset_count, (size_t)1);
     A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * MWB_ROOM_WORDS); A(d.segs, N * d.S_max * 4); A(d.frame, N * MWB_FRAME_WORDS);
     A(d.obs, N * d.W * d.H * 3);
@@ -335,12 +342,14 @@ extern "C" int mwb_set_texture(mwb_handle *h, int tex_id, int width, int height,
 
 static int upload_textures(mwb_handle *h) {
     HIP_TRY(hipSetDevice(h->cfg.device));
-    for (int i = 0; i < MWB_MAX_TEX; i++)
-        if (h->tex_w[i] == 0) return set_err(MWB_ESTATE, "render requested before all 7 textures were set (mwb_set_texture)");
+    const int n_tex = h->dev.n_tex;
+    for (int i = 0; i < n_tex; i++)
+        if (h->tex_w[i] == 0)
+            return set_err(MWB_ESTATE, "render requested before the task's " + std::to_string(n_tex) + " textures were set (mwb_set_texture)");
     std::vector<uint32_t> all;
     MwbTexDesc desc[MWB_MAX_TEX];
     memset(desc, 0, sizeof(desc));
-    for (int i = 0; i < MWB_MAX_TEX; i++) {
+    for (int i = 0; i < n_tex; i++) {
         desc[i].w = h->tex_w[i]; desc[i].h = h->tex_h[i]; desc[i].n_levels = (int)h->tex_levels[i].size();
         desc[i].sc_s = (float)(512.0 / h->tex_w[i]); desc[i].sc_t = (float)(512.0 / h->tex_h[i]);
         for (size_t l = 0; l < h->tex_levels[i].size(); l++) {
@@ -562,6 +571,10 @@ extern "C" int mwb_get_state(mwb_handle *h, int first, int count, mwb_state *o) 
         if (o->box2_dir) memset(o->box2_dir, 0, sizeof(double) * count);
         if (o->box2_color) memset(o->box2_color, 0, sizeof(double) * 3 * count);
     }
+    if ((rc = fetch(o->box_size, d.box_size, first, count, 1))) return rc;
+    if (d.n_boxes == 2) { if ((rc = fetch(o->box2_size, d.box_size + d.N, first, count, 1))) return rc; }
+    else if (o->box2_size) memset(o->box2_size, 0, sizeof(double) * count);
+    if ((rc = fetch(o->goal_dist, d.goal_dist, first, count, 1))) return rc;
     if ((rc = fetch(o->goal_idx, d.goal_idx, first, count, 1))) return rc;
     if ((rc = fetch(o->episode_count, d.episode_count, first, count, 1))) return rc;
     if ((rc = fetch(o->task_step_count, d.task_step_count, first, count, 1))) return rc;
@@ -602,6 +615,8 @@ extern "C" int mwb_set_agent(mwb_handle *h, int first, int count, const double *
     if (step_count) HIP_TRY(hipMemcpy(d.step_count + first, step_count, count * sizeof(int32_t), hipMemcpyHostToDevice));
     return MWB_OK;
 }
+
+extern "C" int mwb_num_textures(mwb_handle *h) { return h ? h->dev.n_tex : 0; }
 
 extern "C" int mwb_set_domain_rand(mwb_handle *h, int domain_rand) {
     if (!h) return set_err(MWB_EINVAL, "mwb_set_domain_rand: null handle");

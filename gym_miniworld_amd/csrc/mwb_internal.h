@@ -16,7 +16,7 @@
 #include "../../include/miniworld_batch.h"
 
 #define MWB_MT_WORDS 625   // 624 key words + pos
-#define MWB_MAX_TEX 7
+#define MWB_MAX_TEX MWB_NUM_TEXTURES
 #define MWB_MAX_LEVELS 12
 #define MWB_MAX_BOXES 2
 #define MWB_FRAME_WORDS 104
@@ -82,7 +82,10 @@ struct MwbParam { double def[3], lo[3], hi[3]; };
 struct MwbDev {
     int N, task, W, H, want_depth, layout, domain_rand, max_episode_steps;
     int R_max, S_max, auto_reset;
-    int n_boxes;       // 1, or 2 for MWB_TASK_TMAZE_TWOBOX (box 0 red, box 1 blue)
+    int n_boxes;       // 1, or 2 for MWB_TASK_TMAZE_TWOBOX (box 0 red, box 1 blue) and SIM2REAL_PUSH (red, yellow)
+    int n_tex;         // leading texture slots the task can draw (7, or MWB_NUM_TEXTURES for the sim-to-real rinks)
+    int no_ceiling;    // the task's rooms have no ceiling (sim-to-real rinks): selects the NOCEIL render kernels
+    double agent_radius;   // entity.py:451 (0.4), 0.11 in the sim-to-real rinks
     int debug_flags;   // MWB_DEBUG env var at mwb_create: bit0 = resolve every pixel with the full 8-sample path
     double task_args[4];
     MwbParam params[MWB_NPARAM];
@@ -90,6 +93,8 @@ struct MwbDev {
     double *agent_x, *agent_z, *agent_dir;
     double *box_x, *box_z, *box_dir;   // [n_boxes][N]
     double *box_color;      // [n_boxes][N][3]
+    double *box_size;       // [n_boxes][N] Box edge length (0.8 unless the task draws it per episode)
+    double *goal_dist;      // [N] SimToRealPush
     int64_t *episode_count, *task_step_count;   // [N] goal-alternation counters of the T-maze family (envs/tmaze.py)
     int32_t *goal_idx;      // [N]
     double *cam;            // [N][4] height, fwd_disp, pitch, fov_y

@@ -105,10 +105,9 @@ __device__ __forceinline__ bool seg_hit(const double *sg, double px, double pz, 
     return dist < radius;
 }
 
-#define AGENT_RADIUS 0.4   /* entity.py:451 */
 
-__device__ __forceinline__ double box_radius() {
-    double sx = 0.8, sz = 0.8;   // entity.py:367-378, Box(size=0.8)
+__device__ __forceinline__ double box_radius(double size) {
+    double sx = size, sz = size;   // entity.py:367-378, Box(size=s): radius = sqrt(sx^2 + sz^2) / 2
     return sqrt(sx * sx + sz * sz) / 2;
 }
 
@@ -129,8 +128,8 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
     int sc = 0, a = -1;
     double ax = 0, az = 0, adir = 0, nx = 0, nz = 0, turn_step = 0;
     const int NB = d.n_boxes;   // 1, or 2 in the two-box T-maze (entity order: red box, blue box, agent)
-    double bx[MWB_MAX_BOXES] = {0, 0}, bz[MWB_MAX_BOXES] = {0, 0};
-    const double brad = box_radius();
+    double bx[MWB_MAX_BOXES] = {0, 0}, bz[MWB_MAX_BOXES] = {0, 0}, brad[MWB_MAX_BOXES] = {0, 0};
+    const double arad = d.agent_radius;
     if (part == 0) {
         s_move[lane] = 0; s_hit[lane] = 0;
         if (dummy) {
@@ -139,23 +138,59 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
             d.feature[e * 2] = 0.0f; d.feature[e * 2 + 1] = 0.0f;   // info = {"feature": [0, 0]}
         }
         if (live) {
+            a = actions[e];
+            ax = d.agent_x[e]; az = d.agent_z[e]; adir = d.agent_dir[e];
+            bx[0] = d.box_x[e]; bz[0] = d.box_z[e]; brad[0] = box_radius(d.box_size[e]);
+            if (NB > 1) { bx[1] = d.box_x[(size_t)d.N + e]; bz[1] = d.box_z[(size_t)d.N + e]; brad[1] = box_radius(d.box_size[(size_t)d.N + e]); }
+            MtSerial g;
+            const bool use_rng = d.domain_rand || d.task == MWB_TASK_SIM2REAL_PUSH;
+            if (use_rng) g.load(d.rng + (size_t)e * MWB_MT_WORDS);
+            if (d.task == MWB_TASK_SIM2REAL_PUSH && a == 2) {
+                // "Very crude approximation [of] the physics of box pushing", simtorealpush.py:109-125, before
+                // MiniWorldEnv.step: a box the nominal forward move would touch is shoved away by the vector
+                // from that position to the box, unless it would then hit a wall, the other box or the agent,
+                // and turns by a random angle.  The rink has four wall segments: tested here, in wave 0.
+                const double fwd_dist = d.params[MWB_P_FORWARD_STEP].hi[0];
+                const double c = cos(adir), s = sin(adir);
+                const double npx = ax + c * fwd_dist, npz = az + (-s) * fwd_dist;
+                const int ns = d.n_segs[e];
+                for (int b = 0; b < 2; b++) {
+                    const double vx = bx[b] - npx, vz = bz[b] - npz;
+                    const double dist = sqrt((vx * vx + 0.0) + vz * vz);
+                    if (dist < arad + brad[b]) {
+                        const double qx = bx[b] + vx, qz = bz[b] + vz;
+                        bool hit = false;
+                        for (int i = 0; i < ns && !hit; i++) {
+                            double q[4];
+                            for (int cc = 0; cc < 4; cc++) q[cc] = d.segs[(size_t)(i * 4 + cc) * d.N + e];
+                            hit = seg_hit(q, qx, qz, brad[b]);
+                        }
+                        if (!hit) {   // entities in list order: box 0, box 1, agent (itself skipped)
+                            const int o = 1 - b;
+                            double ddx = bx[o] - qx, ddz = bz[o] - qz;
+                            hit = sqrt(ddx * ddx + 0.0 + ddz * ddz) < brad[b] + brad[o];
+                            if (!hit) { ddx = ax - qx; ddz = az - qz; hit = sqrt(ddx * ddx + 0.0 + ddz * ddz) < brad[b] + arad; }
+                        }
+                        if (!hit) {
+                            bx[b] = qx; bz[b] = qz;
+                            const size_t be = (size_t)b * d.N + e;
+                            d.box_x[be] = qx; d.box_z[be] = qz;
+                            d.box_dir[be] += g.uniform(-3.141592653589793 / 5, 3.141592653589793 / 5);
+                        }
+                    }
+                }
+            }
             sc = d.step_count[e] + 1;   // miniworld.py:663
             d.step_count[e] = sc;
             double fwd_step = d.params[MWB_P_FORWARD_STEP].def[0];
             double fwd_drift = d.params[MWB_P_FORWARD_DRIFT].def[0];
             turn_step = d.params[MWB_P_TURN_STEP].def[0];
             if (d.domain_rand) {   // miniworld.py:665-668: three draws every step, whatever the action
-                MtSerial g;
-                g.load(d.rng + (size_t)e * MWB_MT_WORDS);
                 fwd_step = g.uniform(d.params[MWB_P_FORWARD_STEP].lo[0], d.params[MWB_P_FORWARD_STEP].hi[0]);
                 fwd_drift = g.uniform(d.params[MWB_P_FORWARD_DRIFT].lo[0], d.params[MWB_P_FORWARD_DRIFT].hi[0]);
                 turn_step = g.uniform(d.params[MWB_P_TURN_STEP].lo[0], d.params[MWB_P_TURN_STEP].hi[0]);
-                g.store();
             }
-            a = actions[e];
-            ax = d.agent_x[e]; az = d.agent_z[e]; adir = d.agent_dir[e];
-            bx[0] = d.box_x[e]; bz[0] = d.box_z[e];
-            if (NB > 1) { bx[1] = d.box_x[(size_t)d.N + e]; bz[1] = d.box_z[(size_t)d.N + e]; }
+            if (use_rng) g.store();
             if (a == 2 || a == 3) {   // move_agent, miniworld.py:608-633
                 double fd = (a == 2) ? fwd_step : -fwd_step;
                 double c = cos(adir), s = sin(adir);
@@ -177,7 +212,7 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
         const size_t N = (size_t)d.N;
         const int ns = d.n_segs[e];
         bool hit = false;
-        const double guard = AGENT_RADIUS + 1e-9;
+        const double guard = arad + 1e-9;
         for (int i0 = part * 8; i0 < ns; i0 += 8 * STEP_PARTS) {   // 8 segments (32 coalesced loads) in flight, then the tests
             double q[8][4];
 #pragma unroll
@@ -190,7 +225,7 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
             for (int k = 0; k < 8; k++) {
                 bool nearby = px >= fmin(q[k][0], q[k][2]) - guard && px <= fmax(q[k][0], q[k][2]) + guard &&
                               pz >= fmin(q[k][1], q[k][3]) - guard && pz <= fmax(q[k][1], q[k][3]) + guard;
-                if (nearby) hit = seg_hit(q[k], px, pz, AGENT_RADIUS) || hit;
+                if (nearby) hit = seg_hit(q[k], px, pz, arad) || hit;
             }
         }
         if (hit) s_hit[lane] = 1;   // every writer stores the same value
@@ -202,7 +237,7 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
         for (int b = 0; b < NB && !hit; b++) {   // entity test, miniworld.py:946-957 (boxes are the only other entities)
             double ddx = bx[b] - nx, ddz = bz[b] - nz;
             double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
-            hit = dist < AGENT_RADIUS + brad;
+            hit = dist < arad + brad[b];
         }
         if (!hit) { ax = nx; az = nz; d.agent_x[e] = ax; d.agent_z[e] = az; }
     } else if (a == 0 || a == 1) {   // turn_agent, miniworld.py:635-656
@@ -216,13 +251,12 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
     if (sc >= d.max_episode_steps) { done = 1; r = 0.0; }   // miniworld.py:708-711
     {   // near(box), miniworld.py:961-971, then the task rule (e.g. envs/maze.py:106-113)
         const double max_forward_step = d.params[MWB_P_FORWARD_STEP].hi[0];   // miniworld.py:569
-        const double thr = brad + AGENT_RADIUS + 1.1 * max_forward_step;
         bool near[MWB_MAX_BOXES];
 #pragma unroll
         for (int b = 0; b < MWB_MAX_BOXES; b++) {
             double ddx = bx[b] - ax, ddz = bz[b] - az;
             double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
-            near[b] = b < NB && dist < thr;
+            near[b] = b < NB && dist < brad[b] + arad + 1.1 * max_forward_step;
         }
         const double rw = 1.0 - 0.2 * ((double)sc / d.max_episode_steps);   // _reward, miniworld.py:1012
         if (d.task == MWB_TASK_TMAZE_TWOBOX) {   // tmaze.py:196-208 / 299-320: goal box first, then the penalty box
@@ -235,6 +269,9 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
                 d.task_step_count[e] += 1;
             }
             d.goal_pos[e * 3] = g ? bx[1] : bx[0]; d.goal_pos[e * 3 + 1] = 0.0; d.goal_pos[e * 3 + 2] = g ? bz[1] : bz[0];   // info['goal_pos']
+        } else if (d.task == MWB_TASK_SIM2REAL_PUSH) {   // simtorealpush.py:129-133: the boxes are close enough
+            const double ddx = bx[0] - bx[1], ddz = bz[0] - bz[1];
+            if (sqrt((ddx * ddx + 0.0) + ddz * ddz) < d.goal_dist[e]) { r = 1.0; done = 1; }
         } else {
             if (near[0]) { r += rw; done = 1; }
             if (d.task == MWB_TASK_TMAZE) { d.goal_pos[e * 3] = bx[0]; d.goal_pos[e * 3 + 1] = 0.0; d.goal_pos[e * 3 + 2] = bz[0]; }
@@ -269,9 +306,10 @@ struct alignas(16) WRoom {
     int tex_fam[3], tex_id[3];      // wall, floor, ceil
 };
 
-enum { TEXF_FLOOR_TILES_BW = 0, TEXF_CONCRETE, TEXF_CONCRETE_TILES, TEXF_BRICK_WALL };
-__constant__ int c_texf_first[4] = {0, 1, 5, 6};
-__constant__ int c_texf_count[4] = {1, 4, 1, 1};   // <name>_<i>.png variants, opengl.py:50-58
+enum { TEXF_FLOOR_TILES_BW = 0, TEXF_CONCRETE, TEXF_CONCRETE_TILES, TEXF_BRICK_WALL,
+       TEXF_CARDBOARD, TEXF_WOOD, TEXF_WOOD_PLANKS, TEXF_DRYWALL, TEXF_STUCCO, TEXF_CEILING_TILES };
+__constant__ int c_texf_first[10] = {0, 1, 5, 6, 7, 11, 13, 14, 15, 16};
+__constant__ int c_texf_count[10] = {1, 4, 1, 1, 4, 2, 1, 1, 1, 1};   // <name>_<i>.png variants, opengl.py:50-58
 
 struct WorldGen {
     WRoom *rooms;
@@ -494,6 +532,7 @@ struct WorldGen {
         double dir = 0, min_x = 0, max_x = 0, min_z = 0, max_z = 0;
         int n_others = 0;
         double other_x[MWB_MAX_BOXES] = {0, 0}, other_z[MWB_MAX_BOXES] = {0, 0}, other_radius = 0;
+        double other_radius2 = -1;   // radius of the second other entity when it differs (sim-to-real boxes)
     };
     __device__ void place_entity(double radius, bool has_other, double other_x, double other_z, double other_radius,
                                  bool has_dir, double dir_in, bool has_min_x, double min_x, bool has_max_x, double max_x,
@@ -535,7 +574,7 @@ struct WorldGen {
             for (int k = 0; k < opt.n_others; k++) {
                 double ddx = opt.other_x[k] - px, ddz = opt.other_z[k] - pz;
                 double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
-                if (dist < radius + opt.other_radius) blocked = true;
+                if (dist < radius + ((k == 1 && opt.other_radius2 >= 0) ? opt.other_radius2 : opt.other_radius)) blocked = true;
             }
             if (blocked) continue;
             out_dir = has_dir ? dir_in : rng.uniform(-3.141592653589793, 3.141592653589793);
@@ -575,7 +614,8 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
 
     double box_x = 0, box_z = 0, box_dir = 0, ag_x = 0, ag_z = 0, ag_dir = 0;
     double box2_x = 0, box2_z = 0, box2_dir = 0;
-    double brad = box_radius();
+    double brad = box_radius(0.8), brad2 = brad, box_s = 0.8, box2_s = d.n_boxes > 1 ? 0.8 : 0.0, goal_dist = 0.0;
+    const double arad = d.agent_radius;
     // reset() overrides of the T-maze family run before MiniWorldEnv.reset (every lane computes the same)
     int goal_idx = d.goal_idx[e];
     long long episode_count = d.episode_count[e];
@@ -590,7 +630,50 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             goal_idx = (goal_idx + 1) % 2;                               // never cleared (the reference assigns a misspelt name)
         }
     }
-    if (d.task == MWB_TASK_TMAZE || d.task == MWB_TASK_TMAZE_TWOBOX) {   // envs/tmaze.py:27-61, 151-194
+    if (d.task == MWB_TASK_SIM2REAL_GOTO || d.task == MWB_TASK_SIM2REAL_PUSH) {   // envs/simtorealgoto.py:40-82, simtorealpush.py:39-107
+        const bool push = d.task == MWB_TASK_SIM2REAL_PUSH;
+        const double size = push ? w.rng.uniform(1.6, 1.7) : w.rng.uniform(1, 2);
+        const double wall_height = push ? w.rng.uniform(0.42, 0.50) : w.rng.uniform(0.20, 0.50);
+        box_s = push ? w.rng.uniform(0.075, 0.090) : w.rng.uniform(0.07, 0.12);
+        box2_s = push ? w.rng.uniform(0.075, 0.090) : 0.0;
+        brad = box_radius(box_s); brad2 = box_radius(box2_s);
+        // RandGen.choice -> np_random.choice(len) -> randint (random.py:33-41)
+        const int fi = w.rng.randint(0, 3);
+        const int floor_fam = fi == 0 ? TEXF_CARDBOARD : fi == 1 ? TEXF_WOOD : TEXF_WOOD_PLANKS;
+        int wall_fam;
+        if (push) {
+            const int wi = w.rng.randint(0, 4);
+            wall_fam = wi == 0 ? TEXF_DRYWALL : wi == 1 ? TEXF_STUCCO : wi == 2 ? TEXF_CONCRETE_TILES : TEXF_CEILING_TILES;
+        } else {
+            const int wi = w.rng.randint(0, 5);
+            wall_fam = wi == 0 ? TEXF_DRYWALL : wi == 1 ? TEXF_STUCCO : wi == 2 ? TEXF_CARDBOARD : wi == 3 ? TEXF_CONCRETE_TILES : TEXF_CEILING_TILES;
+        }
+        double ox[4] = {size, size, 0, 0}, oz[4] = {size, 0, 0, size};
+        w.add_room(ox, oz, wall_height, wall_fam, floor_fam, TEXF_CONCRETE_TILES);   // no_ceiling: the NOCEIL render kernels
+        w.gen_static_data(dr, d.S_max);
+        WorldGen::PlaceOpt o;
+        if (push) {
+            goal_dist = 1.5 * (box_s + box2_s);
+            const double min_pos = 2 * d.params[MWB_P_BOT_RADIUS].hi[0], max_pos = size - 2 * d.params[MWB_P_BOT_RADIUS].hi[0];
+            o.has_min_x = o.has_max_x = o.has_min_z = o.has_max_z = true;
+            o.min_x = o.min_z = min_pos; o.max_x = o.max_z = max_pos;
+            for (int attempt = 0; attempt < 100000; attempt++) {   // boxes can't start too close to each other
+                o.n_others = 0;
+                w.place_entity_ex(brad, o, box_x, box_z, box_dir);
+                o.n_others = 1; o.other_x[0] = box_x; o.other_z[0] = box_z; o.other_radius = brad;
+                w.place_entity_ex(brad2, o, box2_x, box2_z, box2_dir);
+                const double ddx = box_x - box2_x, ddz = box_z - box2_z;
+                if (sqrt((ddx * ddx + 0.0) + ddz * ddz) > goal_dist) break;
+                if (attempt == 99999) w.fail = true;
+            }
+        } else {
+            w.place_entity_ex(brad, o, box_x, box_z, box_dir);
+        }
+        WorldGen::PlaceOpt a;
+        a.n_others = d.n_boxes; a.other_radius = brad; a.other_radius2 = brad2;
+        a.other_x[0] = box_x; a.other_z[0] = box_z; a.other_x[1] = box2_x; a.other_z[1] = box2_z;
+        w.place_entity_ex(arad, a, ag_x, ag_z, ag_dir);
+    } else if (d.task == MWB_TASK_TMAZE || d.task == MWB_TASK_TMAZE_TWOBOX) {   // envs/tmaze.py:27-61, 151-194
         w.add_rect_room(-1, 8, -2, 2, TEXF_CONCRETE);
         int r2 = w.add_rect_room(8, 12, -8, 8, TEXF_CONCRETE);
         const double r2min = rooms[r2].min_z, r2max = rooms[r2].max_z;
@@ -625,7 +708,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         a.dir = w.rng.uniform(-3.141592653589793 / 4, 3.141592653589793 / 4);   // drawn before the placement loop
         a.n_others = d.n_boxes; a.other_radius = brad;
         a.other_x[0] = box_x; a.other_z[0] = box_z; a.other_x[1] = box2_x; a.other_z[1] = box2_z;
-        w.place_entity_ex(AGENT_RADIUS, a, ag_x, ag_z, ag_dir);
+        w.place_entity_ex(arad, a, ag_x, ag_z, ag_dir);
     } else if (d.task == MWB_TASK_HALLWAY) {   // envs/hallway.py:25-42
         double length = d.task_args[0];
         int r = w.add_rect_room(-1, -1 + length, -2, 2, TEXF_CONCRETE);
@@ -633,13 +716,13 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         w.gen_static_data(dr, d.S_max);
         w.place_entity(brad, false, 0, 0, 0, false, 0, true, rmax - 2, false, 0, box_x, box_z, box_dir);
         double adir = w.rng.uniform(-3.141592653589793 / 4, 3.141592653589793 / 4);
-        w.place_entity(AGENT_RADIUS, true, box_x, box_z, brad, true, adir, false, 0, true, rmax - 2, ag_x, ag_z, ag_dir);
+        w.place_entity(arad, true, box_x, box_z, brad, true, adir, false, 0, true, rmax - 2, ag_x, ag_z, ag_dir);
     } else if (d.task == MWB_TASK_ONEROOM) {   // envs/oneroom.py:26-35
         double size = d.task_args[0];
         w.add_rect_room(0, size, 0, size, TEXF_CONCRETE);
         w.gen_static_data(dr, d.S_max);
         w.place_entity(brad, false, 0, 0, 0, false, 0, false, 0, false, 0, box_x, box_z, box_dir);
-        w.place_entity(AGENT_RADIUS, true, box_x, box_z, brad, false, 0, false, 0, false, 0, ag_x, ag_z, ag_dir);
+        w.place_entity(arad, true, box_x, box_z, brad, false, 0, false, 0, false, 0, ag_x, ag_z, ag_dir);
     } else if (d.task == MWB_TASK_FOURROOMS) {   // envs/fourrooms.py:22-52
         w.add_rect_room(-7, -1, 1, 7, TEXF_CONCRETE);
         w.add_rect_room(1, 7, 1, 7, TEXF_CONCRETE);
@@ -651,7 +734,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         w.connect_rooms(3, 0, 1, -5, -3, true, 2.2);
         w.gen_static_data(dr, d.S_max);
         w.place_entity(brad, false, 0, 0, 0, false, 0, false, 0, false, 0, box_x, box_z, box_dir);
-        w.place_entity(AGENT_RADIUS, true, box_x, box_z, brad, false, 0, false, 0, false, 0, ag_x, ag_z, ag_dir);
+        w.place_entity(arad, true, box_x, box_z, brad, false, 0, false, 0, false, 0, ag_x, ag_z, ag_dir);
     } else {   // envs/maze.py:34-104, recursive backtracker with an explicit stack
         int num_rows = (int)d.task_args[0], num_cols = (int)d.task_args[1];
         double room_size = d.task_args[2], gap = 0.25;
@@ -703,7 +786,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         __syncthreads();
         w.gen_static_data(dr, d.S_max);
         w.place_entity(brad, false, 0, 0, 0, false, 0, false, 0, false, 0, box_x, box_z, box_dir);
-        w.place_entity(AGENT_RADIUS, true, box_x, box_z, brad, false, 0, false, 0, false, 0, ag_x, ag_z, ag_dir);
+        w.place_entity(arad, true, box_x, box_z, brad, false, 0, false, 0, false, 0, ag_x, ag_z, ag_dir);
     }
     // miniworld.py:561-573: sky / light, then entity.randomize in list order (box, agent)
     double sky[3], lpos[3], lcol[3], lamb[3], bias[3], cam[4];
@@ -735,14 +818,15 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         }
         if (d.n_boxes > 1) {   // the blue box, second plane of the box arrays
             const size_t N = (size_t)d.N;
-            d.box_x[N + e] = box2_x; d.box_z[N + e] = box2_z; d.box_dir[N + e] = box2_dir;
-            const double blue[3] = {0.0, 0.0, 1.0};
+            d.box_x[N + e] = box2_x; d.box_z[N + e] = box2_z; d.box_dir[N + e] = box2_dir; d.box_size[N + e] = box2_s;
+            const double blue[3] = {0.0, 0.0, 1.0}, yellow[3] = {1.0, 1.0, 0.0};   // COLORS, entity.py:8-15
             for (int k = 0; k < 3; k++) {
-                double v = blue[k] + bias2[k];
+                double v = (d.task == MWB_TASK_SIM2REAL_PUSH ? yellow[k] : blue[k]) + bias2[k];
                 d.box_color[(N + e) * 3 + k] = v < 0 ? 0 : (v > 1 ? 1 : v);
             }
         }
         d.goal_idx[e] = goal_idx; d.episode_count[e] = episode_count;
+        d.box_size[e] = box_s; d.goal_dist[e] = goal_dist;
         for (int k = 0; k < 4; k++) d.cam[e * 4 + k] = cam[k];
         d.step_count[e] = 0;
         d.n_rooms[e] = w.fail ? -1 : w.n_rooms;
@@ -864,7 +948,8 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     for (int k = 0; k < 6; k++)   // world normal = R_y(dir) n_local (glRotatef about +Y)
         lit_color(L, amb, dif, ln[k][0] * bc + ln[k][2] * bs, ln[k][1], -ln[k][0] * bs + ln[k][2] * bc, bcol, fc + FC_LIT_BOX + 3 * k);
     float bpos[3] = {(float)d.box_x[be], 0.0f, (float)d.box_z[be]};
-    float hx = (float)(0.8 / 2), hz = (float)(0.8 / 2), sy = (float)0.8;
+    const double bsz = d.box_size[be];   // Box.render: extents +-sx/2, 0..sy, +-sz/2 (entity.py:385-408)
+    float hx = (float)(bsz / 2), hz = (float)(bsz / 2), sy = (float)bsz;
     fc[FC_BOX_POS] = bpos[0]; fc[FC_BOX_POS + 1] = bpos[1]; fc[FC_BOX_POS + 2] = bpos[2];
     fc[FC_BOX_C] = bc; fc[FC_BOX_S] = bs; fc[FC_BOX_HX] = hx; fc[FC_BOX_HZ] = hz; fc[FC_BOX_SY] = sy;
     float ro[3] = {eye[0] - bpos[0], eye[1] - bpos[1], eye[2] - bpos[2]};
@@ -923,7 +1008,9 @@ __device__ __forceinline__ void make_ray(const Cam &c, float wx, float wy, float
 // All LDS reads of a step are issued together (both candidate sides are fetched) and the loop has
 // one exit.  With PATH the sequence of sides crossed is returned as 2 bits per crossing under a leading 1
 // (exact for up to 15 crossings; longer paths are flagged by bit 31 and treated as never equal).
-template <bool PATH>
+// NOCEIL: the task's rooms have no ceiling polygon (Room._render, miniworld.py:406): a ray never stops at the
+// ceiling plane and one that reaches a wall plane above the wall's top edge sees the sky.
+template <bool PATH, bool NOCEIL>
 __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms, int n_rooms, int room, const float *o,
                                                 const float *dv, float &t_hit, uint32_t &path) {
     t_hit = INFINITY;
@@ -954,7 +1041,7 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
         const bool usex = tx <= tz;
         const float ts = usex ? tx : tz;
         const int s = usex ? sx : sz;
-        const float tc = ypos ? (height - o[1]) * iy : INFINITY;
+        const float tc = (!NOCEIL && ypos) ? (height - o[1]) * iy : INFINITY;
         const bool hit_floor = tfloor <= ts;
         const bool hit_ceil = tc <= ts;
         const bool escaped = !(ts < INFINITY);
@@ -967,6 +1054,7 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
             // same precedence as the sequential tests of the spec: floor, ceiling, escape, wall
             if (hit_floor) { t_hit = tfloor; key = MAKE_KEY(KIND_FLOOR, 0, room); }
             else if (hit_ceil) { t_hit = tc; key = MAKE_KEY(KIND_CEIL, 0, room); }
+            else if (NOCEIL && !escaped && !(y < height)) { /* over the wall: sky */ }
             else if (!escaped) {
                 t_hit = ts; key = MAKE_KEY(KIND_WALL, s, room);
                 // a wall with a portal is not convex: tag the convex piece (left / right / above / below the
@@ -1082,7 +1170,7 @@ __device__ __forceinline__ bool plane_texcoord(int axis, float plane, float u_or
 }
 #pragma clang fp contract(off)
 
-template <int NBOX>
+template <int NBOX, bool NOCEIL>
 struct RenderCtx {
     const float *rooms, *fc;
     const TexLds *tex;
@@ -1198,7 +1286,7 @@ struct RenderCtx {
             float dv[3], th;
             uint32_t path;
             make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
-            uint32_t key = trace_rooms<false>(rooms, n_rooms, cam_room, cam.eye, dv, th, path);
+            uint32_t key = trace_rooms<false, NOCEIL>(rooms, n_rooms, cam_room, cam.eye, dv, th, path);
             // conservative bounding-sphere cull, then the exact slab test; boxes in entity order, a later
             // box wins only when strictly nearer
             const float dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
@@ -1283,7 +1371,7 @@ struct RenderCtx {
 #define QUEUE_CAP 128
 
 // Renders one env with the whole workgroup (called once per workgroup, or per list entry on the side stream).
-template <int THREADS, int NBOX>
+template <int THREADS, int NBOX, bool NOCEIL>
 __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigned char *smem) {
     const int tid = threadIdx.x;
     const int W = d.W, H = d.H;
@@ -1292,7 +1380,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
     float *rooms = (float *)smem;
     size_t off = ((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15;
     float *fc = (float *)(smem + off); off += MWB_FRAME_WORDS * 4;
-    TexLds *tex = (TexLds *)(smem + off); off += sizeof(TexLds) * MWB_MAX_TEX;
+    TexLds *tex = (TexLds *)(smem + off); off += sizeof(TexLds) * d.n_tex;
     int *cam_room_s = (int *)(smem + off); off += 16 + 2 * (THREADS / WAVE) * sizeof(int);   // + leftover counts
     uint16_t *queues = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
     uint32_t *ikeys = (uint32_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint32_t);
@@ -1307,11 +1395,11 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
         for (int i = tid; i < MWB_FRAME_WORDS; i += THREADS) fc[i] = fsrc[i];
         const uint32_t *tsrc = (const uint32_t *)d.tex_desc;
         uint32_t *tdst = (uint32_t *)tex;
-        for (int i = tid; i < (int)(sizeof(TexLds) * MWB_MAX_TEX / 4); i += THREADS) tdst[i] = tsrc[i];
+        for (int i = tid; i < (int)(sizeof(TexLds) / 4) * d.n_tex; i += THREADS) tdst[i] = tsrc[i];
         if (tid == 0) { cam_room_s[0] = 0x7fffffff; cam_room_s[1] = 0; }   // eye room (atomicMin), work-item counter
     }
     __syncthreads();
-    RenderCtx<NBOX> ctx;
+    RenderCtx<NBOX, NOCEIL> ctx;
     ctx.rooms = rooms; ctx.fc = fc; ctx.tex = tex; ctx.texels = d.texels; ctx.fb = fb;
     ctx.depth = d.want_depth ? d.depth + (size_t)e * W * H : nullptr;
     ctx.n_rooms = n_rooms; ctx.W = W; ctx.H = H; ctx.layout = d.layout;
@@ -1383,7 +1471,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
             float dv[3], th;
             uint32_t path;
             make_ray(cam, (float)(x0 + ci), (float)(H - crow), dv);
-            uint32_t key = trace_rooms<true>(rooms, n_rooms, ctx.cam_room, cam.eye, dv, th, path);
+            uint32_t key = trace_rooms<true, NOCEIL>(rooms, n_rooms, ctx.cam_room, cam.eye, dv, th, path);
             const uint32_t kind = key & 7u;
             bool ok = (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
             // the pixel whose bottom-left corner this lane traced: corners (crow-1, ci), (crow-1, ci+1),
@@ -1479,19 +1567,19 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
 // MODE 0: every env; 1: only the envs regenerated this step (side stream, through the compact list);
 // 2: all the others (bulk).  A template parameter so that the three launches carry distinct kernel names
 // in profiles.
-template <int THREADS, int MODE, int NBOX>
+template <int THREADS, int MODE, int NBOX, bool NOCEIL = false>
 __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (MODE == 1) {
         const int count = d.reset_count[0];
         for (int li = blockIdx.x; li < count; li += gridDim.x) {
-            render_env<THREADS, NBOX>(d, d.reset_list[li], smem);
+            render_env<THREADS, NBOX, NOCEIL>(d, d.reset_list[li], smem);
             __syncthreads();   // LDS is reused by the next env of this block
         }
     } else {
         const int e = blockIdx.x;
         if (MODE == 2 && d.reset_set[e]) return;   // block-uniform
-        render_env<THREADS, NBOX>(d, e, smem);
+        render_env<THREADS, NBOX, NOCEIL>(d, e, smem);
     }
 }
 
@@ -1547,7 +1635,7 @@ __global__ void intersect_kernel(MwbDev d, int e, double x, double z, double rad
     }
     for (int b = 0; b < d.n_boxes && !res; b++) {
         double ddx = d.box_x[(size_t)b * d.N + e] - x, ddz = d.box_z[(size_t)b * d.N + e] - z;
-        if (sqrt(ddx * ddx + 0.0 + ddz * ddz) < radius + box_radius()) res = 2 + b;
+        if (sqrt(ddx * ddx + 0.0 + ddz * ddz) < radius + box_radius(d.box_size[(size_t)b * d.N + e])) res = 2 + b;
     }
     *result = res;
 }
@@ -1560,7 +1648,7 @@ size_t mwb_reset_lds_bytes(const MwbDev &d) {
     return (b + 15) & ~(size_t)15;
 }
 size_t mwb_render_lds_bytes(const MwbDev &d) {
-    size_t b = (((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15) + MWB_FRAME_WORDS * 4 + sizeof(TexLds) * MWB_MAX_TEX + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
+    size_t b = (((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15) + MWB_FRAME_WORDS * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
                (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)d.W * d.H * 3;
     b += (size_t)(d.debug_flags >> 8) * 1024;   // MWB_DEBUG bits 8+: KiB of LDS padding (occupancy experiments)
     return (b + 15) & ~(size_t)15;
@@ -1605,6 +1693,18 @@ void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
     const dim3 g(d.N), b(RENDER_THREADS);
     const size_t lds = mwb_render_lds_bytes(d);
     const dim3 gl(d.N < LIST_GRID ? d.N : LIST_GRID);
+    if (d.no_ceiling) {   // the sim-to-real rinks: their own instantiations
+        if (d.n_boxes == 2) {
+            if (mode == 1) render_kernel<RENDER_THREADS, 1, 2, true><<<gl, b, lds, s>>>(d);
+            else if (mode == 2) render_kernel<RENDER_THREADS, 2, 2, true><<<g, b, lds, s>>>(d);
+            else render_kernel<RENDER_THREADS, 0, 2, true><<<g, b, lds, s>>>(d);
+        } else {
+            if (mode == 1) render_kernel<RENDER_THREADS, 1, 1, true><<<gl, b, lds, s>>>(d);
+            else if (mode == 2) render_kernel<RENDER_THREADS, 2, 1, true><<<g, b, lds, s>>>(d);
+            else render_kernel<RENDER_THREADS, 0, 1, true><<<g, b, lds, s>>>(d);
+        }
+        return;
+    }
     if (d.n_boxes == 2) {   // the two-box T-maze: its own instantiation, so that the one-box kernels stay as they are
         if (mode == 1) render_kernel<RENDER_THREADS, 1, 2><<<gl, b, lds, s>>>(d);
         else if (mode == 2) render_kernel<RENDER_THREADS, 2, 2><<<g, b, lds, s>>>(d);

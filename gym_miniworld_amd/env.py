@@ -47,17 +47,19 @@ class MiniWorldEnv:
                                    obs_height=obs_height, want_depth=True, layout="HWC", device=device,
                                    auto_reset=False, **kwargs)
         self.actions = MiniWorldEnv.Actions
-        self.action_space = Discrete(self.actions.move_forward + 1)   # e.g. envs/hallway.py:23
+        self.action_space = Discrete(self._b.n_actions)   # e.g. envs/hallway.py:23; simtorealpush.py:37 adds move_back
         self.observation_space = Box(0, 255, (obs_height, obs_width, 3), np.uint8)
         self.max_episode_steps = self._b.max_episode_steps
         self.params = self._b.params
-        self.agent, self.box = _Ent(0.4, 1.6), _Ent(float(np.sqrt(0.8 * 0.8 + 0.8 * 0.8) / 2), 0.8)
+        self.agent, self.box = _Ent(self._b.agent_radius, 1.6), _Ent(float(np.sqrt(0.8 * 0.8 + 0.8 * 0.8) / 2), 0.8)
         self.entities = [self.box, self.agent]
         if self._b.n_boxes == 2:   # the two-box T-maze, tmaze.py:166-169
             self.red_box, self.blue_box = self.box, _Ent(self.box.radius, 0.8)
             self.boxes = [self.red_box, self.blue_box]
             self.entities = [self.red_box, self.blue_box, self.agent]
             self.goal_box_idx, self.penalty_box_idx = 0, 1
+            if self._b.task == "SimToRealPush":   # simtorealpush.py:88-99
+                self.box1, self.box2 = self.red_box, self.blue_box
         self.rooms, self.step_count = [], 0
         self._seeded = False
         if seed is not None:
@@ -83,9 +85,15 @@ class MiniWorldEnv:
         self.agent.pos, self.agent.dir = st["agent_pos"][0].copy(), float(st["agent_dir"][0])
         self.box.pos, self.box.dir = st["box_pos"][0].copy(), float(st["box_dir"][0])
         self.box.color_vec = st["box_color"][0].copy()
+        s0 = float(st["box_size"][0])
+        self.box.radius, self.box.height, self.box.size = float(np.sqrt(s0 * s0 + s0 * s0) / 2), s0, np.array([s0, s0, s0])
         if self._b.n_boxes == 2:
             self.blue_box.pos, self.blue_box.dir = st["box2_pos"][0].copy(), float(st["box2_dir"][0])
             self.blue_box.color_vec = st["box2_color"][0].copy()
+            s1 = float(st["box2_size"][0])
+            self.blue_box.radius, self.blue_box.height = float(np.sqrt(s1 * s1 + s1 * s1) / 2), s1
+            self.blue_box.size = np.array([s1, s1, s1])
+            self.goal_dist = float(st["goal_dist"][0])
             self.goal_box_idx = int(st["goal_idx"][0])
             self.penalty_box_idx = 1 - self.goal_box_idx
         (self.agent.cam_height, self.agent.cam_fwd_disp, self.agent.cam_pitch, self.agent.cam_fov_y) = st["cam"][0]

@@ -96,7 +96,7 @@ class MiniWorldVecEnv(VecEnv):
             shape = (shape[0] * self.nstack,) + shape[1:]
             # fused in the library: shift + zero-on-done + append + uint8->float in one HBM pass
             self.stackedobs = b.stack_enable(self.nstack, "float32" if to_float else "uint8")
-        VecEnv.__init__(self, num_envs, Box(0, 255, shape, np.float32 if to_float else np.uint8), Discrete(3))
+        VecEnv.__init__(self, num_envs, Box(0, 255, shape, np.float32 if to_float else np.uint8), Discrete(b.n_actions))
         self.device = b.device
         self.feature_info = feature_info
         self._infos_plain = tuple((_DUMMY_INFO if feature_info else _EMPTY_INFO) for _ in range(num_envs))

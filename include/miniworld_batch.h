@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MWB_ABI_VERSION 2
+#define MWB_ABI_VERSION 3
 
 enum { MWB_OK = 0, MWB_EINVAL = -1, MWB_EHIP = -2, MWB_ENOMEM = -3, MWB_ESTATE = -4 };
 
@@ -41,7 +41,16 @@ enum { MWB_TASK_HALLWAY = 0,   /* envs/hallway.py   task_args = {length}        
         * sub_task_length-th reset (TMazeTwoBoxDynamic.reset 210-217); rule 1 = at every reset once more than
         * sub_task_length steps have been taken - the counter is never cleared, as in the reference - and
         * info['feature'] = [near(blue), near(red)] is produced (*Features*.step 299-320, reset 322-330) */
-       MWB_TASK_TMAZE_TWOBOX = 5 };
+       MWB_TASK_TMAZE_TWOBOX = 5,
+       /* the sim-to-real rinks, envs/simtorealgoto.py and envs/simtorealpush.py: one square room of random size
+        * without ceiling (low walls, sky above), random wall / floor texture families, a robot of radius 0.11
+        * and per-episode box sizes; pass their `sim_params` table (params.py sim_to_real_params) and
+        * domain_rand = 1 (the classes force it).  GoTo: reach the red box (Discrete(3)).  Push: drive the red box
+        * to the yellow one - a forward move first shoves any box it would touch (simtorealpush.py:109-125, with an
+        * RNG draw for the box's new heading), move_back is allowed (Discrete(4)), reward 1 when the boxes are
+        * within goal_dist = 1.5 (size1 + size2).  task_args = {} */
+       MWB_TASK_SIM2REAL_GOTO = 6,
+       MWB_TASK_SIM2REAL_PUSH = 7 };
 
 /* observation layouts */
 enum { MWB_LAYOUT_HWC = 0,  /* [N,H,W,3]  MiniWorldEnv.observation_space, miniworld.py:473-478 */
@@ -111,6 +120,10 @@ typedef struct mwb_state {
     int32_t *goal_idx;      /* [count] current_goal (tmaze.py:91) / goal_box_idx (tmaze.py:135) */
     int64_t *episode_count; /* [count] tmaze.py:80,130 (1 after construction: MiniWorldEnv.__init__ resets once) */
     int64_t *task_step_count; /* [count] tmaze.py:240 */
+    /* sim-to-real rinks: per-episode sizes (the other tasks: 0.8, 0.8 or 0, 0) */
+    double *box_size;       /* [count] Box.size[0] of the first box (entity.py:366-378) */
+    double *box2_size;      /* [count] second box, 0 where there is none */
+    double *goal_dist;      /* [count] simtorealpush.py:84 */
 } mwb_state;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
@@ -125,7 +138,11 @@ int mwb_abi_version(void);
 /* ---- assets ------------------------------------------------------------------------------ */
 /* replaces: Texture.load (opengl.py:71-108): upload RGB8 pixels (row 0 = TOP of the image, tightly
  * packed) for texture slot `tex_id` (0 floor_tiles_bw_1, 1-4 concrete_1..4, 5 concrete_tiles_1,
- * 6 brick_wall_1); the library builds the mip chain.  Must precede the first render. Synchronous. */
+ * 6 brick_wall_1; the sim-to-real rinks also use 7-10 cardboard_1..4, 11-12 wood_1..2, 13 wood_planks_1,
+ * 14 drywall_1, 15 stucco_1, 16 ceiling_tiles_1); the library builds the mip chain.  Every slot the task can
+ * draw must be set before the first render. Synchronous. */
+#define MWB_NUM_TEXTURES 17
+int mwb_num_textures(mwb_handle *h);   /* how many leading slots the handle's task uses (7 or 17) */
 int mwb_set_texture(mwb_handle *h, int tex_id, int width, int height, const uint8_t *rgb);
 
 /* ---- simulation -------------------------------------------------------------------------- */
