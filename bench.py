@@ -29,10 +29,14 @@ WORKLOADS = {
     # the two-box T-maze with info['feature'] the fork's trainer uses;
     # 14 400 B obs + ~0.2 KB state + 2 rooms x 96 B + 416 B frame constants
     "tmaze_features8192": ("MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0", 8192, False, False, 15200),
+    # the sim-to-real rink with box pushing (no ceiling, own params, always randomised, Discrete(4) incl. move_back
+    # is available but the shared action stream stays on {0, 1, 2}); 14 400 B obs + ~0.8 KB state incl. the RNG words
+    "sim2real_push8192": ("MiniWorld-SimToRealPush-v0", 8192, False, True, 15200),
 }
 ORACLE_TASK = {"MiniWorld-Maze-v0": ("Maze", None), "MiniWorld-OneRoom-v0": ("OneRoom", None),
                "MiniWorld-FourRooms-v0": ("FourRooms", None), "MiniWorld-Hallway-v0": ("Hallway", None),
-               "MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0": ("TMazeTwoBox", [1, 0, 0, 100000])}
+               "MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0": ("TMazeTwoBox", [1, 0, 0, 100000]),
+               "MiniWorld-SimToRealPush-v0": ("SimToRealPush", None)}
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ACTION_SEED = 12345
 
@@ -88,8 +92,13 @@ def cpu_baseline(env_id, depth, dr, budget_s=10.0):
     from oracle import oracle as O
     task, args = ORACLE_TASK[env_id]
 
+    params = None
+    if task.startswith("SimToReal"):   # the classes' own parameter table (simtorealpush.py:8-18)
+        from gym_miniworld_amd.params import sim_to_real_params
+        params = sim_to_real_params(push=task.endswith("Push")).to_table()
+
     def make(i):
-        e = O.OracleEnv(task, seed=1 + i, domain_rand=dr, task_args=args)
+        e = O.OracleEnv(task, seed=1 + i, domain_rand=dr, task_args=args, params=params)
         e.reset(render=False)
         return e
     env0 = make(0)
