@@ -154,17 +154,19 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
                 const double c = cos(adir), s = sin(adir);
                 const double npx = ax + c * fwd_dist, npz = az + (-s) * fwd_dist;
                 const int ns = d.n_segs[e];
+                double wq[4][4];   // the rink's four wall segments, loaded together (16 coalesced loads in flight)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) wq[i][cc] = d.segs[(size_t)((i < ns ? i : 0) * 4 + cc) * d.N + e];
                 for (int b = 0; b < 2; b++) {
                     const double vx = bx[b] - npx, vz = bz[b] - npz;
                     const double dist = sqrt((vx * vx + 0.0) + vz * vz);
                     if (dist < arad + brad[b]) {
                         const double qx = bx[b] + vx, qz = bz[b] + vz;
                         bool hit = false;
-                        for (int i = 0; i < ns && !hit; i++) {
-                            double q[4];
-                            for (int cc = 0; cc < 4; cc++) q[cc] = d.segs[(size_t)(i * 4 + cc) * d.N + e];
-                            hit = seg_hit(q, qx, qz, brad[b]);
-                        }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) hit = hit || (i < ns && seg_hit(wq[i], qx, qz, brad[b]));
                         if (!hit) {   // entities in list order: box 0, box 1, agent (itself skipped)
                             const int o = 1 - b;
                             double ddx = bx[o] - qx, ddz = bz[o] - qz;
