@@ -36,7 +36,8 @@ struct mwb_handle {
     // timing
     // timing: five events per pipeline pass, drawn from a pool and only read back in
     // mwb_timing_read, so that enabling it adds no host synchronisation to the timed region
-    bool timing;
+    bool timing, timing_now;   // enabled at all / recording the current pass
+    int timing_period, timing_tick;   // record every timing_period-th pass (the events themselves cost ~20 us per pass)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used;
     hipEvent_t *ev;   // the current pass' events: 0-4 on the caller's stream, 5-6 around reset_kernel
@@ -254,7 +255,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     d.tex_desc = h->tex_desc_dev;
     h->texels_dev = nullptr; d.texels = nullptr;
     h->seeded = false; h->textures_dirty = false; h->have_textures = false;
-    h->timing = false; h->ev_used = 0; h->ev = nullptr;
+    h->timing = false; h->timing_now = false; h->timing_period = 1; h->timing_tick = 0; h->ev_used = 0; h->ev = nullptr;
     { const char *no = getenv("MWB_NO_OVERLAP"); h->overlap_reset = !(no && atoi(no)); }
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
     h->stack = nullptr; h->stack_n = 0; h->stack_dtype = 0; h->stack_bytes = 0;
@@ -391,7 +392,8 @@ static int check_launch(const char *what) {
 
 #define EVN 7
 static int timing_begin(mwb_handle *h, hipStream_t s) {
-    if (!h->timing) return MWB_OK;
+    h->timing_now = h->timing && (h->timing_tick++ % h->timing_period) == 0;
+    if (!h->timing_now) return MWB_OK;
     if (h->ev_used + EVN > h->ev_pool.size()) {
         size_t old = h->ev_pool.size();
         h->ev_pool.resize(old + EVN * 256);
@@ -402,7 +404,7 @@ static int timing_begin(mwb_handle *h, hipStream_t s) {
     HIP_TRY(hipEventRecord(h->ev[0], s));
     return MWB_OK;
 }
-#define TMARK(i) do { if (h->timing) HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
+#define TMARK(i) do { if (h->timing_now) HIP_TRY(hipEventRecord(h->ev[i], s)); } while (0)
 
 static int render_tail(mwb_handle *h, int mode, hipStream_t s) {
     mwb_launch_prep(h->dev, mode, s);
@@ -458,10 +460,10 @@ extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t
     // caller's stream renders everybody else; join before returning control of the outputs
     HIP_TRY(hipEventRecord(h->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    if (h->timing) HIP_TRY(hipEventRecord(h->ev[5], h->side));
+    if (h->timing_now) HIP_TRY(hipEventRecord(h->ev[5], h->side));
     mwb_launch_reset(h->dev, 128, h->side);   // a handful of envs end per step: few blocks, started ahead of the bulk render
     rc = check_launch("reset_kernel"); if (rc) return rc;
-    if (h->timing) HIP_TRY(hipEventRecord(h->ev[6], h->side));
+    if (h->timing_now) HIP_TRY(hipEventRecord(h->ev[6], h->side));
     mwb_launch_prep(h->dev, 1, h->side);
     rc = check_launch("prep_kernel"); if (rc) return rc;
     mwb_launch_render(h->dev, 1, h->side);
@@ -682,6 +684,8 @@ extern "C" int mwb_timing_enable(mwb_handle *h, int enable) {
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipDeviceSynchronize());
     h->timing = enable != 0;
+    h->timing_period = enable > 1 ? enable : 1;
+    h->timing_tick = 0;
     h->ev_used = 0;
     return MWB_OK;
 }

@@ -202,7 +202,8 @@ int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_rooms, double
 
 /* ---- timing hooks used by bench.py -------------------------------------------------------- */
 /* average device time (ms) of each kernel of the step pipeline since the last call (HIP events
- * recorded on the stream the kernels were launched on); names: "step","reset","prep","render". */
+ * recorded on the stream the kernels were launched on); names: "step","reset","prep","render".
+ * enable: 0 off, 1 every pass, n > 1 every n-th pass (the seven events of a pass cost ~20 us of stream time). */
 int mwb_timing_enable(mwb_handle *h, int enable);
 int mwb_timing_read(mwb_handle *h, double *ms_step, double *ms_reset, double *ms_prep, double *ms_render,
                     int *n_samples);
