@@ -394,6 +394,8 @@ static int check_launch(const char *what) {
 static int timing_begin(mwb_handle *h, hipStream_t s) {
     h->timing_now = h->timing && (h->timing_tick++ % h->timing_period) == 0;
     if (!h->timing_now) return MWB_OK;
+    if (h->ev_used + EVN > h->ev_pool.size() && h->ev_pool.size() >= (size_t)EVN * 65536)
+        h->ev_used = 0;   // nobody read the samples for 65536 timed passes: start over instead of growing without bound
     if (h->ev_used + EVN > h->ev_pool.size()) {
         size_t old = h->ev_pool.size();
         h->ev_pool.resize(old + EVN * 256);
