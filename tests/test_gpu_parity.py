@@ -348,3 +348,45 @@ def test_other_observation_sizes_match_oracle(oracle_mod, W, H, layout):
             assert d.max() <= 1, (env_id, W, H, layout, i, int(d.max()), int((d > 1).sum()))
             assert np.abs(dep[i] - refd).max() <= 1e-4
         b.close()
+
+
+@pytest.mark.parametrize("env_id,task,args", [("MiniWorld-FourRooms-v0", "FourRooms", None), ("MiniWorld-MazeS3-v0", "Maze", [3, 3, 3]),
+                                              ("MiniWorld-Hallway-v0", "Hallway", None)])
+def test_extreme_camera_parameters_match_oracle(oracle_mod, env_id, task, args):
+    """A custom DomainParams table far outside the defaults: steep camera pitch both ways, narrow to very wide
+    field of view, eyes from ankle height to above the 2.2 m lintels, the camera pushed forward or back, strong
+    light variation.  Portals, lintels and the box are then seen under angles the default tables never produce."""
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    from gym_miniworld_amd.params import DEFAULT_PARAMS
+    O = oracle_mod
+    p = DEFAULT_PARAMS.copy()
+    p.set("cam_pitch", 0, -25, 25)
+    p.set("cam_fov_y", 60, 35, 95)
+    p.set("cam_height", 1.5, 0.25, 2.6)
+    p.set("cam_fwd_disp", 0, -0.2, 0.2)
+    p.set("light_pos", [0, 2.5, 0], [-60, -10, -60], [60, 20, 60])
+    p.set("light_color", [0.7, 0.7, 0.7], [0.1, 0.1, 0.1], [1.5, 1.5, 1.5])
+    p.set("obj_color_bias", [0, 0, 0], [-0.9, -0.9, -0.9], [0.9, 0.9, 0.9])
+    n = 40
+    b = BatchedMiniWorld(env_id, num_envs=n, seed=321, domain_rand=True, params=p, want_depth=True)
+    envs = [O.OracleEnv(task, seed=321 + i, domain_rand=True, task_args=args, params=p.to_table()) for i in range(n)]
+    b.reset()
+    for e in envs:
+        e.reset(render=False)
+    st = oracle_states(envs)
+    assert_state_equal(b.get_state(), st, tag=env_id)
+    assert min(s.cam_pitch for s in st) < -15 and max(s.cam_pitch for s in st) > 15 and max(s.cam_fov_y for s in st) > 85
+    pos = np.array([[s.agent_pos[0], s.agent_pos[2]] for s in st])
+    rng = np.random.default_rng(8)
+    for rnd in range(4):
+        dirs = np.array([s.agent_dir for s in st]) if rnd == 0 else rng.uniform(-np.pi, np.pi, size=n)
+        b.set_agent(0, pos_xz=pos, dir=dirs)
+        obs = b.render().cpu().numpy()
+        dep = b.depth.cpu().numpy()[..., 0]
+        for i, e in enumerate(envs):
+            e.set_agent(pos[i, 0], pos[i, 1], dirs[i])
+            ref, refd = e.render_obs(depth=True)
+            d = obs_diff(obs[i], ref)
+            assert d.max() <= 1, (env_id, rnd, i, int(d.max()), int((d > 1).sum()))
+            assert np.abs(dep[i] - refd).max() <= 1e-4, (env_id, rnd, i)
+    b.close()
