@@ -59,35 +59,45 @@ class DomainParams:
         return t
 
 
-DEFAULT_PARAMS = DomainParams()
-DEFAULT_PARAMS.set("sky_color", [0.25, 0.82, 1], [0.1, 0.1, 0.1], [1.0, 1.0, 1.0])
-DEFAULT_PARAMS.set("light_pos", [0, 2.5, 0], [-40, 2.5, -40], [40, 5, 40])
-DEFAULT_PARAMS.set("light_color", [0.7, 0.7, 0.7], [0.45, 0.45, 0.45], [0.8, 0.8, 0.8])
-DEFAULT_PARAMS.set("light_ambient", [0.45, 0.45, 0.45], [0.35, 0.35, 0.35], [0.55, 0.55, 0.55])
-DEFAULT_PARAMS.set("obj_color_bias", [0, 0, 0], [-0.2, -0.2, -0.2], [0.2, 0.2, 0.2])
-DEFAULT_PARAMS.set("forward_step", 0.15, 0.12, 0.17)
-DEFAULT_PARAMS.set("forward_drift", 0, -0.05, 0.05)
-DEFAULT_PARAMS.set("turn_step", 15, 10, 20)
-DEFAULT_PARAMS.set("bot_radius", 0.4, 0.38, 0.42)
-DEFAULT_PARAMS.set("cam_pitch", 0, -5, 5)
-DEFAULT_PARAMS.set("cam_fov_y", 60, 55, 65)
-DEFAULT_PARAMS.set("cam_height", 1.5, 1.45, 1.55)
-DEFAULT_PARAMS.set("cam_fwd_disp", 0, -0.05, 0.10)
+# name -> (default, min, max): the values of the reference table (params.py:110-123), vectors as tuples
+_DEFAULT_TABLE = {
+    "sky_color": ((0.25, 0.82, 1), (0.1, 0.1, 0.1), (1.0, 1.0, 1.0)),
+    "light_pos": ((0, 2.5, 0), (-40, 2.5, -40), (40, 5, 40)),
+    "light_color": ((0.7,) * 3, (0.45,) * 3, (0.8,) * 3),
+    "light_ambient": ((0.45,) * 3, (0.35,) * 3, (0.55,) * 3),
+    "obj_color_bias": ((0,) * 3, (-0.2,) * 3, (0.2,) * 3),
+    "forward_step": (0.15, 0.12, 0.17),
+    "forward_drift": (0, -0.05, 0.05),
+    "turn_step": (15, 10, 20),
+    "bot_radius": (0.4, 0.38, 0.42),
+    "cam_pitch": (0, -5, 5),
+    "cam_fov_y": (60, 55, 65),
+    "cam_height": (1.5, 1.45, 1.55),
+    "cam_fwd_disp": (0, -0.05, 0.10),
+}
+
+
+def _from_table(base, table):
+    p = base.copy() if base is not None else DomainParams()
+    for name, (dflt, lo, hi) in table.items():
+        as_list = lambda v: list(v) if isinstance(v, tuple) else v  # noqa: E731
+        p.set(name, as_list(dflt), as_list(lo), as_list(hi))
+    return p
+
+
+DEFAULT_PARAMS = _from_table(None, _DEFAULT_TABLE)
 
 
 def sim_to_real_params(push=False):
     """envs/simtorealgoto.py:8-18 / simtorealpush.py:8-18: a robot about 15 cm tall with a Pi camera.  The two
     files differ only in bot_radius (0.4 +- 0.02, unused, vs 0.11, which SimToRealPush uses to keep boxes off the walls)."""
-    p = DEFAULT_PARAMS.copy()
-    p.set("forward_step", 0.035, 0.028, 0.042)
-    p.set("forward_drift", 0, -0.005, 0.005)
-    p.set("turn_step", 17, 13, 21)
-    if push:
-        p.set("bot_radius", 0.11, 0.11, 0.11)
-    else:
-        p.set("bot_radius", 0.4, 0.38, 0.42)   # FIXME in the reference: not used
-    p.set("cam_pitch", -10, -15, -3)
-    p.set("cam_fov_y", 49, 45, 55)
-    p.set("cam_height", 0.18, 0.17, 0.19)
-    p.set("cam_fwd_disp", 0, -0.02, 0.02)
-    return p
+    return _from_table(DEFAULT_PARAMS, {
+        "forward_step": (0.035, 0.028, 0.042),
+        "forward_drift": (0, -0.005, 0.005),
+        "turn_step": (17, 13, 21),
+        "bot_radius": (0.11, 0.11, 0.11) if push else (0.4, 0.38, 0.42),
+        "cam_pitch": (-10, -15, -3),
+        "cam_fov_y": (49, 45, 55),
+        "cam_height": (0.18, 0.17, 0.19),
+        "cam_fwd_disp": (0, -0.02, 0.02),
+    })
