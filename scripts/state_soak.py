@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Randomised state-parity soak (not part of the test suite): long random rollouts with auto-reset, many envs
+per task; reward (f64), done and step count compared with the CPU oracle at EVERY step, the RNG position / key
+checksum, box poses and counters every 100 steps.  usage: state_soak.py [envs] [steps]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from gym_miniworld_amd.batch import BatchedMiniWorld, ENV_SPECS  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+TASKS = [("MiniWorld-Hallway-v0", "Hallway"), ("MiniWorld-OneRoom-v0", "OneRoom"), ("MiniWorld-FourRooms-v0", "FourRooms"),
+         ("MiniWorld-MazeS3-v0", "Maze"), ("MiniWorld-Maze-v0", "Maze"), ("MiniWorld-TMaze-v0", "TMaze"),
+         ("MiniWorld-TMazeDynamic-v0", "TMaze"), ("MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0", "TMazeTwoBox"),
+         ("MiniWorld-SimToRealGoTo-v0", "SimToRealGoTo"), ("MiniWorld-SimToRealPush-v0", "SimToRealPush")]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+for env_id, task in TASKS:
+    spec = ENV_SPECS[env_id]
+    params = spec[3]().to_table() if spec[3] else None
+    for dr in ((1,) if task.startswith("SimToReal") else (0, 1)):
+        t0 = time.time()
+        b = BatchedMiniWorld(env_id, num_envs=n, seed=7000, domain_rand=bool(dr))
+        envs = [O.OracleEnv(task, seed=7000 + i, domain_rand=bool(dr), task_args=spec[1] or None, params=params,
+                            max_episode_steps=spec[2], textures=True) for i in range(n)]
+        b.reset()
+        for e in envs:
+            e.reset(render=False)
+        rng = np.random.default_rng(1)
+        na = b.n_actions
+        episodes = rewards = mism = 0
+        for t in range(steps):
+            a = rng.choice(na, size=n, p=[0.2, 0.2, 0.6] if na == 3 else [0.2, 0.2, 0.5, 0.1]).astype(np.int32)
+            b.step(torch.from_numpy(a))
+            rew, done, eps = b.reward64.cpu().numpy(), b.done.cpu().numpy(), b.ep_steps.cpu().numpy()
+            for i, e in enumerate(envs):
+                _, r, d, _ = e.step(int(a[i]))
+                if r != rew[i] or d != bool(done[i]) or e.state().step_count != eps[i]:
+                    mism += 1
+                rewards += r != 0
+                if d:
+                    episodes += 1
+                    e.reset(render=False)
+            if t % 100 == 99:
+                st = b.get_state()
+                os_ = [e.state() for e in envs]
+                for k, f in (("rng_pos", lambda s: s.rng_pos), ("rng_keysum", lambda s: s.rng_keysum), ("box_dir", lambda s: s.box_dir),
+                             ("goal_idx", lambda s: s.goal_idx), ("task_step_count", lambda s: s.task_step_count)):
+                    if not np.array_equal(st[k].astype(np.int64) if st[k].dtype.kind in "iu" else st[k], np.array([f(s) for s in os_])):
+                        mism += 1
+                if not np.allclose(st["box_pos"], np.array([list(s.box_pos) for s in os_]), rtol=0, atol=1e-11):
+                    mism += 1
+        b.close()
+        print("%-46s dr%d  %d envs x %d steps  episodes %6d  nonzero rewards %6d  MISMATCHES %d  (%.0f s)"
+              % (env_id, dr, n, steps, episodes, rewards, mism, time.time() - t0), flush=True)
