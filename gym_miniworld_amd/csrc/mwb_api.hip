@@ -197,6 +197,12 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     const bool sim2real = cfg->task == MWB_TASK_SIM2REAL_GOTO || cfg->task == MWB_TASK_SIM2REAL_PUSH;
     d.n_boxes = (cfg->task == MWB_TASK_TMAZE_TWOBOX || cfg->task == MWB_TASK_SIM2REAL_PUSH) ? 2 : 1;
     d.n_tex = sim2real ? MWB_NUM_TEXTURES : 7;
+    {   // the last ~0.6 round of resident workgroups (5 per CU x 256 CUs = 1280) of a bulk render launch drains in
+        // half-frame units: measured best between 640 and 960 envs (+4 % at 8192 Maze envs); MWB_SPLIT overrides
+        const char *sp = getenv("MWB_SPLIT");
+        int split = sp ? atoi(sp) : 768;
+        d.split_envs = split < 0 ? 0 : (split > cfg->num_envs ? cfg->num_envs : split);
+    }
     d.no_ceiling = sim2real ? 1 : 0;
     d.agent_radius = sim2real ? 0.11 : 0.4;   // simtorealgoto.py:50 / entity.py:451
     for (int i = 0; i < 4; i++) d.task_args[i] = cfg->task_args[i] != 0 ? cfg->task_args[i] : dflt[cfg->task][i];

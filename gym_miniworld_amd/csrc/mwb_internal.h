@@ -84,6 +84,7 @@ struct MwbDev {
     int R_max, S_max, auto_reset;
     int n_boxes;       // 1, or 2 for MWB_TASK_TMAZE_TWOBOX (box 0 red, box 1 blue) and SIM2REAL_PUSH (red, yellow)
     int n_tex;         // leading texture slots the task can draw (7, or MWB_NUM_TEXTURES for the sim-to-real rinks)
+    int split_envs;    // the last split_envs envs of a bulk render launch are rendered by two half-frame workgroups each
     int no_ceiling;    // the task's rooms have no ceiling (sim-to-real rinks): selects the NOCEIL render kernels
     double agent_radius;   // entity.py:451 (0.4), 0.11 in the sim-to-real rinks
     int debug_flags;   // MWB_DEBUG env var at mwb_create: bit0 = resolve every pixel with the full 8-sample path

@@ -1372,9 +1372,28 @@ struct RenderCtx {
 #define TILE_CY 4
 #define QUEUE_CAP 128
 
+// LDS -> HBM copy of the byte range [begin, end) of the frame with the widest vectors its alignment allows
+template <int THREADS>
+__device__ __forceinline__ void copy_frame_range(uint8_t *__restrict__ dst, const uint8_t *__restrict__ fb, int begin, int end, int tid) {
+    if (((begin | end) & 15) == 0) {
+        const uint4 *s4 = (const uint4 *)fb;
+        uint4 *d4 = (uint4 *)dst;
+        for (int i = begin / 16 + tid; i < end / 16; i += THREADS) d4[i] = s4[i];
+    } else if (((begin | end) & 3) == 0) {
+        const uint32_t *s1 = (const uint32_t *)fb;
+        uint32_t *d1 = (uint32_t *)dst;
+        for (int i = begin / 4 + tid; i < end / 4; i += THREADS) d1[i] = s1[i];
+    } else {
+        for (int i = begin + tid; i < end; i += THREADS) dst[i] = fb[i];
+    }
+}
+
 // Renders one env with the whole workgroup (called once per workgroup, or per list entry on the side stream).
+// part < 0: the whole frame; part 0 / 1: one half of it (the last envs of a bulk launch are cut in two so that the
+// launch drains in units of half a workgroup time) - the upper / lower rows for HWC frames, the left / right
+// strips for CWH ones, so that a half's bytes are one (three) contiguous run(s).
 template <int THREADS, int NBOX, bool NOCEIL>
-__device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigned char *smem) {
+__device__ __forceinline__ void render_env(const MwbDev &d, const int e, const int part, unsigned char *smem) {
     const int tid = threadIdx.x;
     const int W = d.W, H = d.H;
     int n_rooms = d.n_rooms[e];
@@ -1455,8 +1474,11 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
     // none wasted).  Waves take them from an LDS counter as they become free, so a wave that drew cheap
     // (uniform) items does not idle while another one works through the edge-rich ones.
     const int part_h = (H + 3) / 4;                       // pixel rows per item
-    const int n_items = n_strips * 4;
     const int n_pass = (part_h + 1 + TILE_CY - 1) / TILE_CY;   // corner rows per item: part_h + 1
+    const bool split_x = d.layout == MWB_LAYOUT_CWH;
+    const int half_strips = (n_strips + 1) / 2;
+    const int n_items = part < 0 ? n_strips * 4
+                                 : (split_x ? (part == 0 ? half_strips : n_strips - half_strips) * 4 : n_strips * 2);
     (void)n_waves;
 
     for (;;) {
@@ -1464,6 +1486,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
         if (lane == 0) item = atomicAdd(cam_room_s + 1, 1);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= n_items) break;
+        if (part >= 0) item = split_x ? item + part * half_strips * 4 : ((item >> 1) << 2) + (item & 1) + 2 * part;
         const int x0 = (item >> 2) * (TILE_CX - 1), row0 = (item & 3) * part_h;
         const int rows = (H - row0) < part_h ? (H - row0) : part_h;   // pixel rows of this item
         if (rows <= 0) continue;
@@ -1553,15 +1576,19 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, unsigne
         }
     }
     __syncthreads();
-    {   // framebuffer LDS -> HBM, 16 bytes per lane
+    {   // framebuffer LDS -> HBM, 16 bytes per lane where the alignment allows
         const int nbytes = W * H * 3;
         uint8_t *dst = d.obs + (size_t)e * nbytes;
-        if ((nbytes & 15) == 0) {
-            const uint4 *s4 = (const uint4 *)fb;
-            uint4 *d4 = (uint4 *)dst;
-            for (int i = tid; i < nbytes / 16; i += THREADS) d4[i] = s4[i];
-        } else {
-            for (int i = tid; i < nbytes; i += THREADS) dst[i] = fb[i];
+        if (part < 0) {
+            copy_frame_range<THREADS>(dst, fb, 0, nbytes, tid);
+        } else if (!split_x) {   // HWC: rows [r0, r1)
+            const int mid = 2 * part_h < H ? 2 * part_h : H;
+            const int r0 = part ? mid : 0, r1 = part ? H : mid;
+            copy_frame_range<THREADS>(dst, fb, r0 * W * 3, r1 * W * 3, tid);
+        } else {                 // CWH: columns [xa, xb) of each channel plane
+            const int midx = half_strips * (TILE_CX - 1) < W ? half_strips * (TILE_CX - 1) : W;
+            const int xa = part ? midx : 0, xb = part ? W : midx;
+            for (int q = 0; q < 3; q++) copy_frame_range<THREADS>(dst, fb, (q * W + xa) * H, (q * W + xb) * H, tid);
         }
     }
 }
@@ -1575,13 +1602,17 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     if (MODE == 1) {
         const int count = d.reset_count[0];
         for (int li = blockIdx.x; li < count; li += gridDim.x) {
-            render_env<THREADS, NBOX, NOCEIL>(d, d.reset_list[li], smem);
+            render_env<THREADS, NBOX, NOCEIL>(d, d.reset_list[li], -1, smem);
             __syncthreads();   // LDS is reused by the next env of this block
         }
     } else {
-        const int e = blockIdx.x;
+        // the last d.split_envs envs of a bulk launch run as two half-frame workgroups each
+        const int whole = d.N - d.split_envs;
+        const int b = blockIdx.x;
+        const int e = b < whole ? b : whole + ((b - whole) >> 1);
+        const int part = b < whole ? -1 : ((b - whole) & 1);
         if (MODE == 2 && d.reset_set[e]) return;   // block-uniform
-        render_env<THREADS, NBOX, NOCEIL>(d, e, smem);
+        render_env<THREADS, NBOX, NOCEIL>(d, e, part, smem);
     }
 }
 
@@ -1692,7 +1723,7 @@ void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s) {
     hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, s, d, mode);
 }
 void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
-    const dim3 g(d.N), b(RENDER_THREADS);
+    const dim3 g(d.N + d.split_envs), b(RENDER_THREADS);
     const size_t lds = mwb_render_lds_bytes(d);
     const dim3 gl(d.N < LIST_GRID ? d.N : LIST_GRID);
     if (d.no_ceiling) {   // the sim-to-real rinks: their own instantiations
