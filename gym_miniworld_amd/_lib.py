@@ -52,7 +52,7 @@ EXPORTS = [
     "mwb_create", "mwb_destroy", "mwb_last_error", "mwb_abi_version", "mwb_set_texture", "mwb_seed", "mwb_reset",
     "mwb_step", "mwb_render", "mwb_get_outputs", "mwb_get_state", "mwb_set_agent", "mwb_intersect",
     "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read", "mwb_stack_enable", "mwb_stack_update", "mwb_check", "mwb_seed_key",
-    "mwb_set_task_state", "mwb_set_domain_rand", "mwb_num_textures",
+    "mwb_set_task_state", "mwb_set_domain_rand", "mwb_num_textures", "mwb_debug_wg_times",
 ]
 
 _lib = None
@@ -89,6 +89,7 @@ def load():
     L.mwb_set_task_state.argtypes = [vp, i32, i32, vp, vp, vp]
     L.mwb_set_domain_rand.argtypes = [vp, i32]
     L.mwb_num_textures.argtypes = [vp]
+    L.mwb_debug_wg_times.argtypes = [vp, vp, i32]
     L.mwb_intersect.argtypes = [vp, i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(i32)]
     L.mwb_get_geometry.argtypes = [vp, i32, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.mwb_timing_enable.argtypes = [vp, i32]

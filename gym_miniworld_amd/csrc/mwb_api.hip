@@ -48,6 +48,8 @@ struct mwb_handle {
     size_t stack_bytes;
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
+    int32_t *order_buf[2];   // blockIdx -> env maps: the bulk render reads [order_cur], the side stream fills the other one
+    int order_cur;
 };
 
 extern "C" const char *mwb_last_error(void) { return g_err.c_str(); }
@@ -248,6 +250,19 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     A(h->scratch_int_dev, (size_t)4);
     A(d.error_flag, (size_t)1);
 #undef A
+    if (rc == MWB_OK && (d.debug_flags & 16)) rc = dev_alloc(h, &d.wg_ts, 2 * (N + (size_t)d.split_envs));
+    if (rc == MWB_OK) rc = dev_alloc(h, &d.cost, 2 * N);
+    if (rc == MWB_OK) rc = dev_alloc(h, &d.bucket, N);
+    h->order_buf[0] = h->order_buf[1] = nullptr; h->order_cur = 0;
+    if (rc == MWB_OK) rc = dev_alloc(h, &h->order_buf[0], N);
+    if (rc == MWB_OK) rc = dev_alloc(h, &h->order_buf[1], N);
+    if (rc == MWB_OK) {   // no cost known yet: identity order
+        std::vector<int32_t> ident(N);
+        for (size_t i = 0; i < N; i++) ident[i] = (int32_t)i;
+        for (int k = 0; k < 2 && rc == MWB_OK; k++)
+            if (hipMemcpy(h->order_buf[k], ident.data(), N * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = set_err(MWB_EHIP, "mwb_create: hipMemcpy failed");
+        d.order = h->order_buf[0];
+    }
     if (rc != MWB_OK) { mwb_destroy(h); return rc; }
     // MiniWorldEnv.__init__ ends with self.reset() (miniworld.py:523): the episode counters of TMazeDynamic /
     // TMazeTwoBoxDynamic (tmaze.py:80,130) have seen one reset when the caller gets the env
@@ -477,10 +492,15 @@ extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t
     mwb_launch_render(h->dev, 1, h->side);
     rc = check_launch("render_kernel"); if (rc) return rc;
     mwb_launch_clear_list(h->dev, h->side);   // the list is consumed; off the critical path
+    // also off the critical path: the next step's dispatch order, from the frame costs measured so far
+    mwb_launch_order(h->dev, h->order_buf[h->order_cur ^ 1], h->side);
+    rc = check_launch("order_kernel"); if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev_join, h->side));
     TMARK(2);
     rc = render_tail(h, 2, s); if (rc) return rc;
     HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+    h->order_cur ^= 1;   // the map filled beside this step is complete once the join has passed
+    h->dev.order = h->order_buf[h->order_cur];
     return MWB_OK;
 }
 
@@ -627,6 +647,19 @@ extern "C" int mwb_set_agent(mwb_handle *h, int first, int count, const double *
 }
 
 extern "C" int mwb_num_textures(mwb_handle *h) { return h ? h->dev.n_tex : 0; }
+
+/* debugging aid (MWB_DEBUG bit 4 at mwb_create): start / end s_memrealtime ticks (100 MHz) of every workgroup of the last
+ * bulk render launch; out: [2 * n] u64, returns n = workgroups or a negative code */
+extern "C" int mwb_debug_wg_times(mwb_handle *h, unsigned long long *out, int max_wgs) {
+    if (!h || !out) return set_err(MWB_EINVAL, "mwb_debug_wg_times: null argument");
+    if (!h->dev.wg_ts) return set_err(MWB_ESTATE, "mwb_debug_wg_times: create the handle with MWB_DEBUG bit 4 set");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    int n = h->dev.N + h->dev.split_envs;
+    if (n > max_wgs) n = max_wgs;
+    HIP_TRY(hipMemcpy(out, h->dev.wg_ts, (size_t)n * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return n;
+}
 
 extern "C" int mwb_set_domain_rand(mwb_handle *h, int domain_rand) {
     if (!h) return set_err(MWB_EINVAL, "mwb_set_domain_rand: null handle");

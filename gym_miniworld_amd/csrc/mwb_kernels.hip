@@ -971,6 +971,40 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     }   // boxes
 }
 
+// Counting sort of the envs by the measured render cost of a recent frame, most expensive first (256 buckets of
+// 1.28 us): the bulk render's blockIdx -> env map for the NEXT step.  One block, off the critical path (side stream);
+// it may read costs the current bulk render is just rewriting - either value will do, but each env's bucket is
+// decided once (kept in d.bucket) so that the result is a permutation whatever changes underneath.  The order
+// inside a bucket is whatever the atomics give - results do not depend on it.
+__global__ void __launch_bounds__(1024) order_kernel(MwbDev d, int32_t *__restrict__ order_out) {
+    __shared__ int hist[256], scan[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < d.N; i += 1024) {
+        const uint32_t c = (d.cost[2 * i] + d.cost[2 * i + 1]) >> 7;
+        const int bk = 255 - (int)(c > 255u ? 255u : c);
+        d.bucket[i] = (uint8_t)bk;
+        atomicAdd(&hist[bk], 1);
+    }
+    __syncthreads();
+    const int own = tid < 256 ? hist[tid] : 0;
+    if (tid < 256) scan[tid] = own;
+    __syncthreads();
+    for (int ofs = 1; ofs < 256; ofs <<= 1) {   // inclusive prefix, 8 doubling steps
+        const int v = (tid < 256 && tid >= ofs) ? scan[tid - ofs] : 0;
+        __syncthreads();
+        if (tid < 256) scan[tid] += v;
+        __syncthreads();
+    }
+    if (tid < 256) hist[tid] = scan[tid] - own;
+    __syncthreads();
+    for (int i = tid; i < d.N; i += 1024) order_out[atomicAdd(&hist[d.bucket[i]], 1)] = i;   // own writes of pass 1
+}
+void mwb_launch_order(const MwbDev &d, int32_t *order_out, hipStream_t s) {
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, s, d, order_out);
+}
+
 __global__ void __launch_bounds__(256) prep_kernel(MwbDev d, int mode) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (mode == 1) {   // the regenerated envs, through the compact list
@@ -1606,13 +1640,26 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
             __syncthreads();   // LDS is reused by the next env of this block
         }
     } else {
-        // the last d.split_envs envs of a bulk launch run as two half-frame workgroups each
+        // Workgroups take the envs in the order of decreasing cost measured by the previous launch (frames change
+        // little from step to step): a frame's time varies from 0.5x to 2.5x the mean, and starting the slow ones
+        // first keeps the launch from ending on a few stragglers.  The last d.split_envs of that order - the
+        // cheapest frames - run as two half-frame workgroups each.
         const int whole = d.N - d.split_envs;
         const int b = blockIdx.x;
-        const int e = b < whole ? b : whole + ((b - whole) >> 1);
+        const int slot = b < whole ? b : whole + ((b - whole) >> 1);
         const int part = b < whole ? -1 : ((b - whole) & 1);
+        const int e = d.order[slot];
         if (MODE == 2 && d.reset_set[e]) return;   // block-uniform
+        unsigned long long t0 = 0;
+        if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memrealtime(); if (d.wg_ts) d.wg_ts[2 * b] = t0; }
         render_env<THREADS, NBOX, NOCEIL>(d, e, part, smem);
+        if (threadIdx.x == 0) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+            if (d.wg_ts) d.wg_ts[2 * b + 1] = t1;
+            const uint32_t dt = (uint32_t)(t1 - t0);
+            if (part < 0) { d.cost[2 * e] = dt; d.cost[2 * e + 1] = 0; }
+            else d.cost[2 * e + part] = dt;
+        }
     }
 }
 
@@ -1691,6 +1738,7 @@ void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *ski
     hipLaunchKernelGGL(step_kernel, dim3((d.N + 63) / 64), dim3(64 * STEP_PARTS), 0, s, d, actions, skip);
 }
 __global__ void clear_list_kernel(MwbDev d) { d.reset_count[0] = 0; }
+
 void mwb_launch_clear_list(const MwbDev &d, hipStream_t s) { hipLaunchKernelGGL(clear_list_kernel, dim3(1), dim3(1), 0, s, d); }
 void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s) {
     hipLaunchKernelGGL(mark_reset_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d, mask);

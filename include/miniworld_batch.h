@@ -143,6 +143,9 @@ int mwb_abi_version(void);
  * draw must be set before the first render. Synchronous. */
 #define MWB_NUM_TEXTURES 17
 int mwb_num_textures(mwb_handle *h);   /* how many leading slots the handle's task uses (7 or 17) */
+/* debugging aid (MWB_DEBUG bit 4 at mwb_create): start / end s_memrealtime ticks (100 MHz) of every workgroup of the
+ * last bulk render launch, [2 * n] u64; returns n or a negative code */
+int mwb_debug_wg_times(mwb_handle *h, unsigned long long *out, int max_wgs);
 int mwb_set_texture(mwb_handle *h, int tex_id, int width, int height, const uint8_t *rgb);
 
 /* ---- simulation -------------------------------------------------------------------------- */

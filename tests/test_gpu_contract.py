@@ -74,3 +74,26 @@ def test_graph_capture_of_a_step():
         g.replay()
         assert torch.equal(a.obs, b.obs) and torch.equal(a.reward64, b.reward64) and torch.equal(a.done, b.done), t
     a.close(); b.close()
+
+
+def test_cost_ordered_dispatch_renders_every_env_exactly_once():
+    """mwb_step dispatches the bulk render's workgroups by decreasing measured frame cost (a map rebuilt every step
+    on the side stream, the cheapest envs as half-frame workgroups).  Whatever the map, every env must be rendered
+    exactly once: the observations a step leaves behind equal a plain mwb_render of the same state, for every env."""
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    for env_id, n, layout in (("MiniWorld-Maze-v0", 3000, "HWC"), ("MiniWorld-FourRooms-v0", 1500, "CWH")):
+        b = BatchedMiniWorld(env_id, num_envs=n, seed=11, domain_rand=True, want_depth=True, layout=layout)
+        b.reset()
+        g = torch.Generator().manual_seed(0)
+        for t in range(40):
+            b.step(torch.randint(0, 3, (n,), generator=g, dtype=torch.int32))
+            if t % 8 == 7:
+                obs_step, dep_step = b.obs.clone(), b.depth.clone()
+                b.obs.zero_()   # a workgroup that never ran would leave zeros behind
+                b.render()
+                assert torch.equal(b.obs, obs_step) and torch.equal(b.depth, dep_step), (env_id, t)
+                b.obs.zero_()
+                b.step(torch.randint(0, 3, (n,), generator=g, dtype=torch.int32))
+                assert int((b.obs.reshape(n, -1).max(dim=1).values == 0).sum()) == 0, (env_id, t, "an env was not rendered")
+        b.close()
