@@ -651,7 +651,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             wall_fam = wi == 0 ? TEXF_DRYWALL : wi == 1 ? TEXF_STUCCO : wi == 2 ? TEXF_CARDBOARD : wi == 3 ? TEXF_CONCRETE_TILES : TEXF_CEILING_TILES;
         }
         double ox[4] = {size, size, 0, 0}, oz[4] = {size, 0, 0, size};
-        w.add_room(ox, oz, wall_height, wall_fam, floor_fam, TEXF_CONCRETE_TILES);   // no_ceiling: the NOCEIL render kernels
+        w.add_room(ox, oz, wall_height, wall_fam, floor_fam, TEXF_CONCRETE_TILES);   // no ceiling: negative height word in the room table
         w.gen_static_data(dr, d.S_max);
         WorldGen::PlaceOpt o;
         if (push) {
@@ -841,7 +841,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         const WRoom &r = rooms[ri];
         float *o = grooms + (size_t)ri * MWB_ROOM_WORDS;
         o[RW_MINX] = (float)r.min_x; o[RW_MAXX] = (float)r.max_x; o[RW_MINZ] = (float)r.min_z; o[RW_MAXZ] = (float)r.max_z;
-        o[RW_HEIGHT] = (float)r.height;
+        o[RW_HEIGHT] = d.no_ceiling ? -(float)r.height : (float)r.height;   // negative: no ceiling polygon (trace_rooms)
         uint32_t texw = (uint32_t)(r.tex_id[0] | (r.tex_id[1] << 8) | (r.tex_id[2] << 16));
         uint32_t nbrs[4] = {RW_NO_NBR, RW_NO_NBR, RW_NO_NBR, RW_NO_NBR};
         for (int s = 0; s < 4; s++) {
@@ -1044,9 +1044,10 @@ __device__ __forceinline__ void make_ray(const Cam &c, float wx, float wy, float
 // All LDS reads of a step are issued together (both candidate sides are fetched) and the loop has
 // one exit.  With PATH the sequence of sides crossed is returned as 2 bits per crossing under a leading 1
 // (exact for up to 15 crossings; longer paths are flagged by bit 31 and treated as never equal).
-// NOCEIL: the task's rooms have no ceiling polygon (Room._render, miniworld.py:406): a ray never stops at the
-// ceiling plane and one that reaches a wall plane above the wall's top edge sees the sky.
-template <bool PATH, bool NOCEIL>
+// A room without ceiling polygon (Room._render, miniworld.py:406; the sim-to-real rinks) carries a NEGATIVE height
+// word: a ray that crosses its ceiling plane - which every ray that would pass over a wall's top edge does first -
+// sees the sky.
+template <bool PATH>
 __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms, int n_rooms, int room, const float *o,
                                                 const float *dv, float &t_hit, uint32_t &path) {
     t_hit = INFINITY;
@@ -1066,7 +1067,7 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
     for (int iter = 0; iter <= n_rooms; iter++) {
         const float *r = rooms + __umul24((uint32_t)room, MWB_ROOM_WORDS);
         const float4 rect = *(const float4 *)(r + RW_MINX);   // min_x max_x min_z max_z
-        const float height = r[RW_HEIGHT];
+        const float height_w = r[RW_HEIGHT], height = fabsf(height_w);
         const float4 portx = *(const float4 *)(r + RW_SIDE0 + RW_SIDE_WORDS * sx);   // lo hi max_y u_org
         const float4 portz = *(const float4 *)(r + RW_SIDE0 + RW_SIDE_WORDS * sz);
         const uint32_t n01 = (uint32_t)__float_as_int(r[RW_NBR01]), n23 = (uint32_t)__float_as_int(r[RW_NBR23]);
@@ -1077,7 +1078,7 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
         const bool usex = tx <= tz;
         const float ts = usex ? tx : tz;
         const int s = usex ? sx : sz;
-        const float tc = (!NOCEIL && ypos) ? (height - o[1]) * iy : INFINITY;
+        const float tc = ypos ? (height - o[1]) * iy : INFINITY;
         const bool hit_floor = tfloor <= ts;
         const bool hit_ceil = tc <= ts;
         const bool escaped = !(ts < INFINITY);
@@ -1089,8 +1090,7 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
         if (hit_floor || hit_ceil || escaped || !pass) {
             // same precedence as the sequential tests of the spec: floor, ceiling, escape, wall
             if (hit_floor) { t_hit = tfloor; key = MAKE_KEY(KIND_FLOOR, 0, room); }
-            else if (hit_ceil) { t_hit = tc; key = MAKE_KEY(KIND_CEIL, 0, room); }
-            else if (NOCEIL && !escaped && !(y < height)) { /* over the wall: sky */ }
+            else if (hit_ceil) { if (!(height_w < 0.0f)) { t_hit = tc; key = MAKE_KEY(KIND_CEIL, 0, room); } }   // no ceiling: sky
             else if (!escaped) {
                 t_hit = ts; key = MAKE_KEY(KIND_WALL, s, room);
                 // a wall with a portal is not convex: tag the convex piece (left / right / above / below the
@@ -1206,7 +1206,7 @@ __device__ __forceinline__ bool plane_texcoord(int axis, float plane, float u_or
 }
 #pragma clang fp contract(off)
 
-template <int NBOX, bool NOCEIL>
+template <int NBOX>
 struct RenderCtx {
     const float *rooms, *fc;
     const TexLds *tex;
@@ -1322,7 +1322,7 @@ struct RenderCtx {
             float dv[3], th;
             uint32_t path;
             make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
-            uint32_t key = trace_rooms<false, NOCEIL>(rooms, n_rooms, cam_room, cam.eye, dv, th, path);
+            uint32_t key = trace_rooms<false>(rooms, n_rooms, cam_room, cam.eye, dv, th, path);
             // conservative bounding-sphere cull, then the exact slab test; boxes in entity order, a later
             // box wins only when strictly nearer
             const float dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
@@ -1426,7 +1426,7 @@ __device__ __forceinline__ void copy_frame_range(uint8_t *__restrict__ dst, cons
 // part < 0: the whole frame; part 0 / 1: one half of it (the last envs of a bulk launch are cut in two so that the
 // launch drains in units of half a workgroup time) - the upper / lower rows for HWC frames, the left / right
 // strips for CWH ones, so that a half's bytes are one (three) contiguous run(s).
-template <int THREADS, int NBOX, bool NOCEIL>
+template <int THREADS, int NBOX>
 __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const int part, unsigned char *smem) {
     const int tid = threadIdx.x;
     const int W = d.W, H = d.H;
@@ -1454,7 +1454,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         if (tid == 0) { cam_room_s[0] = 0x7fffffff; cam_room_s[1] = 0; }   // eye room (atomicMin), work-item counter
     }
     __syncthreads();
-    RenderCtx<NBOX, NOCEIL> ctx;
+    RenderCtx<NBOX> ctx;
     ctx.rooms = rooms; ctx.fc = fc; ctx.tex = tex; ctx.texels = d.texels; ctx.fb = fb;
     ctx.depth = d.want_depth ? d.depth + (size_t)e * W * H : nullptr;
     ctx.n_rooms = n_rooms; ctx.W = W; ctx.H = H; ctx.layout = d.layout;
@@ -1530,7 +1530,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             float dv[3], th;
             uint32_t path;
             make_ray(cam, (float)(x0 + ci), (float)(H - crow), dv);
-            uint32_t key = trace_rooms<true, NOCEIL>(rooms, n_rooms, ctx.cam_room, cam.eye, dv, th, path);
+            uint32_t key = trace_rooms<true>(rooms, n_rooms, ctx.cam_room, cam.eye, dv, th, path);
             const uint32_t kind = key & 7u;
             bool ok = (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
             // the pixel whose bottom-left corner this lane traced: corners (crow-1, ci), (crow-1, ci+1),
@@ -1630,13 +1630,13 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
 // MODE 0: every env; 1: only the envs regenerated this step (side stream, through the compact list);
 // 2: all the others (bulk).  A template parameter so that the three launches carry distinct kernel names
 // in profiles.
-template <int THREADS, int MODE, int NBOX, bool NOCEIL = false>
+template <int THREADS, int MODE, int NBOX>
 __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (MODE == 1) {
         const int count = d.reset_count[0];
         for (int li = blockIdx.x; li < count; li += gridDim.x) {
-            render_env<THREADS, NBOX, NOCEIL>(d, d.reset_list[li], -1, smem);
+            render_env<THREADS, NBOX>(d, d.reset_list[li], -1, smem);
             __syncthreads();   // LDS is reused by the next env of this block
         }
     } else {
@@ -1648,14 +1648,13 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
         const int b = blockIdx.x;
         const int slot = b < whole ? b : whole + ((b - whole) >> 1);
         const int part = b < whole ? -1 : ((b - whole) & 1);
-        const int e = d.order[slot];
+        const int e = __builtin_amdgcn_readfirstlane(d.order[slot]);
         if (MODE == 2 && d.reset_set[e]) return;   // block-uniform
-        unsigned long long t0 = 0;
-        if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memrealtime(); if (d.wg_ts) d.wg_ts[2 * b] = t0; }
-        render_env<THREADS, NBOX, NOCEIL>(d, e, part, smem);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // read by every wave: stays in scalar registers
+        render_env<THREADS, NBOX>(d, e, part, smem);
         if (threadIdx.x == 0) {
             const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-            if (d.wg_ts) d.wg_ts[2 * b + 1] = t1;
+            if (d.wg_ts) { d.wg_ts[2 * b] = t0; d.wg_ts[2 * b + 1] = t1; }
             const uint32_t dt = (uint32_t)(t1 - t0);
             if (part < 0) { d.cost[2 * e] = dt; d.cost[2 * e + 1] = 0; }
             else d.cost[2 * e + part] = dt;
@@ -1774,18 +1773,6 @@ void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
     const dim3 g(d.N + d.split_envs), b(RENDER_THREADS);
     const size_t lds = mwb_render_lds_bytes(d);
     const dim3 gl(d.N < LIST_GRID ? d.N : LIST_GRID);
-    if (d.no_ceiling) {   // the sim-to-real rinks: their own instantiations
-        if (d.n_boxes == 2) {
-            if (mode == 1) render_kernel<RENDER_THREADS, 1, 2, true><<<gl, b, lds, s>>>(d);
-            else if (mode == 2) render_kernel<RENDER_THREADS, 2, 2, true><<<g, b, lds, s>>>(d);
-            else render_kernel<RENDER_THREADS, 0, 2, true><<<g, b, lds, s>>>(d);
-        } else {
-            if (mode == 1) render_kernel<RENDER_THREADS, 1, 1, true><<<gl, b, lds, s>>>(d);
-            else if (mode == 2) render_kernel<RENDER_THREADS, 2, 1, true><<<g, b, lds, s>>>(d);
-            else render_kernel<RENDER_THREADS, 0, 1, true><<<g, b, lds, s>>>(d);
-        }
-        return;
-    }
     if (d.n_boxes == 2) {   // the two-box T-maze: its own instantiation, so that the one-box kernels stay as they are
         if (mode == 1) render_kernel<RENDER_THREADS, 1, 2><<<gl, b, lds, s>>>(d);
         else if (mode == 2) render_kernel<RENDER_THREADS, 2, 2><<<g, b, lds, s>>>(d);

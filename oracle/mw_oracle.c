@@ -1046,13 +1046,16 @@ static Hit trace_rooms(const RRoom *rr, int n_rooms, int room, const float *o, c
         float ts; int s;
         if (tx <= tz) { ts = tx; s = sx; } else { ts = tz; s = sz; }
         if (d[1] < 0) { float tf = (0.0f - o[1]) * iy; if (tf <= ts) { h.kind = 1; h.room = room; h.t = tf; return h; } }
-        if (d[1] > 0 && !r->no_ceiling) { float tc = (r->height - o[1]) * iy; if (tc <= ts) { h.kind = 2; h.room = room; h.t = tc; return h; } }
+        if (d[1] > 0) { /* a room without ceiling polygon (Room._render, miniworld.py:406): crossing its ceiling plane - which
+                         * every ray passing over a wall's top edge does first - means sky */
+            float tc = (r->height - o[1]) * iy;
+            if (tc <= ts) { if (r->no_ceiling) return h; h.kind = 2; h.room = room; h.t = tc; return h; }
+        }
         if (!(ts < INFINITY)) return h;
         const RSide *sd = &r->side[s];
         float hc = (s == 0 || s == 2) ? fmaf(ts, d[2], o[2]) : fmaf(ts, d[0], o[0]);
         float y = fmaf(ts, d[1], o[1]);
         if (sd->nbr >= 0 && sd->lo < hc && hc < sd->hi && sd->min_y < y && y < sd->max_y) { room = sd->nbr; continue; }
-        if (r->no_ceiling && !(y < r->height)) return h; /* Room._render draws no ceiling (miniworld.py:406): over the wall = sky */
         h.kind = 3; h.room = room; h.side = s; h.t = ts; return h;
     }
     return h;

@@ -60,7 +60,7 @@ def test_rink_reset_state_geometry_and_first_obs(oracle_mod, env_id, task):
         o = g["outline"]
         rect = np.stack([o[:, :, 0].min(1), o[:, :, 0].max(1), o[:, :, 1].min(1), o[:, :, 1].max(1)], axis=1)
         assert np.array_equal(rooms[:, 0:4], rect.astype(np.float32))
-        assert np.array_equal(rooms[:, 4], g["wall_height"].astype(np.float32))   # random wall height, 0.2 .. 0.5 m
+        assert np.array_equal(rooms[:, 4], -g["wall_height"].astype(np.float32))   # random wall height 0.2 .. 0.5 m; negative word = no ceiling
         tex = rooms[:, 5].view(np.int32)
         got = np.stack([tex & 255, (tex >> 8) & 255, (tex >> 16) & 255], axis=1)
         assert np.array_equal(got, g["tex_ids"])
