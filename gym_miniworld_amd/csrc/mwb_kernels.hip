@@ -1426,9 +1426,12 @@ __device__ __forceinline__ void copy_frame_range(uint8_t *__restrict__ dst, cons
 // part < 0: the whole frame; part 0 / 1: one half of it (the last envs of a bulk launch are cut in two so that the
 // launch drains in units of half a workgroup time) - the upper / lower rows for HWC frames, the left / right
 // strips for CWH ones, so that a half's bytes are one (three) contiguous run(s).
-template <int THREADS, int NBOX>
+template <int THREADS, int NBOX, bool LOOPED>
 __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const int part, unsigned char *smem) {
-    const int tid = threadIdx.x;
+    // LOOPED (the body sits in a loop over the regenerated-env list): make the lane id opaque to the optimiser so that
+    // nothing derived from it is hoisted out of that loop and kept alive across whole frames (200 -> 76 B/lane of scratch)
+    int tid = threadIdx.x;
+    if (LOOPED) asm volatile("" : "+v"(tid));
     const int W = d.W, H = d.H;
     int n_rooms = d.n_rooms[e];
     if (n_rooms < 0) n_rooms = 0;
@@ -1636,7 +1639,7 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     if (MODE == 1) {
         const int count = d.reset_count[0];
         for (int li = blockIdx.x; li < count; li += gridDim.x) {
-            render_env<THREADS, NBOX>(d, d.reset_list[li], -1, smem);
+            render_env<THREADS, NBOX, true>(d, d.reset_list[li], -1, smem);
             __syncthreads();   // LDS is reused by the next env of this block
         }
     } else {
@@ -1651,7 +1654,7 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
         const int e = __builtin_amdgcn_readfirstlane(d.order[slot]);
         if (MODE == 2 && d.reset_set[e]) return;   // block-uniform
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // read by every wave: stays in scalar registers
-        render_env<THREADS, NBOX>(d, e, part, smem);
+        render_env<THREADS, NBOX, false>(d, e, part, smem);
         if (threadIdx.x == 0) {
             const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
             if (d.wg_ts) { d.wg_ts[2 * b] = t0; d.wg_ts[2 * b + 1] = t1; }
