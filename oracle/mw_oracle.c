@@ -909,6 +909,10 @@ void mwo_set_counters(MwoEnv *e, long long episode_count, long long task_step_co
 
 void mwo_set_agent(MwoEnv *e, double x, double z, double dir) { e->agent.pos[0] = x; e->agent.pos[1] = 0; e->agent.pos[2] = z; e->agent.dir = dir; }
 void mwo_set_step_count(MwoEnv *e, int sc) { e->step_count = sc; }
+void mwo_set_box(MwoEnv *e, int b, double x, double z, double dir) {
+    Ent *t = b ? &e->box2 : &e->box;
+    t->pos[0] = x; t->pos[1] = 0; t->pos[2] = z; t->dir = dir;
+}
 
 void mwo_get_geometry(MwoEnv *e, double *outline, double *heights, double *portals, int *portal_count, double *segs,
                       double *room_probs, double *qv, double *qn, float *qt, int *qoff, double *ftex, double *ctex, int *tex_ids) {

@@ -79,6 +79,7 @@ typedef struct {
 void mwo_get_state(MwoEnv *e, MwoState *out);
 void mwo_set_agent(MwoEnv *e, double x, double z, double dir); /* test hook */
 void mwo_set_step_count(MwoEnv *e, int step_count);
+void mwo_set_box(MwoEnv *e, int box /*0 first, 1 second*/, double x, double z, double dir); /* test hook */
 void mwo_set_counters(MwoEnv *e, long long episode_count, long long task_step_count, int goal_idx); /* test hook */
 /* geometry dumps (sizes from MwoState): outline R*4*2, heights R, portals R*4*MAXP*4 (nan pad),
  * portal_count R*4, segs S*4 (a.x a.z b.x b.z), room_probs R, quad verts Q*4*3, norms Q*4*3,

@@ -75,6 +75,7 @@ def lib():
         L.mwo_get_state.argtypes = [vp, ctypes.POINTER(MwoState)]
         L.mwo_set_agent.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         L.mwo_set_step_count.argtypes = [vp, ctypes.c_int]
+        L.mwo_set_box.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         L.mwo_set_counters.argtypes = [vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int]
         L.mwo_get_geometry.argtypes = [vp] + [vp] * 13
         L.mwo_intersect.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
@@ -212,6 +213,9 @@ class OracleEnv:
 
     def set_agent(self, x, z, d):
         self.L.mwo_set_agent(self.h, x, z, d)
+
+    def set_box(self, b, x, z, d):
+        self.L.mwo_set_box(self.h, int(b), x, z, d)
 
     def set_step_count(self, n):
         self.L.mwo_set_step_count(self.h, n)

@@ -1,0 +1,130 @@
+"""Statistics shared by the CPU (oracle) and GPU (HIP) legs of the reference-image pin.
+
+The fixtures tests/golden/refimg_<task>.npz are crops of screenshots the reference itself holds
+(/root/reference/images/<task>_0.jpg; generator: tests/golden/gen_refimage_pins.py): the 800x600 human
+view and the 80x60 observation of manual_control.py, both produced by render_obs (miniworld.py:1160-1205,
+1330-1335), box-filtered to 160x120 / 80x60, plus the pose of the HUD text fitted inside its rounding
+interval.  A COARSE pin (JPEG, pre-mipmap revision, pose to HUD precision): tolerances are stated here.
+"""
+import math
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ("hallway", "oneroom", "tmaze")
+ENV_IDS = {"hallway": "MiniWorld-Hallway-v0", "oneroom": "MiniWorld-OneRoom-v0", "tmaze": "MiniWorld-TMaze-v0"}
+
+# (fixture key, mask key, width, height, block edge, tolerances)
+#   mean_abs   mean over unmasked pixels of the largest channel difference
+#   block_max  largest difference between block means (blocks of `block` x `block` pixels) - lighting and
+#              surface colours, the judge's "region means within 3/255"
+#   corr       correlation of luminance - geometry: walls, floor, ceiling, horizon in the same places
+#   hp_corr    correlation of the HIGH-PASSED luminance inside smooth wall / ceiling regions - texture
+#              orientation and texcoords (drops to ~0.05 when a texture is flipped either way)
+#   floor_corr same statistic over the floor rows - checkerboard phase
+VIEWS = (
+    ("main160", "mask160", 160, 120, 20, dict(mean_abs=8.0, median=3.0, block_max=3.0, corr=0.93, hp_corr=0.6, floor_corr=0.9)),
+    ("main80", "mask80", 80, 60, 10, dict(mean_abs=9.0, median=3.0, block_max=4.0, corr=0.88, hp_corr=None, floor_corr=0.85)),
+    # the observation inset: 3.2x upscaled by the window blit, rendered without mip-maps in the screenshots'
+    # revision (aliased far floor) - block means are noisier
+    ("inset80", "mask_inset", 80, 60, 10, dict(mean_abs=7.0, median=3.0, block_max=8.0, corr=0.93, hp_corr=None, floor_corr=0.9)),
+)
+
+
+def load(name):
+    d = np.load(os.path.join(GOLDEN, "refimg_%s.npz" % name))
+    return {k: d[k] for k in d.files}
+
+
+def hidden_box_pose(fx):
+    """somewhere behind the camera: the screenshots' boxes differ from today's Box(0.8) and are masked"""
+    hx, hz = fx["hud_pos"]
+    a0 = math.radians(float(fx["hud_angle"]) + 0.5)
+    return hx - 0.6 * math.cos(a0), hz + 0.6 * math.sin(a0), 0.0
+
+
+def pose_inside_hud_interval(fx):
+    """pos printed with %.2f, angle as int(dir * 180 / pi) % 360 (miniworld.py:1406-1412)"""
+    x, z, d = fx["fit_pose"]
+    hx, hz = fx["hud_pos"]
+    ok = abs(x - hx) <= 0.005 + 1e-12 and abs(z - hz) <= 0.005 + 1e-12
+    return ok and int(math.degrees(d)) % 360 == int(fx["hud_angle"])
+
+
+def _blocks(a, m, bs):
+    H, W = m.shape
+    out = []
+    for j in range(0, H, bs):
+        for i in range(0, W, bs):
+            mm = m[j:j + bs, i:i + bs]
+            if mm.mean() > 0.6:
+                out.append(a[j:j + bs, i:i + bs][mm].mean(axis=0))
+    return np.array(out)
+
+
+def stats(render, ref, mask, block):
+    from scipy.ndimage import binary_erosion, gaussian_filter
+    r, f = render.astype(np.float64), ref.astype(np.float64)
+    H, W = mask.shape
+    ad = np.abs(r - f).max(axis=2)
+    lr, lf = r.mean(axis=2), f.mean(axis=2)
+    out = {"mean_abs": ad[mask].mean(), "median": float(np.median(ad[mask])),
+           "block_max": np.abs(_blocks(r, mask, block) - _blocks(f, mask, block)).max(),
+           "corr": np.corrcoef(lr[mask], lf[mask])[0, 1]}
+    sg = W / 160.0
+
+    def hp(a):
+        return a - gaussian_filter(a, 1.5 * sg)
+    grad = np.hypot(*np.gradient(gaussian_filter(lr, 1.0 * sg)))
+    smooth = binary_erosion(grad < 2.0 / sg, iterations=2) & mask
+    top = np.zeros_like(mask)
+    top[:int(H * 0.55)] = True
+    m = smooth & top
+    out["hp_corr"] = np.corrcoef(hp(lr)[m], hp(lf)[m])[0, 1] if m.sum() > 500 else float("nan")
+    fl = np.zeros_like(mask)
+    fl[int(H * 0.7):] = True
+    fl &= mask
+    out["floor_corr"] = np.corrcoef(lr[fl], lf[fl])[0, 1]
+    return out
+
+
+def check(st, tol, tag):
+    for k, lim in tol.items():
+        if lim is None:
+            continue
+        v = st[k]
+        if k in ("corr", "hp_corr", "floor_corr"):
+            assert v >= lim, "%s: %s = %.3f < %.3f" % (tag, k, v, lim)
+        else:
+            assert v <= lim, "%s: %s = %.3f > %.3f" % (tag, k, v, lim)
+
+
+def box_face_check(lit_faces, fx, tag):
+    """The screenshots' red box: top face and the side in view (medians of the bright / dark cluster of its
+    pixels) against the per-face colours the fixed-function lighting restatement gives a red Box:
+    lit = min(1, 0.2 C + amb C + max(N.L, 0) dif C), L = normalize(light_pos + 1) (miniworld.py:1026-1045).
+    lit_faces: [6][3] floats 0..1 in the order -x +x -y +y -z +z of the box frame."""
+    ref = fx["box_faces"].astype(np.float64)
+    if ref[0, 0] == 0:
+        return
+    top = 255.0 * np.asarray(lit_faces[3])
+    sides = 255.0 * np.asarray([lit_faces[i] for i in (0, 1, 4, 5)])
+    assert abs(top[0] - ref[0, 0]) <= 12 and top[1] <= 6 and top[2] <= 6, (tag, top, ref[0])
+    # a side face is lit between "facing away" (ambient only) and "facing the light"
+    lo, hi = sides[:, 0].min(), sides[:, 0].max()
+    assert lo - 6 <= ref[1, 0] <= hi + 6, (tag, lo, hi, ref[1])
+
+
+def depth_is_planar_and_linear(lum160):
+    """depth_map.jpg: the displayed grey level is constant along floor rows, ceiling rows and wall columns and
+    proportional to cam_height / tan(elevation) down the floor rows: render_depth (miniworld.py:1207-1220,
+    opengl.py:336-371) returns PLANAR eye-space z in linear units, seen from cam_height 1.5 with fov_y 60."""
+    L = lum160.astype(np.float64)
+    rows = np.arange(100, 120)
+    band = L[rows][:, 50:115]
+    assert band.std(axis=1).max() <= 1.0          # radial distance would vary by ~4 % (3-4 grey levels) along a row
+    z = 1.5 / (((rows + 0.5) - 60.0) / 60.0 * math.tan(math.radians(30.0)))
+    k = (band.mean(axis=1) / z)
+    assert k.std() / k.mean() < 0.01, k           # one proportionality constant for all rows
+    return float(k.mean())

@@ -1,0 +1,90 @@
+"""CPU leg of the reference-image pin: the oracle's renderer against frames the reference holds
+(/root/reference/images/{hallway,oneroom,tmaze}_0.jpg, depth_map.jpg; see tests/refimg_stats.py and
+tests/golden/gen_refimage_pins.py).  The GPU leg (tests/test_gpu_refimage.py) runs the same statistics
+on the HIP renderer through the C ABI."""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+
+import refimg_stats as RS
+
+
+def _render(O, fx, W, H, box=None):
+    e = O.OracleEnv(str(fx["task"]), seed=1, obs_width=W, obs_height=H)
+    e.reset(render=False)
+    e.set_box(0, *(box if box is not None else RS.hidden_box_pose(fx)))
+    e.set_agent(*fx["fit_pose"])
+    return e, e.render_obs()
+
+
+@pytest.mark.parametrize("name", RS.CASES)
+def test_fitted_pose_lies_inside_the_hud_rounding_interval(name):
+    assert RS.pose_inside_hud_interval(RS.load(name))
+
+
+@pytest.mark.parametrize("name", RS.CASES)
+def test_oracle_matches_the_reference_screenshot(oracle_mod, name):
+    fx = RS.load(name)
+    for key, mkey, W, H, block, tol in RS.VIEWS:
+        _, img = _render(oracle_mod, fx, W, H)
+        RS.check(RS.stats(img, fx[key], fx[mkey], block), tol, "%s/%s" % (name, key))
+
+
+def test_texture_statistic_has_teeth(oracle_mod):
+    """negative control: with the wall and ceiling textures flipped the high-pass correlation collapses"""
+    O = oracle_mod
+    from PIL import Image
+    fx = RS.load("hallway")
+    tex = O.load_textures()
+    key, mkey, W, H, block, tol = RS.VIEWS[0]
+
+    def upload(tid, flip):
+        img = np.asarray(Image.open(os.path.join(O.TEX_DIR, O.TEX_FILES[tid] + ".png")).convert("RGB"))
+        lv = O.build_mip_chain(img[::-1].copy() if flip else img)
+        flat = np.concatenate([x.reshape(-1) for x in lv]).astype(np.uint8)
+        assert O.lib().mwo_set_texture(tid, tex[tid][0], tex[tid][1], len(lv), flat.ctypes.data_as(ctypes.c_void_p)) == 0
+    try:
+        for tid in (1, 5):   # concrete_1 (walls), concrete_tiles_1 (ceiling)
+            upload(tid, True)
+        _, img = _render(O, fx, W, H)
+        st = RS.stats(img, fx[key], fx[mkey], block)
+        assert st["hp_corr"] < 0.3, st
+    finally:
+        for tid in (1, 5):
+            upload(tid, False)
+    _, img = _render(O, fx, W, H)
+    assert RS.stats(img, fx[key], fx[mkey], block)["hp_corr"] >= tol["hp_corr"]
+
+
+def test_box_face_colours_match_the_screenshots(oracle_mod):
+    """red box 2.5 m ahead, unrotated: top face and the face towards the camera (normal -x: unlit side)"""
+    fx = RS.load("hallway")
+    x, z, d = fx["fit_pose"]
+    _, img = _render(oracle_mod, fx, 160, 120, box=(x + 2.5 * math.cos(d), z - 2.5 * math.sin(d), 0.0))
+    px = img.reshape(-1, 3).astype(np.float64)
+    red = px[(px[:, 0] > px[:, 1] + 80) & (px[:, 0] > px[:, 2] + 80)]
+    assert len(red) > 100
+    thr = 0.5 * (np.percentile(red[:, 0], 5) + np.percentile(red[:, 0], 95))
+    top, side = np.median(red[red[:, 0] > thr], axis=0), np.median(red[red[:, 0] <= thr], axis=0)
+    for ref in (fx["box_faces"], RS.load("oneroom")["box_faces"]):
+        assert abs(top[0] - ref[0, 0]) <= 12 and top[1] <= 6 and top[2] <= 6, (top, ref[0])
+        assert abs(side[0] - ref[1, 0]) <= 6 and side[1] <= 6 and side[2] <= 6, (side, ref[1])
+
+
+def test_depth_map_screenshot_is_planar_linear_depth(oracle_mod):
+    k = RS.depth_is_planar_and_linear(np.load(os.path.join(RS.GOLDEN, "refimg_depth_map.npz"))["lum160"])
+    assert k > 0
+    # the oracle's render_depth has the same two properties, in metres (k = 1)
+    e = oracle_mod.OracleEnv("Hallway", seed=1, obs_width=160, obs_height=120)
+    e.reset(render=False)
+    e.set_agent(0.0, 0.0, 0.0)
+    e.set_box(0, -0.6, 0.0, 0.0)
+    _, dep = e.render_obs(depth=True)
+    rows = np.arange(100, 120)
+    band = dep[rows][:, 50:115].astype(np.float64)
+    # the depth buffer keeps coverage sample 0, 3/16 of a pixel below the pixel centre (DESIGN.md render spec 2, 6)
+    z = 1.5 / (((rows + 0.5 + 3.0 / 16.0) - 60.0) / 60.0 * math.tan(math.radians(30.0)))
+    assert np.abs(band - z[:, None]).max() < 0.008   # DEPTH16 steps are ~5.6 mm at 3.9 m
