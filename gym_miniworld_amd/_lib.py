@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(HERE, "libmwbatch.so")
 
 NPARAM = 13
 ROOM_WORDS = 24
-ABI_VERSION = 3
+ABI_VERSION = 4
+MT_WORDS = 625
 
 TASK_IDS = {"Hallway": 0, "OneRoom": 1, "FourRooms": 2, "Maze": 3, "TMaze": 4, "TMazeTwoBox": 5,
             "SimToRealGoTo": 6, "SimToRealPush": 7}
@@ -42,17 +43,16 @@ class MwbOutputs(ctypes.Structure):
 
 class MwbState(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "agent_pos", "agent_dir", "box_pos", "box_dir", "box_color", "cam", "sky_color", "light_pos",
+        "agent_pos", "agent_dir", "box_pos", "box_dir", "box_color", "box_size", "cam", "sky_color", "light_pos",
         "light_color", "light_ambient", "step_count", "rng_pos", "rng_keysum", "n_rooms", "n_segs",
-        "box2_pos", "box2_dir", "box2_color", "goal_idx", "episode_count", "task_step_count",
-        "box_size", "box2_size", "goal_dist")]
+        "goal_idx", "episode_count", "task_step_count", "goal_dist", "rng_state")]
 
 
 EXPORTS = [
     "mwb_create", "mwb_destroy", "mwb_last_error", "mwb_abi_version", "mwb_set_texture", "mwb_seed", "mwb_reset",
     "mwb_step", "mwb_render", "mwb_get_outputs", "mwb_get_state", "mwb_set_agent", "mwb_intersect",
     "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read", "mwb_stack_enable", "mwb_stack_update", "mwb_check", "mwb_seed_key",
-    "mwb_set_task_state", "mwb_set_domain_rand", "mwb_num_textures", "mwb_debug_wg_times",
+    "mwb_set_task_state", "mwb_set_domain_rand", "mwb_num_textures", "mwb_debug_wg_times", "mwb_set_state", "mwb_num_boxes",
 ]
 
 _lib = None
@@ -85,12 +85,14 @@ def load():
     L.mwb_render.argtypes = [vp, vp]
     L.mwb_get_outputs.argtypes = [vp, ctypes.POINTER(MwbOutputs)]
     L.mwb_get_state.argtypes = [vp, i32, i32, ctypes.POINTER(MwbState)]
+    L.mwb_set_state.argtypes = [vp, i32, i32, ctypes.POINTER(MwbState)]
+    L.mwb_num_boxes.argtypes = [vp]
     L.mwb_set_agent.argtypes = [vp, i32, i32, vp, vp, vp]
     L.mwb_set_task_state.argtypes = [vp, i32, i32, vp, vp, vp]
     L.mwb_set_domain_rand.argtypes = [vp, i32]
     L.mwb_num_textures.argtypes = [vp]
     L.mwb_debug_wg_times.argtypes = [vp, vp, i32]
-    L.mwb_intersect.argtypes = [vp, i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(i32)]
+    L.mwb_intersect.argtypes = [vp, i32, i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(i32)]
     L.mwb_get_geometry.argtypes = [vp, i32, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.mwb_timing_enable.argtypes = [vp, i32]
     L.mwb_stack_enable.argtypes = [vp, i32, i32]

@@ -222,24 +222,61 @@ class BatchedMiniWorld:
         """Synchronous: raises if world generation ever flagged a failure (see mwb_check)."""
         _lib.check(self.L.mwb_check(self.h))
 
-    def get_state(self, first=0, count=None):
+    _STATE_F64 = {"agent_pos": (3,), "agent_dir": (), "cam": (4,), "sky_color": (3,), "light_pos": (3,),
+                  "light_color": (3,), "light_ambient": (3,), "goal_dist": ()}
+    _STATE_BOX = {"box_pos": (3,), "box_dir": (), "box_color": (3,), "box_size": ()}   # [count][B] + shape
+    _STATE_INT = {"step_count": np.int32, "rng_pos": np.int32, "rng_keysum": np.uint32, "n_rooms": np.int32,
+                  "n_segs": np.int32, "goal_idx": np.int32, "episode_count": np.int64, "task_step_count": np.int64}
+
+    def get_state(self, first=0, count=None, rng_state=False):
+        """Host snapshot of the env range (mwb_get_state).  Box fields come as "boxes_pos" [count, B, 3],
+        "boxes_dir", "boxes_color", "boxes_size" and, for the one- and two-box tasks, also under the
+        reference's attribute names: "box_*" = entity 0 (env.box / red_box), "box2_*" = entity 1."""
         self.check()
         count = self.num_envs - first if count is None else count
-        shapes = {"agent_pos": (count, 3), "agent_dir": (count,), "box_pos": (count, 3), "box_dir": (count,),
-                  "box_color": (count, 3), "cam": (count, 4), "sky_color": (count, 3), "light_pos": (count, 3),
-                  "light_color": (count, 3), "light_ambient": (count, 3),
-                  "box2_pos": (count, 3), "box2_dir": (count,), "box2_color": (count, 3),
-                  "box_size": (count,), "box2_size": (count,), "goal_dist": (count,)}
-        out = {k: np.zeros(s, np.float64) for k, s in shapes.items()}
-        out.update({"step_count": np.zeros(count, np.int32), "rng_pos": np.zeros(count, np.int32),
-                    "rng_keysum": np.zeros(count, np.uint32), "n_rooms": np.zeros(count, np.int32),
-                    "n_segs": np.zeros(count, np.int32), "goal_idx": np.zeros(count, np.int32),
-                    "episode_count": np.zeros(count, np.int64), "task_step_count": np.zeros(count, np.int64)})
+        B = self.n_boxes
+        out = {k: np.zeros((count,) + s, np.float64) for k, s in self._STATE_F64.items()}
+        boxes = {k: np.zeros((count, B) + s, np.float64) for k, s in self._STATE_BOX.items()}
+        out.update({k: np.zeros(count, dt) for k, dt in self._STATE_INT.items()})
+        if rng_state:
+            out["rng_state"] = np.zeros((count, _lib.MT_WORDS), np.uint32)
         st = _lib.MwbState()
-        for k, v in out.items():
+        for k, v in list(out.items()) + list(boxes.items()):
             setattr(st, k, v.ctypes.data_as(ctypes.c_void_p))
         _lib.check(self.L.mwb_get_state(self.h, first, count, ctypes.byref(st)))
+        for k, v in boxes.items():
+            out["boxes_" + k[4:]] = v
+            out[k] = v[:, 0]
+            out["box2_" + k[4:]] = v[:, 1] if B > 1 else np.zeros_like(v[:, 0])
         return out
+
+    def set_state(self, first, **fields):
+        """Overwrite simulator state of envs first .. first+count-1 (mwb_set_state).  Keys as returned by
+        get_state(): agent_pos [count,3], agent_dir, boxes_pos [count,B,3], boxes_dir, boxes_color, boxes_size,
+        cam, sky_color, light_*, step_count, goal_idx, episode_count, task_step_count, goal_dist,
+        rng_state [count,625]."""
+        st = _lib.MwbState()
+        keep, count = [], None
+        for k, v in fields.items():
+            name = "box_" + k[6:] if k.startswith("boxes_") else k
+            if name in self._STATE_BOX:
+                shape, dt = (-1, self.n_boxes) + self._STATE_BOX[name], np.float64
+            elif name in self._STATE_F64:
+                shape, dt = (-1,) + self._STATE_F64[name], np.float64
+            elif name == "rng_state":
+                shape, dt = (-1, _lib.MT_WORDS), np.uint32
+            elif name in ("step_count", "goal_idx", "episode_count", "task_step_count"):
+                shape, dt = (-1,), self._STATE_INT[name]
+            else:
+                raise KeyError("set_state: %r is not a writable state field" % k)
+            a = np.ascontiguousarray(np.asarray(v, dtype=dt).reshape(shape))
+            if count is not None and a.shape[0] != count:
+                raise ValueError("set_state: fields disagree on the number of envs")
+            count = a.shape[0]
+            keep.append(a)
+            setattr(st, name, a.ctypes.data_as(ctypes.c_void_p))
+        if count:
+            _lib.check(self.L.mwb_set_state(self.h, int(first), int(count), ctypes.byref(st)))
 
     def set_agent(self, first, pos_xz=None, dir=None, step_count=None):
         arrs = [None if a is None else np.ascontiguousarray(a, dt) for a, dt in
@@ -261,9 +298,13 @@ class BatchedMiniWorld:
         ptrs = [None if a is None else a.ctypes.data_as(ctypes.c_void_p) for a in arrs]
         _lib.check(self.L.mwb_set_task_state(self.h, first, count, *ptrs))
 
-    def intersect(self, env, x, z, radius=0.4):
+    def intersect(self, env, x, z, radius=0.4, ent=None):
+        """MiniWorldEnv.intersect(ent, pos, radius) of env `env` (miniworld.py:933-959).  ent = index of the
+        querying entity in the entity list (boxes first, the agent last; default: the agent), -1 = nobody is
+        skipped.  Returns 0 none, 1 wall, 2 + k = entity k."""
         r = ctypes.c_int()
-        _lib.check(self.L.mwb_intersect(self.h, env, float(x), float(z), float(radius), ctypes.byref(r)))
+        ent = self.n_boxes if ent is None else int(ent)
+        _lib.check(self.L.mwb_intersect(self.h, env, ent, float(x), float(z), float(radius), ctypes.byref(r)))
         return r.value
 
     def get_geometry(self, env, max_rooms=512, max_segs=2048):

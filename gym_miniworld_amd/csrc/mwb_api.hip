@@ -23,6 +23,22 @@ static int set_err(int code, const std::string &msg) { g_err = msg; return code;
             return set_err(MWB_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
     } while (0)
 
+// Every entry point runs on the handle's device and puts the caller's current device back on the way out
+// (torch.cuda.current_device() reads the runtime's current device: a handle on cuda:1 must not move it).
+struct DevGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DevGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) err = hipSetDevice(dev); else if (err == hipSuccess) prev = -1;
+    }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define USE_DEVICE(dev)                                                                             \
+    DevGuard _dev_guard(dev);                                                                        \
+    if (_dev_guard.err != hipSuccess)                                                                \
+        return set_err(MWB_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(_dev_guard.err))
+
 struct mwb_handle {
     mwb_config cfg;
     MwbDev dev;
@@ -185,7 +201,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return set_err(MWB_EHIP, "mwb_create: no HIP device available (this library has no CPU path)");
     if (cfg->device < 0 || cfg->device >= ndev) return set_err(MWB_EINVAL, "mwb_create: bad device ordinal");
-    HIP_TRY(hipSetDevice(cfg->device));
+    USE_DEVICE(cfg->device);
 
     mwb_handle *h = new mwb_handle();
     h->cfg = *cfg;
@@ -291,8 +307,10 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     for (int i = 0; i < MWB_MAX_TEX; i++) { h->tex_w[i] = 0; h->tex_h[i] = 0; }
     if (int prc = mwb_prepare_kernels(d)) {
         mwb_destroy(h);
-        return set_err(prc == -1 ? MWB_EINVAL : MWB_EHIP, prc == -1 ? "mwb_create: world too large for the 160 KB LDS staging buffers"
-                                                                   : "mwb_create: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        return set_err(prc == -2 ? MWB_EHIP : MWB_EINVAL,
+                       prc == -1 ? "mwb_create: world + observation too large for the 160 KB LDS staging buffers (room table + W*H*3 frame)"
+                       : prc == -3 ? "mwb_create: observation too large for the 16-bit pixel queue (H << ceil(log2 W) must not exceed 65536)"
+                                   : "mwb_create: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     }
     *out = h;
     return MWB_OK;
@@ -300,7 +318,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
 
 extern "C" int mwb_destroy(mwb_handle *h) {
     if (!h) return MWB_OK;
-    hipSetDevice(h->cfg.device);
+    DevGuard _dev_guard(h->cfg.device);
     hipDeviceSynchronize();
     for (void *p : h->allocs) hipFree(p);
     if (h->texels_dev) hipFree(h->texels_dev);
@@ -363,7 +381,7 @@ extern "C" int mwb_set_texture(mwb_handle *h, int tex_id, int width, int height,
 }
 
 static int upload_textures(mwb_handle *h) {
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     const int n_tex = h->dev.n_tex;
     for (int i = 0; i < n_tex; i++)
         if (h->tex_w[i] == 0)
@@ -392,7 +410,7 @@ static int upload_textures(mwb_handle *h) {
 // ---------------------------------------------------------------------------------- simulation
 extern "C" int mwb_seed(mwb_handle *h, const uint64_t *seeds) {
     if (!h || !seeds) return set_err(MWB_EINVAL, "mwb_seed: null argument");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     std::vector<uint32_t> st((size_t)h->dev.N * MWB_MT_WORDS);
     for (int e = 0; e < h->dev.N; e++) {
         uint32_t key[2];
@@ -439,15 +457,15 @@ static int render_tail(mwb_handle *h, int mode, hipStream_t s) {
     return MWB_OK;
 }
 
-static int ensure_ready(mwb_handle *h) {
-    if (!h) return set_err(MWB_EINVAL, "null handle");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+static int ensure_ready(mwb_handle *h) {   // the caller holds the device guard
     if (!h->seeded) return set_err(MWB_ESTATE, "mwb_seed must be called before reset/step (the reference seeds from entropy; this library refuses to)");
     if (h->textures_dirty || !h->have_textures) { int rc = upload_textures(h); if (rc) return rc; }
     return MWB_OK;
 }
 
 extern "C" int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream) {
+    if (!h) return set_err(MWB_EINVAL, "null handle");
+    USE_DEVICE(h->cfg.device);
     int rc = ensure_ready(h); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     rc = timing_begin(h, s); if (rc) return rc;
@@ -463,6 +481,8 @@ extern "C" int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream) {
 }
 
 extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask_dev, void *stream) {
+    if (!h) return set_err(MWB_EINVAL, "null handle");
+    USE_DEVICE(h->cfg.device);
     int rc = ensure_ready(h); if (rc) return rc;
     if (!actions_dev) return set_err(MWB_EINVAL, "mwb_step: null actions");
     hipStream_t s = (hipStream_t)stream;
@@ -505,6 +525,8 @@ extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t
 }
 
 extern "C" int mwb_render(mwb_handle *h, void *stream) {
+    if (!h) return set_err(MWB_EINVAL, "null handle");
+    USE_DEVICE(h->cfg.device);
     int rc = ensure_ready(h); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     rc = timing_begin(h, s); if (rc) return rc;
@@ -526,7 +548,7 @@ extern "C" int mwb_get_outputs(mwb_handle *h, mwb_outputs *out) {
 
 extern "C" int mwb_check(mwb_handle *h) {
     if (!h) return set_err(MWB_EINVAL, "mwb_check: null handle");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     int32_t flag = 0;
     HIP_TRY(hipMemcpy(&flag, h->dev.error_flag, sizeof(flag), hipMemcpyDeviceToHost));
@@ -542,7 +564,7 @@ extern "C" int mwb_stack_enable(mwb_handle *h, int nstack, int dtype) {
     if (d.layout != MWB_LAYOUT_CWH) return set_err(MWB_EINVAL, "mwb_stack_enable: the frame stack is channel-first, create the handle with MWB_LAYOUT_CWH");
     if ((d.W * d.H) % 4) return set_err(MWB_EINVAL, "mwb_stack_enable: W*H must be a multiple of 4");
     if (h->stack) return set_err(MWB_ESTATE, "mwb_stack_enable: already enabled");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     size_t bytes = (size_t)d.N * nstack * 3 * d.W * d.H * (dtype == 1 ? 4 : 1);
     uint8_t *p = nullptr;
     int rc = dev_alloc(h, &p, bytes);
@@ -553,7 +575,7 @@ extern "C" int mwb_stack_enable(mwb_handle *h, int nstack, int dtype) {
 
 extern "C" int mwb_stack_update(mwb_handle *h, int after_reset, void *stream) {
     if (!h || !h->stack) return set_err(MWB_ESTATE, "mwb_stack_update: call mwb_stack_enable first");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     mwb_launch_stack(h->dev, h->stack, h->stack_n, h->stack_dtype, after_reset, (hipStream_t)stream);
     return check_launch("stack_kernel");
 }
@@ -566,12 +588,44 @@ static int fetch(T *dst, const T *src_dev, size_t first, size_t count, size_t st
     return MWB_OK;
 }
 
+extern "C" int mwb_num_boxes(mwb_handle *h) { return h ? h->dev.n_boxes : 0; }
+
+// box arrays live as [B][N] planes on the device and as [count][B](x width) rows in mwb_state
+static int fetch_boxes(double *dst, const double *src_dev, size_t N, int B, size_t first, size_t count, size_t width) {
+    if (!dst) return MWB_OK;
+    std::vector<double> plane(count * width);
+    for (int b = 0; b < B; b++) {
+        HIP_TRY(hipMemcpy(plane.data(), src_dev + ((size_t)b * N + first) * width, count * width * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < count; i++)
+            for (size_t k = 0; k < width; k++) dst[(i * B + b) * width + k] = plane[i * width + k];
+    }
+    return MWB_OK;
+}
+static int store_boxes(const double *src, double *dst_dev, size_t N, int B, size_t first, size_t count, size_t width) {
+    if (!src) return MWB_OK;
+    std::vector<double> plane(count * width);
+    for (int b = 0; b < B; b++) {
+        for (size_t i = 0; i < count; i++)
+            for (size_t k = 0; k < width; k++) plane[i * width + k] = src[(i * B + b) * width + k];
+        HIP_TRY(hipMemcpy(dst_dev + ((size_t)b * N + first) * width, plane.data(), count * width * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return MWB_OK;
+}
+template <typename T>
+static int store(const T *src, T *dst_dev, size_t first, size_t count, size_t stride) {
+    if (!src) return MWB_OK;
+    HIP_TRY(hipMemcpy(dst_dev + first * stride, src, count * stride * sizeof(T), hipMemcpyHostToDevice));
+    return MWB_OK;
+}
+
 extern "C" int mwb_get_state(mwb_handle *h, int first, int count, mwb_state *o) {
     if (!h || !o) return set_err(MWB_EINVAL, "mwb_get_state: null argument");
     const MwbDev &d = h->dev;
     if (first < 0 || count < 0 || first + count > d.N) return set_err(MWB_EINVAL, "mwb_get_state: env range out of bounds");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t)d.N;
+    const int B = d.n_boxes;
     std::vector<double> a(count), b(count);
     int rc;
     if (o->agent_pos) {
@@ -580,30 +634,15 @@ extern "C" int mwb_get_state(mwb_handle *h, int first, int count, mwb_state *o) 
         for (int i = 0; i < count; i++) { o->agent_pos[i * 3] = a[i]; o->agent_pos[i * 3 + 1] = 0.0; o->agent_pos[i * 3 + 2] = b[i]; }
     }
     if (o->box_pos) {
-        if ((rc = fetch(a.data(), d.box_x, first, count, 1))) return rc;
-        if ((rc = fetch(b.data(), d.box_z, first, count, 1))) return rc;
-        for (int i = 0; i < count; i++) { o->box_pos[i * 3] = a[i]; o->box_pos[i * 3 + 1] = 0.0; o->box_pos[i * 3 + 2] = b[i]; }
+        std::vector<double> bx((size_t)count * B), bz((size_t)count * B);
+        if ((rc = fetch_boxes(bx.data(), d.box_x, N, B, first, count, 1))) return rc;
+        if ((rc = fetch_boxes(bz.data(), d.box_z, N, B, first, count, 1))) return rc;
+        for (size_t i = 0; i < (size_t)count * B; i++) { o->box_pos[i * 3] = bx[i]; o->box_pos[i * 3 + 1] = 0.0; o->box_pos[i * 3 + 2] = bz[i]; }
     }
     if ((rc = fetch(o->agent_dir, d.agent_dir, first, count, 1))) return rc;
-    if ((rc = fetch(o->box_dir, d.box_dir, first, count, 1))) return rc;
-    if ((rc = fetch(o->box_color, d.box_color, first, count, 3))) return rc;
-    if (d.n_boxes == 2) {   // box 1 (blue) lives in the second plane of the box arrays
-        const size_t N = (size_t)d.N;
-        if (o->box2_pos) {
-            if ((rc = fetch(a.data(), d.box_x + N, first, count, 1))) return rc;
-            if ((rc = fetch(b.data(), d.box_z + N, first, count, 1))) return rc;
-            for (int i = 0; i < count; i++) { o->box2_pos[i * 3] = a[i]; o->box2_pos[i * 3 + 1] = 0.0; o->box2_pos[i * 3 + 2] = b[i]; }
-        }
-        if ((rc = fetch(o->box2_dir, d.box_dir + N, first, count, 1))) return rc;
-        if ((rc = fetch(o->box2_color, d.box_color + N * 3, first, count, 3))) return rc;
-    } else {
-        if (o->box2_pos) memset(o->box2_pos, 0, sizeof(double) * 3 * count);
-        if (o->box2_dir) memset(o->box2_dir, 0, sizeof(double) * count);
-        if (o->box2_color) memset(o->box2_color, 0, sizeof(double) * 3 * count);
-    }
-    if ((rc = fetch(o->box_size, d.box_size, first, count, 1))) return rc;
-    if (d.n_boxes == 2) { if ((rc = fetch(o->box2_size, d.box_size + d.N, first, count, 1))) return rc; }
-    else if (o->box2_size) memset(o->box2_size, 0, sizeof(double) * count);
+    if ((rc = fetch_boxes(o->box_dir, d.box_dir, N, B, first, count, 1))) return rc;
+    if ((rc = fetch_boxes(o->box_color, d.box_color, N, B, first, count, 3))) return rc;
+    if ((rc = fetch_boxes(o->box_size, d.box_size, N, B, first, count, 1))) return rc;
     if ((rc = fetch(o->goal_dist, d.goal_dist, first, count, 1))) return rc;
     if ((rc = fetch(o->goal_idx, d.goal_idx, first, count, 1))) return rc;
     if ((rc = fetch(o->episode_count, d.episode_count, first, count, 1))) return rc;
@@ -616,7 +655,7 @@ extern "C" int mwb_get_state(mwb_handle *h, int first, int count, mwb_state *o) 
     if ((rc = fetch(o->step_count, d.step_count, first, count, 1))) return rc;
     if ((rc = fetch(o->n_rooms, d.n_rooms, first, count, 1))) return rc;
     if ((rc = fetch(o->n_segs, d.n_segs, first, count, 1))) return rc;
-    if (o->rng_pos || o->rng_keysum) {
+    if (o->rng_pos || o->rng_keysum || o->rng_state) {
         std::vector<uint32_t> st((size_t)count * MWB_MT_WORDS);
         if ((rc = fetch(st.data(), d.rng, first, count, MWB_MT_WORDS))) return rc;
         for (int i = 0; i < count; i++) {
@@ -625,7 +664,53 @@ extern "C" int mwb_get_state(mwb_handle *h, int first, int count, mwb_state *o) 
             if (o->rng_keysum) o->rng_keysum[i] = (uint32_t)(sum & 0xFFFFFFFFu);
             if (o->rng_pos) o->rng_pos[i] = (int32_t)st[(size_t)i * MWB_MT_WORDS + 624];
         }
+        if (o->rng_state) memcpy(o->rng_state, st.data(), st.size() * sizeof(uint32_t));
     }
+    return MWB_OK;
+}
+
+extern "C" int mwb_set_state(mwb_handle *h, int first, int count, const mwb_state *in) {
+    if (!h || !in) return set_err(MWB_EINVAL, "mwb_set_state: null argument");
+    const MwbDev &d = h->dev;
+    if (first < 0 || count < 0 || first + count > d.N) return set_err(MWB_EINVAL, "mwb_set_state: env range out of bounds");
+    if (in->goal_idx)
+        for (int i = 0; i < count; i++)
+            if (in->goal_idx[i] < 0 || in->goal_idx[i] > 1) return set_err(MWB_EINVAL, "mwb_set_state: goal_idx must be 0 or 1");
+    if (in->rng_state)
+        for (int i = 0; i < count; i++)
+            if (in->rng_state[(size_t)i * MWB_MT_WORDS + 624] > 624u) return set_err(MWB_EINVAL, "mwb_set_state: MT19937 position must be 0..624");
+    USE_DEVICE(h->cfg.device);
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t N = (size_t)d.N;
+    const int B = d.n_boxes;
+    int rc;
+    if (in->agent_pos) {
+        std::vector<double> a(count), b(count);
+        for (int i = 0; i < count; i++) { a[i] = in->agent_pos[i * 3]; b[i] = in->agent_pos[i * 3 + 2]; }
+        if ((rc = store(a.data(), d.agent_x, first, count, 1))) return rc;
+        if ((rc = store(b.data(), d.agent_z, first, count, 1))) return rc;
+    }
+    if (in->box_pos) {
+        std::vector<double> bx((size_t)count * B), bz((size_t)count * B);
+        for (size_t i = 0; i < (size_t)count * B; i++) { bx[i] = in->box_pos[i * 3]; bz[i] = in->box_pos[i * 3 + 2]; }
+        if ((rc = store_boxes(bx.data(), d.box_x, N, B, first, count, 1))) return rc;
+        if ((rc = store_boxes(bz.data(), d.box_z, N, B, first, count, 1))) return rc;
+    }
+    if ((rc = store(in->agent_dir, d.agent_dir, first, count, 1))) return rc;
+    if ((rc = store_boxes(in->box_dir, d.box_dir, N, B, first, count, 1))) return rc;
+    if ((rc = store_boxes(in->box_color, d.box_color, N, B, first, count, 3))) return rc;
+    if ((rc = store_boxes(in->box_size, d.box_size, N, B, first, count, 1))) return rc;
+    if ((rc = store(in->goal_dist, d.goal_dist, first, count, 1))) return rc;
+    if ((rc = store(in->goal_idx, d.goal_idx, first, count, 1))) return rc;
+    if ((rc = store(in->episode_count, d.episode_count, first, count, 1))) return rc;
+    if ((rc = store(in->task_step_count, d.task_step_count, first, count, 1))) return rc;
+    if ((rc = store(in->cam, d.cam, first, count, 4))) return rc;
+    if ((rc = store(in->sky_color, d.sky_color, first, count, 3))) return rc;
+    if ((rc = store(in->light_pos, d.light_pos, first, count, 3))) return rc;
+    if ((rc = store(in->light_color, d.light_color, first, count, 3))) return rc;
+    if ((rc = store(in->light_ambient, d.light_ambient, first, count, 3))) return rc;
+    if ((rc = store(in->step_count, d.step_count, first, count, 1))) return rc;
+    if ((rc = store(in->rng_state, d.rng, first, count, MWB_MT_WORDS))) return rc;
     return MWB_OK;
 }
 
@@ -633,7 +718,7 @@ extern "C" int mwb_set_agent(mwb_handle *h, int first, int count, const double *
     if (!h) return set_err(MWB_EINVAL, "mwb_set_agent: null handle");
     const MwbDev &d = h->dev;
     if (first < 0 || count < 0 || first + count > d.N) return set_err(MWB_EINVAL, "mwb_set_agent: env range out of bounds");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     if (pos_xz) {
         std::vector<double> a(count), b(count);
@@ -653,7 +738,7 @@ extern "C" int mwb_num_textures(mwb_handle *h) { return h ? h->dev.n_tex : 0; }
 extern "C" int mwb_debug_wg_times(mwb_handle *h, unsigned long long *out, int max_wgs) {
     if (!h || !out) return set_err(MWB_EINVAL, "mwb_debug_wg_times: null argument");
     if (!h->dev.wg_ts) return set_err(MWB_ESTATE, "mwb_debug_wg_times: create the handle with MWB_DEBUG bit 4 set");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     int n = h->dev.N + h->dev.split_envs;
     if (n > max_wgs) n = max_wgs;
@@ -663,7 +748,7 @@ extern "C" int mwb_debug_wg_times(mwb_handle *h, unsigned long long *out, int ma
 
 extern "C" int mwb_set_domain_rand(mwb_handle *h, int domain_rand) {
     if (!h) return set_err(MWB_EINVAL, "mwb_set_domain_rand: null handle");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());   // kernels in flight took the struct by value; order the change after them
     h->dev.domain_rand = domain_rand ? 1 : 0;
     h->cfg.domain_rand = h->dev.domain_rand;
@@ -675,7 +760,7 @@ extern "C" int mwb_set_task_state(mwb_handle *h, int first, int count, const int
     if (!h) return set_err(MWB_EINVAL, "mwb_set_task_state: null handle");
     const MwbDev &d = h->dev;
     if (first < 0 || count < 0 || first + count > d.N) return set_err(MWB_EINVAL, "mwb_set_task_state: env range out of bounds");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     if (episode_count) HIP_TRY(hipMemcpy(d.episode_count + first, episode_count, count * sizeof(int64_t), hipMemcpyHostToDevice));
     if (task_step_count) HIP_TRY(hipMemcpy(d.task_step_count + first, task_step_count, count * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -687,11 +772,12 @@ extern "C" int mwb_set_task_state(mwb_handle *h, int first, int count, const int
     return MWB_OK;
 }
 
-extern "C" int mwb_intersect(mwb_handle *h, int env, double x, double z, double radius, int *result) {
+extern "C" int mwb_intersect(mwb_handle *h, int env, int ent, double x, double z, double radius, int *result) {
     if (!h || !result) return set_err(MWB_EINVAL, "mwb_intersect: null argument");
     if (env < 0 || env >= h->dev.N) return set_err(MWB_EINVAL, "mwb_intersect: env out of range");
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    mwb_launch_intersect(h->dev, env, x, z, radius, h->scratch_int_dev, 0);
+    if (ent < -1 || ent > h->dev.n_boxes) return set_err(MWB_EINVAL, "mwb_intersect: ent must be -1 .. number of boxes (= the agent)");
+    USE_DEVICE(h->cfg.device);
+    mwb_launch_intersect(h->dev, env, ent, x, z, radius, h->scratch_int_dev, 0);
     int rc = check_launch("intersect_kernel"); if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(result, h->scratch_int_dev, sizeof(int), hipMemcpyDeviceToHost));
@@ -702,7 +788,7 @@ extern "C" int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_ro
     if (!h || !n_rooms || !n_segs) return set_err(MWB_EINVAL, "mwb_get_geometry: null argument");
     const MwbDev &d = h->dev;
     if (env < 0 || env >= d.N) return set_err(MWB_EINVAL, "mwb_get_geometry: env out of range");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(n_rooms, d.n_rooms + env, sizeof(int), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(n_segs, d.n_segs + env, sizeof(int), hipMemcpyDeviceToHost));
@@ -722,7 +808,7 @@ extern "C" int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_ro
 // -------------------------------------------------------------------------------------- timing
 extern "C" int mwb_timing_enable(mwb_handle *h, int enable) {
     if (!h) return set_err(MWB_EINVAL, "mwb_timing_enable: null handle");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     h->timing = enable != 0;
     h->timing_period = enable > 1 ? enable : 1;
@@ -733,7 +819,7 @@ extern "C" int mwb_timing_enable(mwb_handle *h, int enable) {
 
 extern "C" int mwb_timing_read(mwb_handle *h, double *ms_step, double *ms_reset, double *ms_prep, double *ms_render, int *n) {
     if (!h) return set_err(MWB_EINVAL, "mwb_timing_read: null handle");
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    USE_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     double acc[4] = {0, 0, 0, 0};
     int passes = (int)(h->ev_used / EVN);

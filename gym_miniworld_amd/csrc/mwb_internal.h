@@ -135,7 +135,7 @@ void mwb_launch_reset(const MwbDev &d, int max_blocks, hipStream_t s);   // grid
 void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s);
 void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s);
 void mwb_launch_stack(const MwbDev &d, void *stack, int nstack, int dtype, int after_reset, hipStream_t s);
-void mwb_launch_intersect(const MwbDev &d, int env, double x, double z, double radius, int *result_dev, hipStream_t s);
-int mwb_prepare_kernels(const MwbDev &d);   // 0 ok, -1 world too large for LDS, -2 HIP error
+void mwb_launch_intersect(const MwbDev &d, int env, int ent, double x, double z, double radius, int *result_dev, hipStream_t s);
+int mwb_prepare_kernels(const MwbDev &d);   // 0 ok, -1 world too large for LDS, -2 HIP error, -3 frame too large for the pixel queue
 size_t mwb_reset_lds_bytes(const MwbDev &d);
 size_t mwb_render_lds_bytes(const MwbDev &d);

@@ -1706,8 +1706,9 @@ void mwb_launch_stack(const MwbDev &d, void *stack, int nstack, int dtype, int a
 }
 
 // ============================================================================== small utilities
-__global__ void intersect_kernel(MwbDev d, int e, double x, double z, double radius, int *result) {
-    // MiniWorldEnv.intersect(agent, pos, radius), miniworld.py:933-959
+__global__ void intersect_kernel(MwbDev d, int e, int ent, double x, double z, double radius, int *result) {
+    // MiniWorldEnv.intersect(ent, pos, radius), miniworld.py:933-959: walls, then the entities in list order
+    // (boxes, agent) except `ent` itself
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int ns = d.n_segs[e], res = 0;
     for (int i = 0; i < ns && !res; i++) {
@@ -1716,8 +1717,13 @@ __global__ void intersect_kernel(MwbDev d, int e, double x, double z, double rad
         if (seg_hit(q, x, z, radius)) res = 1;
     }
     for (int b = 0; b < d.n_boxes && !res; b++) {
+        if (b == ent) continue;
         double ddx = d.box_x[(size_t)b * d.N + e] - x, ddz = d.box_z[(size_t)b * d.N + e] - z;
         if (sqrt(ddx * ddx + 0.0 + ddz * ddz) < radius + box_radius(d.box_size[(size_t)b * d.N + e])) res = 2 + b;
+    }
+    if (!res && ent != d.n_boxes) {   // the agent is the last entity of the list
+        double ddx = d.agent_x[e] - x, ddz = d.agent_z[e] - z;
+        if (sqrt(ddx * ddx + 0.0 + ddz * ddz) < radius + d.agent_radius) res = 2 + d.n_boxes;
     }
     *result = res;
 }
@@ -1752,14 +1758,14 @@ int mwb_prepare_kernels(const MwbDev &d) {
     {   // the render kernel's pixel queues hold (py << ceil(log2 W)) | px in 16 bits
         int wshift = 0;
         while ((1 << wshift) < d.W) wshift++;
-        if (((size_t)d.H << wshift) > 65536) return -1;
+        if (((size_t)d.H << wshift) > 65536) return -3;
     }
     if (r > 64 * 1024 && hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r) != hipSuccess) return -2;
-    if (q > 64 * 1024) {   // only Maze worlds get this large, and they have one box
-        if (hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess ||
-            hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess ||
-            hipFuncSetAttribute((const void *)render_kernel<RENDER_THREADS, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess)
-            return -2;
+    if (q > 64 * 1024) {   // large mazes, or any task at a large observation size (the W*H*3 frame is in LDS too)
+        const void *fns[2][3] = {{(const void *)render_kernel<RENDER_THREADS, 0, 1>, (const void *)render_kernel<RENDER_THREADS, 1, 1>, (const void *)render_kernel<RENDER_THREADS, 2, 1>},
+                                 {(const void *)render_kernel<RENDER_THREADS, 0, 2>, (const void *)render_kernel<RENDER_THREADS, 1, 2>, (const void *)render_kernel<RENDER_THREADS, 2, 2>}};
+        for (int m = 0; m < 3; m++)
+            if (hipFuncSetAttribute(fns[d.n_boxes == 2 ? 1 : 0][m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess) return -2;
     }
     return 0;
 }
@@ -1786,6 +1792,6 @@ void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
     else if (mode == 2) render_kernel<RENDER_THREADS, 2, 1><<<g, b, lds, s>>>(d);
     else render_kernel<RENDER_THREADS, 0, 1><<<g, b, lds, s>>>(d);
 }
-void mwb_launch_intersect(const MwbDev &d, int env, double x, double z, double radius, int *result_dev, hipStream_t s) {
-    hipLaunchKernelGGL(intersect_kernel, dim3(1), dim3(64), 0, s, d, env, x, z, radius, result_dev);
+void mwb_launch_intersect(const MwbDev &d, int env, int ent, double x, double z, double radius, int *result_dev, hipStream_t s) {
+    hipLaunchKernelGGL(intersect_kernel, dim3(1), dim3(64), 0, s, d, env, ent, x, z, radius, result_dev);
 }

@@ -132,14 +132,11 @@ class MiniWorldEnv:
 
     def intersect(self, ent, pos, radius):
         """miniworld.py:933-959: True for a wall, the other entity for an entity hit, else None."""
-        r = self._b.intersect(0, pos[0], pos[2], radius)
+        idx = next((i for i, e2 in enumerate(self.entities) if e2 is ent), -1)
+        r = self._b.intersect(0, pos[0], pos[2], radius, ent=idx)
         if r == 1:
             return True
-        if r == 2 and ent is not self.box:
-            return self.box
-        if r == 3 and ent is not self.blue_box:
-            return self.blue_box
-        return None
+        return self.entities[r - 2] if r >= 2 else None
 
     def near(self, ent0, ent1=None):   # miniworld.py:961-971
         ent1 = ent1 or self.agent

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MWB_ABI_VERSION 3
+#define MWB_ABI_VERSION 4
 
 enum { MWB_OK = 0, MWB_EINVAL = -1, MWB_EHIP = -2, MWB_ENOMEM = -3, MWB_ESTATE = -4 };
 
@@ -98,32 +98,28 @@ typedef struct mwb_outputs {
     double *goal_pos;   /* f64 [N][3] info['goal_pos'] of the transition, T-maze family (tmaze.py:66,206); else zeros */
 } mwb_outputs;
 
-/* host-side snapshot of the simulator state of a contiguous env range, for tests / debugging;
- * every pointer may be NULL to skip that field. Arrays are [count] or [count][3]. */
+/* host-side snapshot of the simulator state of a contiguous env range, for tests / debugging / checkpoints;
+ * every pointer may be NULL to skip that field. B = mwb_num_boxes(h); boxes in the order of the reference's
+ * entity list (hallway.py:31 one red box; tmaze.py:166-169 red, blue; simtorealpush.py:88-99 red, yellow). */
 typedef struct mwb_state {
     double *agent_pos;  /* [count][3] Entity.pos (entity.py:22-24), y = 0 */
     double *agent_dir;  /* [count]    Entity.dir                          */
-    double *box_pos;    /* [count][3] */
-    double *box_dir;    /* [count]    */
-    double *box_color;  /* [count][3] Box.color_vec (entity.py:381-383)   */
+    double *box_pos;    /* [count][B][3] */
+    double *box_dir;    /* [count][B]    */
+    double *box_color;  /* [count][B][3] Box.color_vec (entity.py:381-383)   */
+    double *box_size;   /* [count][B] Box.size[0] (entity.py:366-378): 0.8 unless the task draws it per episode */
     double *cam;        /* [count][4] cam_height, cam_fwd_disp, cam_pitch, cam_fov_y (entity.py:486-492) */
     double *sky_color, *light_pos, *light_color, *light_ambient; /* [count][3] (miniworld.py:561-566) */
     int32_t *step_count;    /* [count] miniworld.py:539,663 */
-    int32_t *rng_pos;       /* [count] MT19937 position (RandomState.get_state()[2]) */
-    uint32_t *rng_keysum;   /* [count] sum of the 624 key words mod 2^32 */
-    int32_t *n_rooms;       /* [count] */
-    int32_t *n_segs;        /* [count] */
-    /* T-maze family (NULL-able like the rest; zeros for the other tasks) */
-    double *box2_pos;       /* [count][3] the blue box of the two-box tasks (tmaze.py:168) */
-    double *box2_dir;       /* [count]    */
-    double *box2_color;     /* [count][3] */
+    int32_t *rng_pos;       /* [count] MT19937 position (RandomState.get_state()[2]); read-only */
+    uint32_t *rng_keysum;   /* [count] sum of the 624 key words mod 2^32; read-only */
+    int32_t *n_rooms;       /* [count] read-only */
+    int32_t *n_segs;        /* [count] read-only */
     int32_t *goal_idx;      /* [count] current_goal (tmaze.py:91) / goal_box_idx (tmaze.py:135) */
     int64_t *episode_count; /* [count] tmaze.py:80,130 (1 after construction: MiniWorldEnv.__init__ resets once) */
     int64_t *task_step_count; /* [count] tmaze.py:240 */
-    /* sim-to-real rinks: per-episode sizes (the other tasks: 0.8, 0.8 or 0, 0) */
-    double *box_size;       /* [count] Box.size[0] of the first box (entity.py:366-378) */
-    double *box2_size;      /* [count] second box, 0 where there is none */
     double *goal_dist;      /* [count] simtorealpush.py:84 */
+    uint32_t *rng_state;    /* [count][625] RandomState.get_state(): the 624 key words, then the position */
 } mwb_state;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
@@ -184,7 +180,12 @@ int mwb_stack_update(mwb_handle *h, int after_reset, void *stream);
 int mwb_check(mwb_handle *h);
 
 /* ---- introspection (tests, Gym single-env view) ------------------------------------------- */
+int mwb_num_boxes(mwb_handle *h);   /* B: boxes per env of the handle's task */
 int mwb_get_state(mwb_handle *h, int first_env, int count, mwb_state *out);          /* synchronous */
+/* replaces: assigning env.agent.pos / env.box.pos / env.rand.np_random.set_state(...) etc. on the reference's
+ * Python objects - overwrite the state of an env range with every non-NULL, non-read-only field of `in`
+ * (test hook: inject oracle / reference states; also restores a snapshot taken with mwb_get_state). Synchronous. */
+int mwb_set_state(mwb_handle *h, int first_env, int count, const mwb_state *in);
 /* overwrite pose / step counter of env range (NULL = leave); used to inject oracle states */
 int mwb_set_agent(mwb_handle *h, int first_env, int count, const double *pos_xz, const double *dir,
                   const int32_t *step_count);
@@ -195,9 +196,11 @@ int mwb_set_domain_rand(mwb_handle *h, int domain_rand);
 /* overwrite the goal-alternation state of the T-maze family for an env range (NULL = leave); test hook */
 int mwb_set_task_state(mwb_handle *h, int first_env, int count, const int64_t *episode_count,
                        const int64_t *task_step_count, const int32_t *goal_idx);
-/* replaces: MiniWorldEnv.intersect(agent, pos, radius) (miniworld.py:933-959) for one env; result
- * 0 none, 1 wall, 2 box (the red one), 3 the blue box. Synchronous. */
-int mwb_intersect(mwb_handle *h, int env, double x, double z, double radius, int *result);
+/* replaces: MiniWorldEnv.intersect(ent, pos, radius) (miniworld.py:933-959) for one env. `ent` = position of the
+ * querying entity in the entity list (0 .. B-1 the boxes, B the agent) - it is skipped, as `ent2 is ent` is - or -1
+ * to skip nobody.  result: 0 none, 1 wall (walls are tested first), 2 + k = the first entity k in list order within
+ * radius + its radius. Synchronous. */
+int mwb_intersect(mwb_handle *h, int env, int ent, double x, double z, double radius, int *result);
 /* geometry of one env as the kernels see it: n_rooms x MWB_ROOM_WORDS f32 words and n_segs x 4 f64 */
 #define MWB_ROOM_WORDS 24
 int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_rooms, double *segs, int max_segs,

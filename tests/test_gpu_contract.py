@@ -97,3 +97,99 @@ def test_cost_ordered_dispatch_renders_every_env_exactly_once():
                 b.step(torch.randint(0, 3, (n,), generator=g, dtype=torch.int32))
                 assert int((b.obs.reshape(n, -1).max(dim=1).values == 0).sum()) == 0, (env_id, t, "an env was not rendered")
         b.close()
+
+
+def test_set_state_round_trips_and_the_rng_stream_can_be_injected(oracle_mod):
+    """mwb_get_state / mwb_set_state: a snapshot (incl. the full MT19937 state) restores the batch exactly; an RNG
+    state injected from another env makes the next episode of env 0 the episode that env would have had."""
+    import torch
+    from gym_miniworld_amd import _lib
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    n = 6
+    b = BatchedMiniWorld("MiniWorld-FourRooms-v0", num_envs=n, seed=50, domain_rand=True)
+    b.reset()
+    snap = b.get_state(rng_state=True)
+    assert snap["rng_state"].shape == (n, 625) and np.array_equal(snap["rng_state"][:, 624], snap["rng_pos"])
+    assert np.array_equal(snap["rng_state"][:, :624].astype(np.uint64).sum(axis=1).astype(np.uint32), snap["rng_keysum"])
+    g = torch.Generator().manual_seed(3)
+    acts = [torch.randint(0, 3, (n,), generator=g, dtype=torch.int32) for _ in range(30)]
+    for a in acts:
+        b.step(a)
+    after = b.get_state(rng_state=True)
+    obs_after = b.obs.clone()
+    keys = ("agent_pos", "agent_dir", "boxes_pos", "boxes_dir", "boxes_color", "boxes_size", "cam", "sky_color", "light_pos",
+            "light_color", "light_ambient", "step_count", "goal_idx", "episode_count", "task_step_count", "goal_dist", "rng_state")
+    b.set_state(0, **{k: snap[k] for k in keys})
+    again = b.get_state(rng_state=True)
+    for k in keys:
+        assert np.array_equal(again[k], snap[k]), k
+    for a in acts:   # same actions from the restored snapshot: same trajectory (nobody finished an episode in 30 steps,
+        b.step(a)    # or if somebody did, the restored RNG regenerates the same world)
+    redo = b.get_state(rng_state=True)
+    for k in keys:
+        assert np.array_equal(redo[k], after[k]), k
+    assert torch.equal(b.obs, obs_after)
+    # env 0 continues env 3's stream: its next reset builds env 3's next world
+    b.set_state(0, rng_state=redo["rng_state"][3:4])
+    b.reset()
+    st = b.get_state(rng_state=True)
+    assert np.array_equal(st["agent_pos"][0], st["agent_pos"][3]) and np.array_equal(st["boxes_pos"][0], st["boxes_pos"][3])
+    assert np.array_equal(st["rng_state"][0], st["rng_state"][3])
+    with pytest.raises(_lib.MwbError, match="position"):
+        bad = redo["rng_state"][:1].copy(); bad[0, 624] = 700
+        b.set_state(0, rng_state=bad)
+    with pytest.raises(KeyError):
+        b.set_state(0, n_rooms=[1])
+    b.close()
+
+
+def test_intersect_skips_the_querying_entity_and_sees_the_agent(oracle_mod):
+    """MiniWorldEnv.intersect(ent, pos, radius), miniworld.py:933-959: walls first, then every entity but `ent`
+    in list order - the agent is an obstacle for a box, a box is not an obstacle for itself."""
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    from gym_miniworld_amd.env import MiniWorldEnv
+    b = BatchedMiniWorld("MiniWorld-TMazeTwoBoxDynamic-v0", num_envs=2, seed=3)
+    b.reset()
+    st = b.get_state()
+    red, blue, ag = st["boxes_pos"][0, 0], st["boxes_pos"][0, 1], st["agent_pos"][0]
+    br = float(np.sqrt(2 * 0.8 * 0.8) / 2)
+    assert b.intersect(0, red[0], red[2], br, ent=0) == 0            # the red box at its own position: itself is skipped
+    assert b.intersect(0, red[0], red[2], br, ent=1) == 2            # ... the blue box asking about the same spot hits red
+    assert b.intersect(0, red[0], red[2], br, ent=-1) == 2
+    assert b.intersect(0, ag[0] + 0.1, ag[2], br, ent=0) == 4        # a box near the agent: the agent (entity 2) blocks
+    assert b.intersect(0, ag[0] + 0.1, ag[2], 0.4) == 0              # the agent asking: itself is skipped (default ent)
+    assert b.intersect(0, blue[0], blue[2] - 0.3, 0.4) == 3
+    b.close()
+    env = MiniWorldEnv("MiniWorld-TMazeTwoBoxDynamic-v0", seed=3)
+    env.reset()
+    assert env.intersect(env.red_box, env.red_box.pos, env.red_box.radius) is None
+    assert env.intersect(env.blue_box, env.red_box.pos, env.red_box.radius) is env.red_box
+    assert env.intersect(env.red_box, env.agent.pos, env.red_box.radius) is env.agent
+    assert env.intersect(env.agent, env.agent.pos, env.agent.radius) is None
+    assert env.intersect(env.agent, np.array([7.9, 0, 3.0]), 0.4) is True
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,task,targs", [("MiniWorld-TMazeTwoBoxDynamic-v0", "TMazeTwoBox", [0, 0, 0, 100]),
+                                               ("MiniWorld-SimToRealPush-v0", "SimToRealPush", None)])
+def test_two_box_tasks_render_large_observations(oracle_mod, env_id, task, targs):
+    """200x150 needs more than the default 64 KB of dynamic LDS (the frame is assembled in LDS): the two-box render
+    kernels must opt in like the one-box ones (round-1 advisor finding)."""
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    from gym_miniworld_amd.params import sim_to_real_params
+    O = oracle_mod
+    prm = sim_to_real_params(push=True).to_table() if task == "SimToRealPush" else None
+    n = 3
+    b = BatchedMiniWorld(env_id, num_envs=n, seed=9, obs_width=200, obs_height=150, want_depth=True, domain_rand=True)
+    obs = b.reset().cpu().numpy()
+    dep = b.depth.cpu().numpy()[..., 0]
+    for i in range(n):
+        e = O.OracleEnv(task, seed=9 + i, domain_rand=True, task_args=targs, params=prm, obs_width=200, obs_height=150)
+        e.reset(render=False)
+        ref, refd = e.render_obs(depth=True)
+        d = np.abs(obs[i].astype(np.int16) - ref.astype(np.int16))
+        assert d.max() <= 1, (env_id, i, int(d.max()))
+        assert np.abs(dep[i] - refd).max() <= 1e-4
+    b.close()
+    with pytest.raises(Exception, match="pixel queue|LDS"):
+        BatchedMiniWorld(env_id, num_envs=1, seed=9, obs_width=640, obs_height=480)
