@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["mwb_api.hip", "mwb_kernels.hip"]
-HEADERS = ["mwb_internal.h", os.path.join("..", "..", "include", "miniworld_batch.h")]
+HEADERS = ["mwb_internal.h", "mwb_glibc_trig.h", "mwb_sincos_table.inc", os.path.join("..", "..", "include", "miniworld_batch.h")]
 OUT = os.path.join(HERE, "libmwbatch.so")
 # -ffp-contract=off: world generation / step must reproduce the reference's float64 arithmetic bit
 # for bit, and the render spec states every fused multiply-add explicitly

@@ -14,8 +14,15 @@
 // float64 results bit for bit, and the visibility arithmetic of the renderer is specified with
 // explicit fmaf() ("render spec").
 #include "mwb_internal.h"
+#include "mwb_glibc_trig.h"
 
 #define WAVE 64
+
+// float64 sin / cos as the reference's process computes them (math.sin / math.cos -> glibc 2.35 __sin_fma / __cos_fma,
+// restated bit for bit in mwb_glibc_trig.h); OCML's differ in the last bit for a few arguments in a thousand, which an
+// accumulating pose would carry along.  Beyond |x| = 105414350 (unreachable for a heading) the platform's functions.
+__device__ __forceinline__ double ref_sin(double x) { return mwb_trig::in_range(x) ? mwb_trig::sin_glibc(x) : sin(x); }
+__device__ __forceinline__ double ref_cos(double x) { return mwb_trig::in_range(x) ? mwb_trig::cos_glibc(x) : cos(x); }
 
 // =========================================================================== MT19937 (numpy legacy)
 // numpy.random.RandomState draw recipes used through reference random.py:4-65.
@@ -151,7 +158,7 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
                 // from that position to the box, unless it would then hit a wall, the other box or the agent,
                 // and turns by a random angle.  The rink has four wall segments: tested here, in wave 0.
                 const double fwd_dist = d.params[MWB_P_FORWARD_STEP].hi[0];
-                const double c = cos(adir), s = sin(adir);
+                const double c = ref_cos(adir), s = ref_sin(adir);
                 const double npx = ax + c * fwd_dist, npz = az + (-s) * fwd_dist;
                 const int ns = d.n_segs[e];
                 double wq[4][4];   // the rink's four wall segments, loaded together (16 coalesced loads in flight)
@@ -195,7 +202,7 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
             if (use_rng) g.store();
             if (a == 2 || a == 3) {   // move_agent, miniworld.py:608-633
                 double fd = (a == 2) ? fwd_step : -fwd_step;
-                double c = cos(adir), s = sin(adir);
+                double c = ref_cos(adir), s = ref_sin(adir);
                 // pos + dir_vec*fwd + right_vec*drift with dir_vec=(cos,0,-sin), right_vec=(sin,0,cos)
                 nx = (ax + c * fd) + s * fwd_drift;
                 nz = (az + (-s) * fd) + c * fwd_drift;
@@ -879,7 +886,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
 __device__ __forceinline__ void rot_matrix(double axx, double axy, double axz, double angle, double *m) {
     double n = sqrt(axx * axx + axy * axy + axz * axz);
     axx /= n; axy /= n; axz /= n;
-    double a = cos(angle / 2.0), s = sin(angle / 2.0);
+    double a = ref_cos(angle / 2.0), s = ref_sin(angle / 2.0);
     double b = -axx * s, c = -axy * s, dd = -axz * s;
     m[0] = a * a + b * b - c * c - dd * dd; m[1] = 2 * (b * c - a * dd); m[2] = 2 * (b * dd + a * c);
     m[3] = 2 * (b * c + a * dd); m[4] = a * a + c * c - b * b - dd * dd; m[5] = 2 * (c * dd - a * b);
@@ -945,7 +952,7 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     float bcol[3];
     for (int k = 0; k < 3; k++) bcol[k] = (float)d.box_color[be * 3 + k];
     double bdir = d.box_dir[be];
-    float bc = (float)cos(bdir), bs = (float)sin(bdir);
+    float bc = (float)ref_cos(bdir), bs = (float)ref_sin(bdir);
     const float ln[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
     for (int k = 0; k < 6; k++)   // world normal = R_y(dir) n_local (glRotatef about +Y)
         lit_color(L, amb, dif, ln[k][0] * bc + ln[k][2] * bs, ln[k][1], -ln[k][0] * bs + ln[k][2] * bc, bcol, fc + FC_LIT_BOX + 3 * k);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised state-parity soak (not part of the test suite): long random rollouts with auto-reset, many envs
-per task; reward (f64), done and step count compared with the CPU oracle at EVERY step, the RNG position / key
-checksum, box poses and counters every 100 steps.  usage: state_soak.py [envs] [steps]"""
+per task; reward (f64), done, step count AND THE AGENT POSE (position and heading, bit for bit) compared with the
+CPU oracle at EVERY step, the RNG position / key checksum, box poses and counters every 100 steps.
+usage: state_soak.py [envs] [steps]"""
 import os
 import sys
 import time
@@ -34,7 +35,8 @@ for env_id, task in TASKS:
             e.reset(render=False)
         rng = np.random.default_rng(1)
         na = b.n_actions
-        episodes = rewards = mism = 0
+        episodes = rewards = mism = pose_mism = 0
+        pose_ulp = 0.0
         for t in range(steps):
             a = rng.choice(na, size=n, p=[0.2, 0.2, 0.6] if na == 3 else [0.2, 0.2, 0.5, 0.1]).astype(np.int32)
             b.step(torch.from_numpy(a))
@@ -47,6 +49,13 @@ for env_id, task in TASKS:
                 if d:
                     episodes += 1
                     e.reset(render=False)
+            st = b.get_state()
+            os_ = [e.state() for e in envs]
+            op = np.array([list(s.agent_pos) for s in os_]); od = np.array([s.agent_dir for s in os_])
+            bad = (st["agent_pos"] != op).any(axis=1) | (st["agent_dir"] != od)
+            if bad.any():
+                pose_mism += int(bad.sum())
+                pose_ulp = max(pose_ulp, float(np.abs(st["agent_pos"] - op).max() / np.spacing(np.abs(op).max())))
             if t % 100 == 99:
                 st = b.get_state()
                 os_ = [e.state() for e in envs]
@@ -54,8 +63,8 @@ for env_id, task in TASKS:
                              ("goal_idx", lambda s: s.goal_idx), ("task_step_count", lambda s: s.task_step_count)):
                     if not np.array_equal(st[k].astype(np.int64) if st[k].dtype.kind in "iu" else st[k], np.array([f(s) for s in os_])):
                         mism += 1
-                if not np.allclose(st["box_pos"], np.array([list(s.box_pos) for s in os_]), rtol=0, atol=1e-11):
+                if not np.array_equal(st["box_pos"], np.array([list(s.box_pos) for s in os_])):
                     mism += 1
         b.close()
-        print("%-46s dr%d  %d envs x %d steps  episodes %6d  nonzero rewards %6d  MISMATCHES %d  (%.0f s)"
-              % (env_id, dr, n, steps, episodes, rewards, mism, time.time() - t0), flush=True)
+        print("%-46s dr%d  %d envs x %d steps  episodes %6d  nonzero rewards %6d  MISMATCHES %d  POSE MISMATCHES %d (max %.1f ulp)  (%.0f s)"
+              % (env_id, dr, n, steps, episodes, rewards, mism, pose_mism, pose_ulp, time.time() - t0), flush=True)

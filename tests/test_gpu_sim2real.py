@@ -136,10 +136,8 @@ def test_rink_rollout_exact_with_pushes_and_rewards(oracle_mod, env_id, task):
                 e.reset(render=False)
         if t % 20 == 19 or t == steps - 1:
             os_ = oracle_states(envs)
-            assert_rink_state_equal(b.get_state(), os_, exact_pose=False, tag="%s t=%d" % (task, t))
-            b.set_agent(0, pos_xz=np.array([[s.agent_pos[0], s.agent_pos[2]] for s in os_]),
-                        dir=np.array([s.agent_dir for s in os_]))
-            obs = b.render().cpu().numpy()
+            assert_rink_state_equal(b.get_state(), os_, tag="%s t=%d" % (task, t))
+            obs = b.obs.cpu().numpy()   # the step's own frame, from the device's own (bit-equal) pose
             for i, e in enumerate(envs):
                 d = obs_diff(obs[i], e.render_obs())
                 assert d.max() <= 1, (task, t, i, int(d.max()), int((d > 1).sum()))
