@@ -7,9 +7,10 @@
 
 One "step" = one pass of the hot path (MiniWorldEnv.step + auto-reset + render_obs for every env of
 the rank's shard) on synthetic uniformly random actions that are resident in HBM before the timed
-region.  For N > 1 every rank owns a contiguous env range (weak scaling: envs per GPU fixed) and
-each step's observation shard is all-gathered (RCCL, uint8) for the learner, overlapped with the
-next step.  Rank 0 prints ONE JSON line.
+region.  For N > 1 every rank owns a contiguous env range (weak scaling: envs per GPU fixed); per step
+rank 0 (the "learner") scatters the actions, and every rank's observation shard + reward / done / info
+pack is exchanged in one round (RCCL), overlapped with the next step and consumed one round behind
+inside the timed loop.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -126,6 +127,38 @@ def cpu_baseline(env_id, depth, dr, budget_s=10.0):
                       "step+auto-reset+render, one env per thread on %d host cores" % (cores, n, env_id, cores)}
 
 
+def vecenv_rates(env_id, per_gpu, dr, device, K, Wm):
+    """The same workload through the boundary the reference's trainer calls (pytorch-a2c-ppo-acktr/main.py:610:
+    `obs, reward, done, infos = envs.step(action, env_mask)`): actions as LongTensor [N,1] on the device, numpy dones,
+    CPU float rewards, info dicts.  Two views: the bare VecEnv (uint8 [N,3,80,60] observations: what the Python layer
+    itself costs on top of the C ABI) and make_vec_envs' view (float32 4-frame stack [N,12,80,60], envs.py:57-165,
+    whose fused stack pass moves 3.4 GB per step at 8192 envs and is HBM-bound)."""
+    import torch
+    from gym_miniworld_amd.vec_env import MiniWorldVecEnv, make_vec_envs
+    out = {}
+    for name in ("vecenv_u8", "make_vec_envs_f32_stack4"):
+        if name == "vecenv_u8":
+            v = MiniWorldVecEnv(env_id, per_gpu, seed=1, device=device.index, domain_rand=dr, to_float=False, feature_info=True)
+        else:
+            v = make_vec_envs(env_id, 1, per_gpu, device=str(device), domain_rand=dr)
+        acts = make_actions(K + Wm, 0, per_gpu, device).to(torch.int64).unsqueeze(2)   # [T, N, 1] LongTensor
+        v.reset()
+        n_done = 0
+        for t in range(Wm):
+            v.step(acts[t])
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for t in range(Wm, Wm + K):
+            _, _, done, infos = v.step(acts[t])
+            n_done += int(done.sum())
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        out[name] = {"value": per_gpu * K / dt, "unit": "env-steps/s", "ms_per_step": dt / K * 1e3, "episodes_ended": n_done,
+                     "infos": type(infos).__name__}
+        v.close()
+    return out
+
+
 def load_traffic(workload):
     """HBM bytes per render launch from the newest committed rocprofv3 --pmc summary that has this
     workload (profiles/r*_pmc_traffic.json, written by scripts/summarize_prof.py), else None."""
@@ -149,18 +182,19 @@ def main():
     ap.add_argument("--workload", default="maze8192", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vecenv", action="store_true", help="skip the (untimed-for-`value`) leg through the VecEnv boundary")
     ap.add_argument("--no-gather", action="store_true", help="skip the obs all-gather for N > 1")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo (+ --no-gather) only to rehearse the multi-rank flow on one GPU")
     ap.add_argument("--force-gather", action="store_true", help="run the staging + exchange path even at N = 1 (self-test)")
     ap.add_argument("--gather", default="auto", choices=["auto", "ring", "direct"],
-                    help="exchange method of the obs all-gather (auto: time both in the warm-up, keep the faster)")
+                    help="exchange method of the per-step shard exchange (auto: time both in the warm-up, keep the faster)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from gym_miniworld_amd.batch import BatchedMiniWorld
-    from gym_miniworld_amd.distributed import ObsGatherer, dist_env, shard_range
+    from gym_miniworld_amd.distributed import ShardExchange, dist_env, shard_range
 
     rank, local_rank, world = dist_env()
     if world != args.gpus:
@@ -188,15 +222,25 @@ def main():
     K, Wm = args.steps, args.warmup
     actions = make_actions(K + Wm, first, count, device)
     gather = None
+    actions_all = None
     if (world > 1 and not args.no_gather) or args.force_gather:
-        gather = ObsGatherer(tuple(env.obs.shape), env.obs.dtype, device, world, rank=rank, method=args.gather)
+        gather = ShardExchange(tuple(env.obs.shape), env.obs.dtype, device, world, rank=rank, method=args.gather)
+        if rank == 0:   # the learner's action table for ALL envs (identical values to every rank's own `actions`)
+            actions_all = make_actions(K + Wm, 0, total, device)
     env.reset()
+    consumed = torch.zeros((), dtype=torch.float64, device=device)
 
     def run(t0, t1):
         for t in range(t0, t1):
-            env.step(actions[t])
             if gather is not None:
-                gather.push(env.obs)
+                a = gather.scatter_actions(actions_all[t] if rank == 0 else None, src=0)   # 4 B/env back to the shards
+            else:
+                a = actions[t]
+            env.step(a)
+            if gather is not None:
+                gather.push(env.obs, env=env)            # obs + reward / done / ep_steps / feature / goal_pos, one round
+                g_obs, g_aux = gather.previous()         # the learner consumes one round behind (overlap with this step)
+                consumed.add_(g_obs.view(-1)[::8191].sum(dtype=torch.float64) + g_aux[:, 0].sum())   # device-side read, no host sync
 
     def fence():
         torch.cuda.synchronize(device)
@@ -208,9 +252,9 @@ def main():
     if gather is not None:
         gather.drain()
     fence()
-    # HIP events on the launch stream, every 4th step of the timed region (seven events per step cost ~2-5 % of a
-    # step's time); read back only after the timed region
-    env.timing_enable(4 if K >= 40 else True)
+    # HIP events on the launch stream, every 4th step of the timed region whatever its length (seven events per step
+    # cost ~2-5 % of a step's time); read back only after the timed region
+    env.timing_enable(4 if K >= 4 else True)
     t_start = time.perf_counter()
     run(Wm, Wm + K)
     if gather is not None:
@@ -235,7 +279,7 @@ def main():
             "config": {"workload": args.workload, "env_id": env_id, "envs_per_gpu": per_gpu, "global_envs": total,
                        "obs": "80x60 RGB" + (" + f32 depth" if depth else ""), "domain_rand": bool(dr),
                        "actions": "uniform random over {turn_left, turn_right, move_forward}, counter-based",
-                       "auto_reset": True, "parallelism": "env-sharded x%d%s" % (world, "" if gather is None else " + RCCL all-gather(obs u8, %s)" % gather.method),
+                       "auto_reset": True, "parallelism": "env-sharded x%d%s" % (world, "" if gather is None else " + per-step exchange(obs u8 + aux f64[8], %s) + action scatter" % gather.method),
                        "gather_tuning_s": None if gather is None else gather.tuned},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
@@ -244,6 +288,13 @@ def main():
                          "note": "nominally HBM-bound path; the practical limiter is VALU issue plus LDS / texel latency (VALU pipes ~54 % busy at 5 waves/SIMD, DESIGN.md 4)"},
             "kernel_ms": {k: kt[k] for k in ("step", "reset", "prep", "render")},
         }
+        if world == 1 and not args.no_vecenv:
+            env.close()
+            try:
+                out["vecenv"] = vecenv_rates(env_id, per_gpu, dr, device, K, Wm)
+                out["vecenv"]["vs_c_abi"] = out["vecenv"]["vecenv_u8"]["value"] / value
+            except Exception as ex:
+                out["vecenv"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(env_id, depth, dr)

@@ -64,8 +64,6 @@ struct mwb_handle {
     size_t stack_bytes;
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
-    int32_t *order_buf[2];   // blockIdx -> env maps: the bulk render reads [order_cur], the side stream fills the other one
-    int order_cur;
 };
 
 extern "C" const char *mwb_last_error(void) { return g_err.c_str(); }
@@ -269,15 +267,14 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     if (rc == MWB_OK && (d.debug_flags & 16)) rc = dev_alloc(h, &d.wg_ts, 2 * (N + (size_t)d.split_envs));
     if (rc == MWB_OK) rc = dev_alloc(h, &d.cost, 2 * N);
     if (rc == MWB_OK) rc = dev_alloc(h, &d.bucket, N);
-    h->order_buf[0] = h->order_buf[1] = nullptr; h->order_cur = 0;
-    if (rc == MWB_OK) rc = dev_alloc(h, &h->order_buf[0], N);
-    if (rc == MWB_OK) rc = dev_alloc(h, &h->order_buf[1], N);
+    if (rc == MWB_OK) rc = dev_alloc(h, &d.order_bufs[0], N);
+    if (rc == MWB_OK) rc = dev_alloc(h, &d.order_bufs[1], N);
+    if (rc == MWB_OK) rc = dev_alloc(h, &d.order_state, (size_t)2);
     if (rc == MWB_OK) {   // no cost known yet: identity order
         std::vector<int32_t> ident(N);
         for (size_t i = 0; i < N; i++) ident[i] = (int32_t)i;
         for (int k = 0; k < 2 && rc == MWB_OK; k++)
-            if (hipMemcpy(h->order_buf[k], ident.data(), N * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = set_err(MWB_EHIP, "mwb_create: hipMemcpy failed");
-        d.order = h->order_buf[0];
+            if (hipMemcpy(d.order_bufs[k], ident.data(), N * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = set_err(MWB_EHIP, "mwb_create: hipMemcpy failed");
     }
     if (rc != MWB_OK) { mwb_destroy(h); return rc; }
     // MiniWorldEnv.__init__ ends with self.reset() (miniworld.py:523): the episode counters of TMazeDynamic /
@@ -477,7 +474,10 @@ extern "C" int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream) {
     TMARK(6); TMARK(2);
     rc = render_tail(h, 0, s); if (rc) return rc;
     mwb_launch_clear_list(h->dev, s);
-    return check_launch("clear_list_kernel");
+    rc = check_launch("clear_list_kernel"); if (rc) return rc;
+    // the first step's bulk render is dispatched by the frame costs this render just measured (not in env order)
+    mwb_launch_order(h->dev, s);
+    return check_launch("order_kernel");
 }
 
 extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask_dev, void *stream) {
@@ -513,15 +513,13 @@ extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t
     rc = check_launch("render_kernel"); if (rc) return rc;
     mwb_launch_clear_list(h->dev, h->side);   // the list is consumed; off the critical path
     // also off the critical path: the next step's dispatch order, from the frame costs measured so far
-    mwb_launch_order(h->dev, h->order_buf[h->order_cur ^ 1], h->side);
+    mwb_launch_order(h->dev, h->side);
     rc = check_launch("order_kernel"); if (rc) return rc;
     HIP_TRY(hipEventRecord(h->ev_join, h->side));
     TMARK(2);
     rc = render_tail(h, 2, s); if (rc) return rc;
     HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
-    h->order_cur ^= 1;   // the map filled beside this step is complete once the join has passed
-    h->dev.order = h->order_buf[h->order_cur];
-    return MWB_OK;
+    return MWB_OK;   // the map filled beside this step is adopted by the next step_kernel (device-side flip: graph-capturable)
 }
 
 extern "C" int mwb_render(mwb_handle *h, void *stream) {

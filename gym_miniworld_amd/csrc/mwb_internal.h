@@ -119,7 +119,11 @@ struct MwbDev {
     int32_t *ep_steps;
     uint32_t *cost;         // [2N] s_memrealtime ticks (10 ns) the last bulk render spent on env e: whole frame at [2e], or the halves
     uint8_t *bucket;        // [N] scratch of order_kernel
-    int32_t *order;         // [N] envs by decreasing cost (order_kernel, double-buffered by the host): the bulk render's blockIdx -> env map, slow frames first
+    // blockIdx -> env maps of the bulk render, envs by decreasing measured frame cost (slow frames first), double-buffered
+    // ON THE DEVICE so that a captured hipGraph keeps the whole mechanism: order_state[0] selects the map in use,
+    // order_kernel fills the other one and raises order_state[1]; the next step_kernel flips the selection.
+    int32_t *order_bufs[2]; // [N] each
+    int32_t *order_state;   // [2] {map in use, the other map is complete}
     unsigned long long *wg_ts;   // [2 * (N + split_envs)] start / end s_memrealtime of every bulk render workgroup, or null (MWB_DEBUG bit 4)
     float *feature;         // [N][2]
     double *goal_pos;       // [N][3]
@@ -128,7 +132,7 @@ struct MwbDev {
 // launch wrappers implemented in mwb_kernels.hip
 void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *skip_mask, hipStream_t s);
 void mwb_launch_clear_list(const MwbDev &d, hipStream_t s);
-void mwb_launch_order(const MwbDev &d, int32_t *order_out, hipStream_t s);   // envs by decreasing measured frame cost
+void mwb_launch_order(const MwbDev &d, hipStream_t s);   // envs by decreasing measured frame cost -> the map not in use
 void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s);
 void mwb_launch_reset(const MwbDev &d, int max_blocks, hipStream_t s);   // grid-strides over reset_list
 // mode 0: every env; 1: only envs with reset_set; 2: only envs without (lets reset overlap the bulk render)

@@ -137,6 +137,9 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
     const int NB = d.n_boxes;   // 1, or 2 in the two-box T-maze (entity order: red box, blue box, agent)
     double bx[MWB_MAX_BOXES] = {0, 0}, bz[MWB_MAX_BOXES] = {0, 0}, brad[MWB_MAX_BOXES] = {0, 0};
     const double arad = d.agent_radius;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && d.order_state[1]) {   // adopt the dispatch order completed beside the last pass
+        d.order_state[0] ^= 1; d.order_state[1] = 0;                  // (nothing reads the maps while step_kernel runs)
+    }
     if (part == 0) {
         s_move[lane] = 0; s_hit[lane] = 0;
         if (dummy) {
@@ -983,7 +986,8 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
 // it may read costs the current bulk render is just rewriting - either value will do, but each env's bucket is
 // decided once (kept in d.bucket) so that the result is a permutation whatever changes underneath.  The order
 // inside a bucket is whatever the atomics give - results do not depend on it.
-__global__ void __launch_bounds__(1024) order_kernel(MwbDev d, int32_t *__restrict__ order_out) {
+__global__ void __launch_bounds__(1024) order_kernel(MwbDev d) {
+    int32_t *__restrict__ order_out = d.order_bufs[d.order_state[0] ^ 1];
     __shared__ int hist[256], scan[256];
     const int tid = threadIdx.x;
     if (tid < 256) hist[tid] = 0;
@@ -1007,9 +1011,11 @@ __global__ void __launch_bounds__(1024) order_kernel(MwbDev d, int32_t *__restri
     if (tid < 256) hist[tid] = scan[tid] - own;
     __syncthreads();
     for (int i = tid; i < d.N; i += 1024) order_out[atomicAdd(&hist[d.bucket[i]], 1)] = i;   // own writes of pass 1
+    __syncthreads();
+    if (tid == 0) { __threadfence(); d.order_state[1] = 1; }
 }
-void mwb_launch_order(const MwbDev &d, int32_t *order_out, hipStream_t s) {
-    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, s, d, order_out);
+void mwb_launch_order(const MwbDev &d, hipStream_t s) {
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, s, d);
 }
 
 __global__ void __launch_bounds__(256) prep_kernel(MwbDev d, int mode) {
@@ -1658,7 +1664,7 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
         const int b = blockIdx.x;
         const int slot = b < whole ? b : whole + ((b - whole) >> 1);
         const int part = b < whole ? -1 : ((b - whole) & 1);
-        const int e = __builtin_amdgcn_readfirstlane(d.order[slot]);
+        const int e = __builtin_amdgcn_readfirstlane(d.order_bufs[d.order_state[0] & 1][slot]);
         if (MODE == 2 && d.reset_set[e]) return;   // block-uniform
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // read by every wave: stays in scalar registers
         render_env<THREADS, NBOX, false>(d, e, part, smem);

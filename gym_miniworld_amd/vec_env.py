@@ -68,6 +68,44 @@ _EMPTY_INFO = {}
 _DUMMY_INFO = {"feature": np.array([0, 0])}   # subproc_vec_env.py:30
 
 
+class LazyInfos:
+    """The `infos` of one step: behaves like the tuple of N dicts SubprocVecEnv returns (len, indexing, iteration,
+    each item a dict), but a dict is only built when it is asked for - at thousands of envs per GPU building them
+    all costs milliseconds per step, several times the device step.  The batched arrays behind the dicts are
+    exposed too, so that a trainer can replace its per-env loop
+        for info in infos: _feature.append(info["feature"])          (pytorch-a2c-ppo-acktr/main.py:612-617)
+    by `infos.feature`:  goal_pos [N,3] float64 or None, feature [N,2] float64 or None, skipped bool [N] or None."""
+
+    def __init__(self, n, goal_pos=None, feature=None, skipped=None, default_feature=False):
+        self.n, self.goal_pos, self.skipped = n, goal_pos, skipped
+        self._task_feature = feature is not None
+        self.feature = feature if feature is not None else (np.zeros((n, 2)) if default_feature else None)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return tuple(self[j] for j in range(*i.indices(self.n)))
+        if i < 0:
+            i += self.n
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        if self.skipped is not None and self.skipped[i]:
+            return _DUMMY_INFO
+        info = {}
+        if self.goal_pos is not None:
+            info["goal_pos"] = self.goal_pos[i].copy()
+        if self._task_feature:
+            info["feature"] = self.feature[i].copy()
+        elif self.feature is not None:
+            info["feature"] = _DUMMY_INFO["feature"]
+        return info
+
+    def __iter__(self):
+        return (self[i] for i in range(self.n))
+
+
 class MiniWorldVecEnv(VecEnv):
     """N MiniWorld envs on one GPU behind the VecEnv protocol.
 
@@ -101,6 +139,15 @@ class MiniWorldVecEnv(VecEnv):
         self.feature_info = feature_info
         self._infos_plain = tuple((_DUMMY_INFO if feature_info else _EMPTY_INFO) for _ in range(num_envs))
         self._pending = False
+        # host mirrors of the small per-step outputs: pinned, filled by asynchronous copies, ONE wait per step
+        pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)   # noqa: E731
+        self._h_done = pin((num_envs,), torch.uint8)
+        self._h_rew = pin((num_envs,), torch.float32 if torch_api else torch.float64)
+        self._h_goal = pin((num_envs, 3), torch.float64) if b.has_goal_pos else None
+        self._h_feat = pin((num_envs, 2), torch.float32) if b.has_features else None
+        self._h_skip = pin((num_envs,), torch.uint8)
+        self._ev = torch.cuda.Event()
+        self._skip_host = None
 
     # ---------------------------------------------------------------------------------- helpers
     def _obs_out(self, done=None):
@@ -121,9 +168,11 @@ class MiniWorldVecEnv(VecEnv):
         else:
             a = torch.as_tensor(np.asarray(actions).reshape(-1))
         skip = None
+        self._skip_host = None
         if isinstance(mask, np.ndarray):   # subproc_vec_env.py:59: only ndarray masks are honoured
-            skip = torch.as_tensor(mask != 0)
-        self._skip = skip
+            self._skip_host = mask.reshape(-1) != 0
+            self._h_skip.copy_(torch.from_numpy(self._skip_host.astype(np.uint8)))
+            skip = self._h_skip.to(self.device, non_blocking=True)
         self.batch.step(a, skip_mask=skip)
         self._pending = True
 
@@ -132,29 +181,28 @@ class MiniWorldVecEnv(VecEnv):
         self._pending = False
         b = self.batch
         obs = self._obs_out(done=b.done)
-        dones = b.done.cpu().numpy().astype(bool)   # host sync: the VecEnv contract returns numpy dones
+        # the VecEnv contract returns numpy dones / CPU rewards / info dicts: asynchronous copies into pinned host
+        # mirrors, then one wait on the stream (the reference pays a pipe round trip per env here)
+        self._h_done.copy_(b.done, non_blocking=True)
+        self._h_rew.copy_(b.reward if self.torch_api else b.reward64, non_blocking=True)
+        if self._h_goal is not None:
+            self._h_goal.copy_(b.goal_pos, non_blocking=True)
+        if self._h_feat is not None:
+            self._h_feat.copy_(b.feature, non_blocking=True)
+        self._ev.record(self.torch.cuda.current_stream(self.device))
+        self._ev.synchronize()
+        dones = self._h_done.numpy().astype(bool)
         if self.torch_api:
-            rews = b.reward.cpu().unsqueeze(1)       # CPU FloatTensor [N,1], envs.py:129
+            rews = self._h_rew.clone().unsqueeze(1)       # CPU FloatTensor [N,1], envs.py:129
         else:
-            rews = b.reward64.cpu().numpy()
-        sk = self._skip.cpu().numpy() if self._skip is not None else None
+            rews = self._h_rew.numpy().copy()
+        sk = self._skip_host
         if b.has_goal_pos:   # the T-maze family: info['goal_pos'] (tmaze.py:66,206) and, where produced, info['feature']
-            gp = b.goal_pos.cpu().numpy()
-            ft = b.feature.cpu().numpy().astype(np.float64) if b.has_features else None
-            infos = []
-            for i in range(self.num_envs):
-                if sk is not None and sk[i]:
-                    infos.append(_DUMMY_INFO)
-                    continue
-                info = {"goal_pos": gp[i].copy()}
-                if ft is not None:
-                    info["feature"] = ft[i].copy()
-                elif self.feature_info:
-                    info["feature"] = _DUMMY_INFO["feature"]
-                infos.append(info)
-            infos = tuple(infos)
-        elif sk is not None:
-            infos = tuple(_DUMMY_INFO if sk[i] else self._infos_plain[i] for i in range(self.num_envs))
+            infos = LazyInfos(self.num_envs, goal_pos=self._h_goal.numpy().copy(),
+                              feature=self._h_feat.numpy().astype(np.float64) if self._h_feat is not None else None,
+                              skipped=sk, default_feature=self.feature_info)
+        elif sk is not None and sk.any():
+            infos = LazyInfos(self.num_envs, skipped=sk, default_feature=self.feature_info)
         else:
             infos = self._infos_plain
         return obs, rews, dones, infos

@@ -193,3 +193,49 @@ def test_two_box_tasks_render_large_observations(oracle_mod, env_id, task, targs
     b.close()
     with pytest.raises(Exception, match="pixel queue|LDS"):
         BatchedMiniWorld(env_id, num_envs=1, seed=9, obs_width=640, obs_height=480)
+
+
+def test_shard_exchange_single_gpu_self_test():
+    """world 1 on the GPU: the staging path of the per-step exchange (obs + aux pack from a BatchedMiniWorld, consumed
+    one round behind) and the action scatter reproduce the env's own outputs; bench.py --force-gather drives the same path."""
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    from gym_miniworld_amd.distributed import ShardExchange, unpack_aux
+    n = 64
+    b = BatchedMiniWorld("MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0", num_envs=n, seed=5, layout="CWH")
+    b.reset()
+    g = ShardExchange(tuple(b.obs.shape), b.obs.dtype, b.device, 1, rank=0)
+    gen = torch.Generator().manual_seed(0)
+    prev = None
+    for t in range(40):
+        a_all = torch.randint(0, 3, (n, 1), generator=gen)
+        a = g.scatter_actions(a_all)
+        assert a.dtype == torch.int32 and a.device.type == "cuda" and a.cpu().tolist() == a_all.reshape(-1).tolist()
+        b.step(a)
+        snap = (b.obs.clone(), b.reward64.clone(), b.done.clone(), b.ep_steps.clone(), b.feature.clone(), b.goal_pos.clone())
+        g.push(b.obs, env=b)
+        if prev is not None:
+            po, pa = g.previous()
+            u = unpack_aux(pa)
+            assert torch.equal(po, prev[0]) and torch.equal(u["reward"], prev[1]) and torch.equal(u["done"], prev[2] != 0)
+            assert torch.equal(u["ep_steps"], prev[3]) and torch.equal(u["feature"].float(), prev[4]) and torch.equal(u["goal_pos"], prev[5])
+        lo, la = g.latest()
+        assert torch.equal(lo, snap[0]) and torch.equal(la[:, 0], snap[1])
+        prev = snap
+    g.drain()
+    b.close()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--envs-per-gpu", "256",
+                          "--no-cpu-baseline", "--no-vecenv", "--force-gather"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][0])
+    assert "exchange" in d["config"]["parallelism"] and d["value"] > 0
+
+
+def test_vecenv_leg_of_the_bench_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--envs-per-gpu", "512",
+                          "--no-cpu-baseline", "--workload", "tmaze_features8192"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][0])
+    v = d["vecenv"]
+    assert "error" not in v, v
+    assert v["vecenv_u8"]["value"] > 0 and v["make_vec_envs_f32_stack4"]["value"] > 0 and v["vecenv_u8"]["infos"] == "LazyInfos"
