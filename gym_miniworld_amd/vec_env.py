@@ -116,10 +116,14 @@ class MiniWorldVecEnv(VecEnv):
                        (VecPyTorch); False -> numpy in / numpy out like SubprocVecEnv
     feature_info    -> every info dict carries "feature" (length-2 zeros) as the fork's PPO loop
                        requires (pytorch-a2c-ppo-acktr/main.py:614-619)
+    graph=True      -> after two eager steps the whole step (mwb_step's kernels on both streams, the frame-stack /
+                       float pass, the copies into the pinned host mirrors) is captured into one HIP graph and
+                       replayed: the VecEnv contract forces a host round trip per step, so the ~10 launches a step
+                       consists of would otherwise sit on the critical path (steps with a `mask` run eagerly)
     """
 
     def __init__(self, env_id, num_envs, seed=1, device=0, domain_rand=False, transpose=True, to_float=True,
-                 frame_stack=0, torch_api=True, feature_info=False, first_env_index=0, **kwargs):
+                 frame_stack=0, torch_api=True, feature_info=False, first_env_index=0, graph=True, **kwargs):
         import torch
         from .batch import BatchedMiniWorld
         self.torch = torch
@@ -148,6 +152,9 @@ class MiniWorldVecEnv(VecEnv):
         self._h_skip = pin((num_envs,), torch.uint8)
         self._ev = torch.cuda.Event()
         self._skip_host = None
+        self._use_graph, self._graph, self._eager_steps = bool(graph), None, 0
+        self._a_static = torch.zeros(num_envs, dtype=torch.int32, device=self.device)
+        self._obs_static = None
 
     # ---------------------------------------------------------------------------------- helpers
     def _obs_out(self, done=None):
@@ -161,34 +168,63 @@ class MiniWorldVecEnv(VecEnv):
         self.batch.reset()
         return self._obs_out()
 
-    def step_async(self, actions, mask=None):
-        torch = self.torch
-        if torch.is_tensor(actions):
-            a = actions.reshape(-1)   # VecPyTorch.step_async: actions.squeeze(1), envs.py:123
-        else:
-            a = torch.as_tensor(np.asarray(actions).reshape(-1))
-        skip = None
-        self._skip_host = None
-        if isinstance(mask, np.ndarray):   # subproc_vec_env.py:59: only ndarray masks are honoured
-            self._skip_host = mask.reshape(-1) != 0
-            self._h_skip.copy_(torch.from_numpy(self._skip_host.astype(np.uint8)))
-            skip = self._h_skip.to(self.device, non_blocking=True)
-        self.batch.step(a, skip_mask=skip)
-        self._pending = True
-
-    def step_wait(self):
-        assert self._pending, "step_wait() without step_async()"
-        self._pending = False
+    def _device_step(self, a, skip):
+        """everything of a step that runs on the device: the stepper + renderer, the learner-side layout pass and the
+        asynchronous copies of the small outputs into the pinned host mirrors"""
         b = self.batch
+        b.step(a, skip_mask=skip)
         obs = self._obs_out(done=b.done)
-        # the VecEnv contract returns numpy dones / CPU rewards / info dicts: asynchronous copies into pinned host
-        # mirrors, then one wait on the stream (the reference pays a pipe round trip per env here)
         self._h_done.copy_(b.done, non_blocking=True)
         self._h_rew.copy_(b.reward if self.torch_api else b.reward64, non_blocking=True)
         if self._h_goal is not None:
             self._h_goal.copy_(b.goal_pos, non_blocking=True)
         if self._h_feat is not None:
             self._h_feat.copy_(b.feature, non_blocking=True)
+        return obs
+
+    def step_async(self, actions, mask=None):
+        torch = self.torch
+        if torch.is_tensor(actions):
+            a = actions.reshape(-1)   # VecPyTorch.step_async: actions.squeeze(1), envs.py:123
+        else:
+            a = torch.as_tensor(np.asarray(actions).reshape(-1))
+        assert a.numel() == self.num_envs
+        self._a_static.copy_(a, non_blocking=True)   # any int dtype / device -> the int32 device buffer the kernels read
+        skip = None
+        self._skip_host = None
+        if isinstance(mask, np.ndarray):   # subproc_vec_env.py:59: only ndarray masks are honoured
+            self._skip_host = mask.reshape(-1) != 0
+            self._h_skip.copy_(torch.from_numpy(self._skip_host.astype(np.uint8)))
+            skip = self._h_skip.to(self.device, non_blocking=True)
+        if skip is None and self._use_graph and self._graph is None and self._eager_steps >= 2:
+            self._capture()
+        if skip is None and self._graph is not None:
+            self._graph.replay()
+            self._obs_now = self._obs_static
+        else:
+            self._obs_now = self._device_step(self._a_static, skip)
+            self._eager_steps += 1
+        self._pending = True
+
+    def _capture(self):
+        torch = self.torch
+        try:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):   # records only; the step itself happens at the first replay
+                self._obs_static = self._device_step(self._a_static, None)
+            self._graph = g
+        except Exception:   # capture is an optimisation: any failure leaves the eager path in charge
+            self._graph, self._use_graph = None, False
+            torch.cuda.synchronize(self.device)
+
+    def step_wait(self):
+        assert self._pending, "step_wait() without step_async()"
+        self._pending = False
+        b = self.batch
+        obs = self._obs_now
+        # the VecEnv contract returns numpy dones / CPU rewards / info dicts: the asynchronous copies into the pinned
+        # host mirrors were enqueued with the step; ONE wait on the stream (the reference pays a pipe round trip per env)
         self._ev.record(self.torch.cuda.current_stream(self.device))
         self._ev.synchronize()
         dones = self._h_done.numpy().astype(bool)
@@ -208,6 +244,7 @@ class MiniWorldVecEnv(VecEnv):
         return obs, rews, dones, infos
 
     def close(self):
+        self._graph = None
         self.batch.close()
 
 
