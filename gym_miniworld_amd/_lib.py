@@ -38,6 +38,7 @@ class MwbOutputs(ctypes.Structure):
         ("obs_bytes", ctypes.c_size_t), ("depth_bytes", ctypes.c_size_t),
         ("stack", ctypes.c_void_p), ("stack_bytes", ctypes.c_size_t),
         ("feature", ctypes.c_void_p), ("goal_pos", ctypes.c_void_p),
+        ("pack", ctypes.c_void_p), ("pack_bytes", ctypes.c_size_t),
     ]
 
 

@@ -139,6 +139,9 @@ class BatchedMiniWorld:
         self.ep_steps = as_t(out.ep_steps, (N,), "<i4")
         self.feature = as_t(out.feature, (N, 2), "<f4")     # info['feature'] (tmaze.py:311-318); zeros elsewhere
         self.goal_pos = as_t(out.goal_pos, (N, 3), "<f8")   # info['goal_pos'] of the T-maze family
+        # the six small outputs above are parts of one allocation: a host-side consumer copies `pack` once per step
+        self.pack = as_t(out.pack, (out.pack_bytes,), "|u1")
+        self.pack_offsets = {k: int(getattr(out, k)) - int(out.pack) for k in ("reward64", "goal_pos", "reward", "feature", "ep_steps", "done")}
         self.n_boxes = 2 if task in ("TMazeTwoBox", "SimToRealPush") else 1
         self.agent_radius = 0.11 if task.startswith("SimToReal") else 0.4
         self.n_actions = 4 if task == "SimToRealPush" else 3   # Discrete(move_back + 1), simtorealpush.py:37

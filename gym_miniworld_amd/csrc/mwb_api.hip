@@ -59,6 +59,8 @@ struct mwb_handle {
     hipEvent_t *ev;   // the current pass' events: 0-4 on the caller's stream, 5-6 around reset_kernel
     // mwb_step overlaps world generation of the finished envs with the bulk render on a side stream
     bool overlap_reset;
+    void *pack;          // reward64 | goal_pos | reward | feature | ep_steps | done in one allocation
+    size_t pack_bytes;
     void *stack;
     int stack_n, stack_dtype;
     size_t stack_bytes;
@@ -254,12 +256,23 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     int rc = MWB_OK;
 #define A(ptr, n) if (rc == MWB_OK) rc = dev_alloc(h, &(ptr), (n))
     A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N * d.n_boxes); A(d.box_z, N * d.n_boxes); A(d.box_dir, N * d.n_boxes);
-    A(d.box_color, N * d.n_boxes * 3); A(d.box_size, N * d.n_boxes); A(d.goal_dist, N); A(d.episode_count, N); A(d.task_step_count, N); A(d.goal_idx, N); A(d.feature, N * 2); A(d.goal_pos, N * 3); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
+    A(d.box_color, N * d.n_boxes * 3); A(d.box_size, N * d.n_boxes); A(d.goal_dist, N); A(d.episode_count, N); A(d.task_step_count, N); A(d.goal_idx, N); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
     A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.reset_set, N); A(d.reset_list, N); A(d.reset_count, (size_t)1);
     A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * MWB_ROOM_WORDS); A(d.segs, N * d.S_max * 4); A(d.frame, N * MWB_FRAME_WORDS);
     A(d.obs, N * d.W * d.H * 3);
     if (d.want_depth) { A(d.depth, N * d.W * d.H); }
-    A(d.reward, N); A(d.reward64, N); A(d.done, N); A(d.ep_steps, N);
+    {   // the small per-step outputs share one allocation (one D2H copy for a host-side consumer); 16-byte aligned parts
+        auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
+        const size_t o_r64 = 0, o_goal = o_r64 + up(N * 8), o_rew = o_goal + up(N * 24), o_feat = o_rew + up(N * 4),
+                     o_eps = o_feat + up(N * 8), o_done = o_eps + up(N * 4), total = o_done + up(N);
+        uint8_t *pack = nullptr;
+        A(pack, total);
+        if (rc == MWB_OK) {
+            h->pack = pack; h->pack_bytes = total;
+            d.reward64 = (double *)(pack + o_r64); d.goal_pos = (double *)(pack + o_goal); d.reward = (float *)(pack + o_rew);
+            d.feature = (float *)(pack + o_feat); d.ep_steps = (int32_t *)(pack + o_eps); d.done = pack + o_done;
+        }
+    }
     A(h->tex_desc_dev, (size_t)MWB_MAX_TEX);
     A(h->scratch_int_dev, (size_t)4);
     A(d.error_flag, (size_t)1);
@@ -541,6 +554,7 @@ extern "C" int mwb_get_outputs(mwb_handle *h, mwb_outputs *out) {
     out->depth_bytes = d.want_depth ? (size_t)d.N * d.W * d.H * 4 : 0;
     out->stack = h->stack; out->stack_bytes = h->stack_bytes;
     out->feature = d.feature; out->goal_pos = d.goal_pos;
+    out->pack = h->pack; out->pack_bytes = h->pack_bytes;
     return MWB_OK;
 }
 

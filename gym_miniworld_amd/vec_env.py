@@ -145,10 +145,13 @@ class MiniWorldVecEnv(VecEnv):
         self._pending = False
         # host mirrors of the small per-step outputs: pinned, filled by asynchronous copies, ONE wait per step
         pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)   # noqa: E731
-        self._h_done = pin((num_envs,), torch.uint8)
-        self._h_rew = pin((num_envs,), torch.float32 if torch_api else torch.float64)
-        self._h_goal = pin((num_envs, 3), torch.float64) if b.has_goal_pos else None
-        self._h_feat = pin((num_envs, 2), torch.float32) if b.has_features else None
+        self._h_pack = pin(tuple(b.pack.shape), torch.uint8)   # reward64 | goal_pos | reward | feature | ep_steps | done
+        hp, off, n = self._h_pack.numpy(), b.pack_offsets, num_envs
+        part = lambda key, dt, cnt: np.frombuffer(hp, dtype=dt, count=cnt, offset=off[key])   # noqa: E731
+        self._h_done = part("done", np.uint8, n)
+        self._h_rew = part("reward", np.float32, n) if torch_api else part("reward64", np.float64, n)
+        self._h_goal = part("goal_pos", np.float64, 3 * n).reshape(n, 3) if b.has_goal_pos else None
+        self._h_feat = part("feature", np.float32, 2 * n).reshape(n, 2) if b.has_features else None
         self._h_skip = pin((num_envs,), torch.uint8)
         self._ev = torch.cuda.Event()
         self._skip_host = None
@@ -174,12 +177,7 @@ class MiniWorldVecEnv(VecEnv):
         b = self.batch
         b.step(a, skip_mask=skip)
         obs = self._obs_out(done=b.done)
-        self._h_done.copy_(b.done, non_blocking=True)
-        self._h_rew.copy_(b.reward if self.torch_api else b.reward64, non_blocking=True)
-        if self._h_goal is not None:
-            self._h_goal.copy_(b.goal_pos, non_blocking=True)
-        if self._h_feat is not None:
-            self._h_feat.copy_(b.feature, non_blocking=True)
+        self._h_pack.copy_(b.pack, non_blocking=True)   # one copy: all the small outputs share an allocation
         return obs
 
     def step_async(self, actions, mask=None):
@@ -227,15 +225,15 @@ class MiniWorldVecEnv(VecEnv):
         # host mirrors were enqueued with the step; ONE wait on the stream (the reference pays a pipe round trip per env)
         self._ev.record(self.torch.cuda.current_stream(self.device))
         self._ev.synchronize()
-        dones = self._h_done.numpy().astype(bool)
+        dones = self._h_done.astype(bool)
         if self.torch_api:
-            rews = self._h_rew.clone().unsqueeze(1)       # CPU FloatTensor [N,1], envs.py:129
+            rews = self.torch.from_numpy(self._h_rew.copy()).unsqueeze(1)       # CPU FloatTensor [N,1], envs.py:129
         else:
-            rews = self._h_rew.numpy().copy()
+            rews = self._h_rew.copy()
         sk = self._skip_host
         if b.has_goal_pos:   # the T-maze family: info['goal_pos'] (tmaze.py:66,206) and, where produced, info['feature']
-            infos = LazyInfos(self.num_envs, goal_pos=self._h_goal.numpy().copy(),
-                              feature=self._h_feat.numpy().astype(np.float64) if self._h_feat is not None else None,
+            infos = LazyInfos(self.num_envs, goal_pos=self._h_goal.copy(),
+                              feature=self._h_feat.astype(np.float64) if self._h_feat is not None else None,
                               skipped=sk, default_feature=self.feature_info)
         elif sk is not None and sk.any():
             infos = LazyInfos(self.num_envs, skipped=sk, default_feature=self.feature_info)

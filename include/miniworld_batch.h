@@ -96,6 +96,11 @@ typedef struct mwb_outputs {
     size_t stack_bytes;
     float *feature;     /* f32 [N][2] info['feature'] of the transition (tmaze.py:311-318); zeros for other tasks */
     double *goal_pos;   /* f64 [N][3] info['goal_pos'] of the transition, T-maze family (tmaze.py:66,206); else zeros */
+    /* reward64, goal_pos, reward, feature, ep_steps and done live in ONE allocation [pack, pack + pack_bytes) so that a
+     * host-side consumer (the VecEnv contract returns numpy dones, CPU rewards and info dicts every step,
+     * vec_env/subproc_vec_env.py:69-75) fetches them with a single device-to-host copy; each pointer above = pack + offset */
+    void *pack;
+    size_t pack_bytes;
 } mwb_outputs;
 
 /* host-side snapshot of the simulator state of a contiguous env range, for tests / debugging / checkpoints;
