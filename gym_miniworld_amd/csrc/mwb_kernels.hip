@@ -1147,9 +1147,11 @@ __device__ __forceinline__ int trace_box(const float *fc, const float *dv, float
 struct TexLds { int w, h, n_levels; float sc_s, sc_t; int pad[3]; uint32_t off[MWB_MAX_LEVELS]; };
 static_assert(sizeof(TexLds) == sizeof(MwbTexDesc), "TexLds mirrors MwbTexDesc");
 
-#pragma clang fp contract(fast)
+// No "fp contract(fast)" here: which products the compiler fuses would depend on the code around each inlined copy, and
+// the interior-pixel path must produce the very bits the 8-sample path produces for the same surface
+// (test_fast_path_equals_full_sample_path).  Every fused multiply-add below is written out.
 __device__ __forceinline__ void bilinear(const uint32_t *__restrict__ texels, uint32_t off, int w, int h, float s, float t, float *rgb) {
-    float uu = s * (float)w - 0.5f, vv = t * (float)h - 0.5f;
+    float uu = fmaf(s, (float)w, -0.5f), vv = fmaf(t, (float)h, -0.5f);
     float fu = floorf(uu), fv = floorf(vv);
     float a = uu - fu, b = vv - fv;
     int i0 = (int)fu, j0 = (int)fv;
@@ -1168,40 +1170,42 @@ __device__ __forceinline__ void bilinear(const uint32_t *__restrict__ texels, ui
     for (int k = 0; k < 3; k++) {
         float c00 = (float)((t00 >> (8 * k)) & 255u), c10 = (float)((t10 >> (8 * k)) & 255u);
         float c01 = (float)((t01 >> (8 * k)) & 255u), c11 = (float)((t11 >> (8 * k)) & 255u);
-        rgb[k] = c00 * w00 + c10 * w10 + c01 * w01 + c11 * w11;
+        rgb[k] = fmaf(c11, w11, fmaf(c01, w01, fmaf(c10, w10, c00 * w00)));
     }
 }
 
 __device__ __forceinline__ void sample_texture(const uint32_t *__restrict__ texels, const TexLds &T, float s, float t, float sx,
                                                float tx, float sy, float ty, bool valid, float *rgb) {
-    const int maxl = T.n_levels - 1;
-    float lambda = (float)maxl;
-    if (valid) {
-        float dsdx = (sx - s) * (float)T.w, dtdx = (tx - t) * (float)T.h;
-        float dsdy = (sy - s) * (float)T.w, dtdy = (ty - t) * (float)T.h;
-        float r1 = dsdx * dsdx + dtdx * dtdx, r2 = dsdy * dsdy + dtdy * dtdy;
-        float rho2 = r1 > r2 ? r1 : r2;
-        if (rho2 < INFINITY) lambda = rho2 <= 1.0f ? 0.0f : 0.5f * __log2f(rho2);
-    }
+    // straight-line code (selects, no divergent branches): the shading batches run with dense lanes and every
+    // exec-mask excursion costs issue slots on all of them
+    const int4 dims = *(const int4 *)&T.w;   // w h n_levels sc_s(bits)
+    const int maxl = dims.z - 1;
+    const float fw = (float)dims.x, fh = (float)dims.y;
+    const float dsdx = (sx - s) * fw, dtdx = (tx - t) * fh;
+    const float dsdy = (sy - s) * fw, dtdy = (ty - t) * fh;
+    const float r1 = fmaf(dsdx, dsdx, dtdx * dtdx), r2 = fmaf(dsdy, dsdy, dtdy * dtdy);
+    const float rho2 = r1 > r2 ? r1 : r2;
+    const float lg = 0.5f * __log2f(fmaxf(rho2, 1.0f));          // rho2 <= 1 (magnification): level 0; NaN -> 1 -> 0
+    const float lambda = (valid && rho2 < INFINITY) ? lg : (float)maxl;
     float ws = s - floorf(s), wt = t - floorf(t);   // GL_REPEAT
     // non-finite coordinates (a plane seen exactly edge-on) must not become texel addresses
-    if (!(ws >= 0.0f && ws < 1.0f)) ws = 0.0f;
-    if (!(wt >= 0.0f && wt < 1.0f)) wt = 0.0f;
-    float fl = floorf(lambda);
-    int l0 = (int)fl; if (l0 > maxl) l0 = maxl;
-    int l1 = l0 + 1 > maxl ? maxl : l0 + 1;
-    float fr = (l0 == maxl) ? 0.0f : lambda - fl;
+    ws = (ws >= 0.0f && ws < 1.0f) ? ws : 0.0f;
+    wt = (wt >= 0.0f && wt < 1.0f) ? wt : 0.0f;
+    const float fl = floorf(lambda);
+    int l0 = (int)fl; l0 = l0 > maxl ? maxl : l0;
+    const int l1 = l0 + 1 > maxl ? maxl : l0 + 1;
+    const float fr = (l0 == maxl) ? 0.0f : lambda - fl;
     // both levels are always fetched (l1 == l0 when there is nothing to blend) so that the eight texel
     // loads are issued together and waited for once
     float c0[3], c1[3];
-    int w0 = T.w >> l0; if (w0 < 1) w0 = 1;
-    int h0 = T.h >> l0; if (h0 < 1) h0 = 1;
-    int w1 = T.w >> l1; if (w1 < 1) w1 = 1;
-    int h1 = T.h >> l1; if (h1 < 1) h1 = 1;
+    int w0 = dims.x >> l0; w0 = w0 < 1 ? 1 : w0;
+    int h0 = dims.y >> l0; h0 = h0 < 1 ? 1 : h0;
+    int w1 = dims.x >> l1; w1 = w1 < 1 ? 1 : w1;
+    int h1 = dims.y >> l1; h1 = h1 < 1 ? 1 : h1;
     bilinear(texels, T.off[l0], w0, h0, ws, wt, c0);
     bilinear(texels, T.off[l1], w1, h1, ws, wt, c1);
 #pragma unroll
-    for (int k = 0; k < 3; k++) rgb[k] = c0[k] + (c1[k] - c0[k]) * fr;
+    for (int k = 0; k < 3; k++) rgb[k] = fmaf(c1[k] - c0[k], fr, c0[k]);
 }
 
 // texture coordinates where ray (o, dv) meets the plane {axis = plane}; false if behind / parallel
@@ -1210,14 +1214,13 @@ __device__ __forceinline__ bool plane_texcoord(int axis, float plane, float u_or
     float od = axis == 0 ? dv[0] : axis == 1 ? dv[1] : dv[2];
     float oo = axis == 0 ? o[0] : axis == 1 ? o[1] : o[2];
     float tt = (plane - oo) * __builtin_amdgcn_rcpf(od);
-    float px = o[0] + tt * dv[0], py = o[1] + tt * dv[1], pz = o[2] + tt * dv[2];
+    float px = fmaf(tt, dv[0], o[0]), py = fmaf(tt, dv[1], o[1]), pz = fmaf(tt, dv[2], o[2]);
     // floor / ceiling: (x, z) * scale; walls: (distance along the edge, y) * scale (miniworld.py:19-68)
     float a = axis == 0 ? pz : px;
     float b = axis == 1 ? pz : py;
     s = (a - u_org) * u_scale; t = b * sc_t;
     return od != 0.0f && tt > 0.0f;
 }
-#pragma clang fp contract(off)
 
 template <int NBOX>
 struct RenderCtx {
@@ -1235,34 +1238,42 @@ struct RenderCtx {
     __device__ __forceinline__ void neighbour_rays(const float *dc, float *dx, float *dy) const {
         const float sx = 2.0f * cam.invW * cam.TW, sy = 2.0f * cam.invH * cam.TH;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { dx[k] = dc[k] + cam.S[k] * sx; dy[k] = dc[k] + cam.U[k] * sy; }
+        for (int k = 0; k < 3; k++) { dx[k] = fmaf(cam.S[k], sx, dc[k]); dy[k] = fmaf(cam.U[k], sy, dc[k]); }
     }
 
+    // INTERIOR: the caller guarantees a room surface (floor / ceiling / wall) whose plane the pixel's centre ray meets
+    // in front of the eye (the four corner rays of the pixel do): no sky / box cases, no fallback to a sample's ray.
+    template <bool INTERIOR>
     __device__ __forceinline__ void shade(uint32_t key, int first_k, float cx, float cy, float *col) const {
-        const uint32_t kind = key & 7u, side = (key >> 3) & 7u;
-        if (kind == KIND_SKY) { col[0] = fc[FC_SKY]; col[1] = fc[FC_SKY + 1]; col[2] = fc[FC_SKY + 2]; return; }
-        if (kind == KIND_BOX) {   // the key's room field holds the box index
-            const float *lb = fc + FC_LIT_BOX + 3 * side + (NBOX > 1 ? (key >> 6) * FC_BOX_STRIDE : 0u);
-            col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2];
-            return;
+        const uint32_t kind = key & 7u, side = (key >> 3) & 3u;
+        if (!INTERIOR) {
+            if (kind == KIND_SKY) { col[0] = fc[FC_SKY]; col[1] = fc[FC_SKY + 1]; col[2] = fc[FC_SKY + 2]; return; }
+            if (kind == KIND_BOX) {   // the key's room field holds the box index
+                const float *lb = fc + FC_LIT_BOX + 3 * ((key >> 3) & 7u) + (NBOX > 1 ? (key >> 6) * FC_BOX_STRIDE : 0u);
+                col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2];
+                return;
+            }
         }
+        // every read below is unconditional (any side index / texture slot is a valid address) and the choices are
+        // selects: the batch runs with dense lanes, divergent excursions would be paid by all of them
         const float *r = rooms + __umul24(key >> 6, MWB_ROOM_WORDS);
-        const uint32_t texw = (uint32_t)__float_as_int(r[RW_TEX]);
-        const int tex_id = kind == KIND_FLOOR ? (texw >> 8) & 255u : kind == KIND_CEIL ? (texw >> 16) & 255u : texw & 255u;
-        const TexLds &T = tex[tex_id];
-        const float *lit = kind == KIND_FLOOR ? fc + FC_LIT_FLOOR : kind == KIND_CEIL ? fc + FC_LIT_CEIL : fc + FC_LIT_WALL + 3 * side;
-        const bool wall = kind == KIND_WALL;
-        const float *sd = r + RW_SIDE0 + RW_SIDE_WORDS * side;
-        // plane of the surface: axis (0 x, 1 y, 2 z) and coordinate, selected without control flow
         const float4 rect = *(const float4 *)(r + RW_MINX);   // min_x max_x min_z max_z
         const float height = r[RW_HEIGHT];
-        const bool is_x = wall && (side == 0u || side == 2u), is_z = wall && (side == 1u || side == 3u);
+        const uint32_t texw = (uint32_t)__float_as_int(r[RW_TEX]);
+        const float u_org_w = r[RW_SIDE0 + RW_SIDE_WORDS * side + RS_UORG];
+        const bool wall = kind == KIND_WALL, floor_ = kind == KIND_FLOOR;
+        const uint32_t tex_id = (wall ? texw : floor_ ? (texw >> 8) : (texw >> 16)) & 255u;
+        const TexLds &T = tex[tex_id];
+        const float *lit = fc + (wall ? FC_LIT_WALL + 3 * side : floor_ ? FC_LIT_FLOOR : FC_LIT_CEIL);
+        // plane of the surface: axis (0 x, 1 y, 2 z) and coordinate
+        const bool is_x = wall && !(side & 1u), is_z = wall && (side & 1u);
         const float wall_plane = side == 0u ? rect.y : side == 2u ? rect.x : side == 3u ? rect.w : rect.z;
         const int axis = is_x ? 0 : (is_z ? 2 : 1);
-        const float plane = wall ? wall_plane : (kind == KIND_CEIL ? height : 0.0f);
+        const float plane = wall ? wall_plane : (floor_ ? 0.0f : height);
         // s = (a - u_org) * u_sgn * sc_s for walls, a * sc_s for floor / ceiling
-        const float u_org = wall ? sd[RS_UORG] : 0.0f;
-        const float u_scale = (wall && ((texw >> (24 + side)) & 1u)) ? -T.sc_s : T.sc_s;
+        const float u_org = wall ? u_org_w : 0.0f;
+        const float sc_s = T.sc_s, sc_t = T.sc_t;
+        const float u_scale = (wall && ((texw >> (24 + side)) & 1u)) ? -sc_s : sc_s;
         // centre ray and the rays through the +1 pixel neighbours, recomputed here rather than kept live
         // across the sample loop (registers are what limits occupancy)
         float dc[3], dx[3], dy[3];
@@ -1270,15 +1281,15 @@ struct RenderCtx {
         neighbour_rays(dc, dx, dy);
         float s0, t0, s1, t1, s2, t2;
         bool valid;
-        if (!plane_texcoord(axis, plane, u_org, u_scale, T.sc_t, cam.eye, dc, s0, t0)) {
-            float dv[3];   // centre ray misses the plane: shade at the sample's own hit point
+        const bool hit0 = plane_texcoord(axis, plane, u_org, u_scale, sc_t, cam.eye, dc, s0, t0);
+        const bool v1 = plane_texcoord(axis, plane, u_org, u_scale, sc_t, cam.eye, dx, s1, t1);
+        const bool v2 = plane_texcoord(axis, plane, u_org, u_scale, sc_t, cam.eye, dy, s2, t2);
+        valid = v1 && v2;
+        if (!INTERIOR && !hit0) {   // centre ray misses the plane (edge pixels only): shade at the sample's own hit point
+            float dv[3];
             make_ray(cam, cx + c_sample_x[first_k], cy + c_sample_y[first_k], dv);
-            plane_texcoord(axis, plane, u_org, u_scale, T.sc_t, cam.eye, dv, s0, t0);
+            plane_texcoord(axis, plane, u_org, u_scale, sc_t, cam.eye, dv, s0, t0);
             valid = false; s1 = s2 = s0; t1 = t2 = t0;
-        } else {
-            bool v1 = plane_texcoord(axis, plane, u_org, u_scale, T.sc_t, cam.eye, dx, s1, t1);
-            bool v2 = plane_texcoord(axis, plane, u_org, u_scale, T.sc_t, cam.eye, dy, s2, t2);
-            valid = v1 && v2;
         }
         float texel[3];
         sample_texture(texels, T, s0, t0, s1, t1, s2, t2, valid, texel);
@@ -1373,7 +1384,7 @@ struct RenderCtx {
                 else if (!(meta & 0xF000u)) { k3 = key; meta |= 0x1000u | ((uint32_t)k << 25); }
                 else {
                     float col[3];
-                    shade(key, k, cx, cy, col);
+                    shade<false>(key, k, cx, cy, col);
                     acc[0] += col[0]; acc[1] += col[1]; acc[2] += col[2];
                 }
             }
@@ -1381,7 +1392,7 @@ struct RenderCtx {
 #pragma unroll 1
         for (int it = 0; it < 4 && (meta & 0xFu); it++) {
             float col[3];
-            shade(k0, (meta >> 16) & 7u, cx, cy, col);
+            shade<false>(k0, (meta >> 16) & 7u, cx, cy, col);
             const float cnt = (float)(meta & 0xFu);
 #pragma unroll
             for (int q = 0; q < 3; q++) acc[q] += cnt * col[q];
@@ -1395,7 +1406,7 @@ struct RenderCtx {
     __device__ __forceinline__ void pixel_interior(int px, int py, uint32_t key) const {
         const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
         float col[3];
-        shade(key, 0, cx, cy, col);
+        shade<true>(key, 0, cx, cy, col);
         float t_s0 = 1.0f;
         if (depth) {   // sample 0's ray meets the known surface at the distance the traversal would report
             float dv[3];
