@@ -1065,8 +1065,7 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
                                                 const float *dv, float &t_hit, uint32_t &path) {
     t_hit = INFINITY;
     path = 1;   // leading sentinel bit: the word encodes the length as well as the sides
-    uint32_t key = MAKE_KEY(KIND_SKY, 0, 0);
-    if (room < 0) return key;
+    if (room < 0) return MAKE_KEY(KIND_SKY, 0, 0);
     const bool xpos = dv[0] > 0, xnz = dv[0] != 0, zpos = dv[2] > 0, znz = dv[2] != 0, ypos = dv[1] > 0, yneg = dv[1] < 0;
     // per-ray reciprocals (one correctly rounded division each); plane distances are (c - o) * inv
     // Sample rays (PATH == false) are part of the bit-exact spec: correctly rounded divisions.  Corner rays
@@ -1074,49 +1073,57 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
     const float ix = xnz ? (PATH ? __builtin_amdgcn_rcpf(dv[0]) : 1.0f / dv[0]) : 0.0f;
     const float iy = (ypos || yneg) ? (PATH ? __builtin_amdgcn_rcpf(dv[1]) : 1.0f / dv[1]) : 0.0f;
     const float iz = znz ? (PATH ? __builtin_amdgcn_rcpf(dv[2]) : 1.0f / dv[2]) : 0.0f;
+    // a ray parallel to a plane never reaches it: (c - o) * 0 + inf.  (fmaf(a, b, 0) is the rounded product a * b, so
+    // the distances are the spec's; written as arithmetic so that the room reads below stay unconditional.)
+    const float x_off = xnz ? 0.0f : INFINITY, z_off = znz ? 0.0f : INFINITY;
     const float tfloor = yneg ? (0.0f - o[1]) * iy : INFINITY;
     const int sx = xpos ? 0 : 2, sz = zpos ? 3 : 1;
-    int steps = 0;
+    // The loop only walks: it has ONE exit and nothing but selects inside; what the ray finally met is worked out
+    // after it from the last room's values (a nest of conditionals in the loop body costs dozens of exec-mask
+    // excursions per iteration on every lane of the wave).
+    float ts = INFINITY, tc = INFINITY, hc = 0.0f, y = 0.0f, height_w = 0.0f, p_lo = 0.0f, p_hi = 0.0f, p_maxy = 0.0f;
+    uint32_t nbr = RW_NO_NBR;
+    int s = 0, steps = 0;
     for (int iter = 0; iter <= n_rooms; iter++) {
         const float *r = rooms + __umul24((uint32_t)room, MWB_ROOM_WORDS);
         const float4 rect = *(const float4 *)(r + RW_MINX);   // min_x max_x min_z max_z
-        const float height_w = r[RW_HEIGHT], height = fabsf(height_w);
+        height_w = r[RW_HEIGHT];
         const float4 portx = *(const float4 *)(r + RW_SIDE0 + RW_SIDE_WORDS * sx);   // lo hi max_y u_org
         const float4 portz = *(const float4 *)(r + RW_SIDE0 + RW_SIDE_WORDS * sz);
         const uint32_t n01 = (uint32_t)__float_as_int(r[RW_NBR01]), n23 = (uint32_t)__float_as_int(r[RW_NBR23]);
         const uint32_t nbrx = xpos ? (n01 & 0xFFFFu) : (n23 & 0xFFFFu);   // sides 0 / 2
         const uint32_t nbrz = zpos ? (n23 >> 16) : (n01 >> 16);             // sides 3 / 1
-        const float tx = xnz ? ((xpos ? rect.y : rect.x) - o[0]) * ix : INFINITY;
-        const float tz = znz ? ((zpos ? rect.w : rect.z) - o[2]) * iz : INFINITY;
+        const float tx = fmaf((xpos ? rect.y : rect.x) - o[0], ix, x_off);
+        const float tz = fmaf((zpos ? rect.w : rect.z) - o[2], iz, z_off);
         const bool usex = tx <= tz;
-        const float ts = usex ? tx : tz;
-        const int s = usex ? sx : sz;
-        const float tc = ypos ? (height - o[1]) * iy : INFINITY;
-        const bool hit_floor = tfloor <= ts;
-        const bool hit_ceil = tc <= ts;
-        const bool escaped = !(ts < INFINITY);
-        const float4 port = usex ? portx : portz;
-        const uint32_t nbr = usex ? nbrx : nbrz;
-        const float hc = usex ? fmaf(ts, dv[2], o[2]) : fmaf(ts, dv[0], o[0]);
-        const float y = fmaf(ts, dv[1], o[1]);
-        const bool pass = nbr != RW_NO_NBR && port.x < hc && hc < port.y && 0.0f < y && y < port.z;   // portal min_y = 0
-        if (hit_floor || hit_ceil || escaped || !pass) {
-            // same precedence as the sequential tests of the spec: floor, ceiling, escape, wall
-            if (hit_floor) { t_hit = tfloor; key = MAKE_KEY(KIND_FLOOR, 0, room); }
-            else if (hit_ceil) { if (!(height_w < 0.0f)) { t_hit = tc; key = MAKE_KEY(KIND_CEIL, 0, room); } }   // no ceiling: sky
-            else if (!escaped) {
-                t_hit = ts; key = MAKE_KEY(KIND_WALL, s, room);
-                // a wall with a portal is not convex: tag the convex piece (left / right / above / below the
-                // opening) so that the corner-ray classification never spans the opening
-                if (PATH && nbr != RW_NO_NBR) key |= (hc <= port.x ? 1u : hc >= port.y ? 2u : y >= port.z ? 3u : 0u) << 28;
-            }
-            break;
-        }
+        ts = usex ? tx : tz;
+        s = usex ? sx : sz;
+        tc = ypos ? (fabsf(height_w) - o[1]) * iy : INFINITY;
+        p_lo = usex ? portx.x : portz.x; p_hi = usex ? portx.y : portz.y; p_maxy = usex ? portx.z : portz.z;
+        nbr = usex ? nbrx : nbrz;
+        hc = usex ? fmaf(ts, dv[2], o[2]) : fmaf(ts, dv[0], o[0]);
+        y = fmaf(ts, dv[1], o[1]);
+        // through the portal of that side (min_y = 0) unless the floor or the ceiling plane comes first
+        const bool go_on = nbr != RW_NO_NBR && p_lo < hc && hc < p_hi && 0.0f < y && y < p_maxy && !(tfloor <= ts) && !(tc <= ts) && ts < INFINITY;
+        if (!go_on) break;
         if (PATH) { path = (path << 2) | (uint32_t)s; steps++; }
         room = (int)nbr;
     }
+    // what stopped the ray, from the last room's values (only floats were carried out of the loop)
+    const bool hit_floor = tfloor <= ts, hit_ceil = tc <= ts, escaped = !(ts < INFINITY);
+    const bool pass = nbr != RW_NO_NBR && p_lo < hc && hc < p_hi && 0.0f < y && y < p_maxy;
+    const bool stopped = hit_floor || hit_ceil || escaped || !pass;   // false: more than n_rooms crossings (nothing is drawn)
     if (PATH && steps > 15) path = 0x80000000u | (uint32_t)steps;
-    return key;
+    // same precedence as the sequential tests of the spec: floor, ceiling (sky where the room has none), escape, wall
+    const bool wall = stopped && !hit_floor && !hit_ceil && !escaped;
+    const bool ceil_drawn = stopped && !hit_floor && hit_ceil && !(height_w < 0.0f);
+    const bool floor_ = stopped && hit_floor;
+    uint32_t wall_key = MAKE_KEY(KIND_WALL, s, room);
+    // a wall with a portal is not convex: tag the convex piece (left / right / above / below the opening) so that
+    // the corner-ray classification never spans the opening
+    if (PATH) wall_key |= (nbr != RW_NO_NBR ? (hc <= p_lo ? 1u : hc >= p_hi ? 2u : y >= p_maxy ? 3u : 0u) : 0u) << 28;
+    t_hit = floor_ ? tfloor : ceil_drawn ? tc : wall ? ts : INFINITY;
+    return floor_ ? MAKE_KEY(KIND_FLOOR, 0, room) : ceil_drawn ? MAKE_KEY(KIND_CEIL, 0, room) : wall ? wall_key : MAKE_KEY(KIND_SKY, 0, 0);
 }
 
 
