@@ -8,7 +8,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmwbatch.so")
+LIB_PATH = os.environ.get("MWB_LIB") or os.path.join(HERE, "libmwbatch.so")   # MWB_LIB: kernel A/B experiments only
 
 NPARAM = 13
 ROOM_WORDS = 24
