@@ -68,6 +68,7 @@
 #define FC_CULL_OC 64    // box bounding-sphere centre minus eye (3)
 #define FC_CULL_CC 67    // |oc|^2 - R^2
 #define FC_CULL_CC_PIXEL 68   // same with R grown by a pixel footprint
+#define FC_BOX_IN_VIEW 103     // (last word of the frame constants) != 0 if some box's footprint-inflated sphere can meet the view cone
 
 struct MwbTexDesc {
     int w, h, n_levels;

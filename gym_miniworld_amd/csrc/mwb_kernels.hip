@@ -949,6 +949,10 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     lit_color(L, amb, dif, 0, 0, 1, white, fc + FC_LIT_WALL + 3);
     lit_color(L, amb, dif, 1, 0, 0, white, fc + FC_LIT_WALL + 6);
     lit_color(L, amb, dif, 0, 0, -1, white, fc + FC_LIT_WALL + 9);
+    // Frame-level gate for every box test of the render kernel: can any box's (pixel-footprint-inflated) bounding sphere
+    // meet the cone around the view direction that contains the whole image (half angle atan |(TW, TH)|)?  Conservative
+    // (2 % + 0.01 rad slack); in a maze the box is out of view in most frames and the tests are skipped wholesale.
+    float any_in_view = 0.0f;
     for (int bi = 0; bi < d.n_boxes; bi++) {   // one block of FC_BOX_STRIDE words per box
     const size_t be = (size_t)bi * d.N + e;
     fc = d.frame + (size_t)e * MWB_FRAME_WORDS + bi * FC_BOX_STRIDE;
@@ -978,7 +982,18 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     float rho = 1.5f * 2.0f * sqrtf(tw * tw + thh * thh);
     float Rp = R + rho * (sqrtf(oc2) + R);
     fc[FC_CULL_CC_PIXEL] = oc2 - Rp * Rp;
+    {
+        const double dist = sqrt((double)oc2), Rg = 1.02 * (double)Rp;
+        if (dist <= Rg) any_in_view = 1.0f;
+        else {
+            const double cosang = ((double)oc[0] * f[0] + (double)oc[1] * f[1] + (double)oc[2] * f[2]) / dist;
+            const double ang = acos(cosang < -1 ? -1 : (cosang > 1 ? 1 : cosang));
+            const double half = atan(sqrt(th * th * ((double)d.W / d.H) * ((double)d.W / d.H) + th * th));
+            if (ang <= half + asin(Rg / dist) + 0.01) any_in_view = 1.0f;
+        }
+    }
     }   // boxes
+    (d.frame + (size_t)e * MWB_FRAME_WORDS)[FC_BOX_IN_VIEW] = any_in_view;
 }
 
 // Counting sort of the envs by the measured render cost of a recent frame, most expensive first (256 buckets of
@@ -1239,6 +1254,7 @@ struct RenderCtx {
     Cam cam;
     int n_rooms, cam_room, W, H, layout;
     float cull_cc[NBOX], cull_oc[NBOX][3], zA, zB;
+    bool boxes_in_view;   // workgroup-uniform (scalar): false = no ray of this frame can touch a box
 
     // rays through the +1 pixel neighbours (for the LOD differences): the ray is affine in the window
     // coordinates, so they are the centre ray plus a per-frame constant (shading-only, tolerance-bound)
@@ -1357,7 +1373,8 @@ struct RenderCtx {
             // conservative bounding-sphere cull, then the exact slab test; boxes in entity order, a later
             // box wins only when strictly nearer
             const float dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
-            if (NBOX == 1) {   // cull constants pinned to scalar registers
+            if (!boxes_in_view) {
+            } else if (NBOX == 1) {   // cull constants pinned to scalar registers
 #pragma unroll
                 for (int bi = 0; bi < NBOX; bi++) {
                     const float b = dv[0] * cull_oc[bi][0] + dv[1] * cull_oc[bi][1] + dv[2] * cull_oc[bi][2];
@@ -1519,6 +1536,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         cull_cc_px[bi] = uni(fb_[FC_CULL_CC_PIXEL]);
     }
     (void)cull_cc_px;
+    ctx.boxes_in_view = __builtin_amdgcn_readfirstlane(__float_as_int(fc[FC_BOX_IN_VIEW])) != 0;
 
     // Pass structure per wave: a 16 x 4 grid of rays through PIXEL CORNERS per pass, marching down a
     // 15-pixel-wide strip; the last corner row of a pass is carried in registers, so a pass classifies
@@ -1569,19 +1587,20 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             bool ok = (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
             // the pixel whose bottom-left corner this lane traced: corners (crow-1, ci), (crow-1, ci+1),
             // (crow, ci), (crow, ci+1); row crow-1 comes from the lanes above or from the previous pass
-            const uint32_t k_br = __shfl(key, lane + 1), p_br = __shfl(path, lane + 1);
-            const uint32_t k_up = __shfl(key, lane - TILE_CX), k_upr = __shfl(key, lane - TILE_CX + 1);
-            const uint32_t p_up = __shfl(path, lane - TILE_CX), p_upr = __shfl(path, lane - TILE_CX + 1);
-            const uint32_t k_pv = __shfl(prev_key, lane + 3 * TILE_CX), k_pvr = __shfl(prev_key, lane + 3 * TILE_CX + 1);
-            const uint32_t p_pv = __shfl(prev_path, lane + 3 * TILE_CX), p_pvr = __shfl(prev_path, lane + 3 * TILE_CX + 1);
-            const uint32_t k_tl = cj ? k_up : k_pv, k_tr = cj ? k_upr : k_pvr;
-            const uint32_t p_tl = cj ? p_up : p_pv, p_tr = cj ? p_upr : p_pvr;
+            // right neighbour: a shift inside the 16-lane row (DPP, no LDS traffic; lane 15 of a row is no pixel)
+            const uint32_t k_br = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+            const uint32_t p_br = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)path, 0x101, 0xf, 0xf, false);
+            // row above: lanes 16..63 want this pass' lane - 16, lanes 0..15 the previous pass' last row (lane + 48):
+            // both are "lane - 16 modulo 64" of a register that holds the previous pass' values in its last row
+            const uint32_t ck = cj == TILE_CY - 1 ? prev_key : key, cp = cj == TILE_CY - 1 ? prev_path : path;
+            const uint32_t k_tl = __shfl(ck, (lane - TILE_CX) & (WAVE - 1)), k_tr = __shfl(ck, (lane - TILE_CX + 1) & (WAVE - 1));
+            const uint32_t p_tl = __shfl(cp, (lane - TILE_CX) & (WAVE - 1)), p_tr = __shfl(cp, (lane - TILE_CX + 1) & (WAVE - 1));
             prev_key = key; prev_path = path;
             const int px = x0 + ci, py = crow - 1;
             const bool is_pixel = ci < TILE_CX - 1 && px < W && py >= row0 && py < row0 + rows && !(p == 0 && cj == 0);
             bool interior = !(d.debug_flags & 1) && is_pixel && ok && key == k_br && key == k_tl && key == k_tr &&
                             path == p_br && path == p_tl && path == p_tr;
-            if (interior) {   // may a box intrude?  centre ray against the footprint-inflated bounding spheres
+            if (interior && ctx.boxes_in_view) {   // may a box intrude?  centre ray against the footprint-inflated bounding spheres
                 float dc[3];
                 make_ray(cam, (float)px + 0.5f, (float)(H - 1 - py) + 0.5f, dc);
                 const float dd = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
