@@ -1567,6 +1567,43 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
                                  : (split_x ? (part == 0 ? half_strips : n_strips - half_strips) * 4 : n_strips * 2);
     (void)n_waves;
 
+    // a classified pixel goes to its per-wave queue; a queue that reaches 64 entries is processed at once (dense lanes)
+    auto emit = [&](int px, int py, bool is_pixel, bool interior, uint32_t key) {
+        const bool edge = is_pixel && !interior;
+        const unsigned long long em = __ballot(edge);
+        if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)((py << wshift) | px);
+        q_count += __popcll(em);
+        const unsigned long long im = __ballot(interior);
+        if (interior) {
+            const int slot = iq_count + __popcll(im & ((1ull << lane) - 1ull));
+            iq_key[slot] = key & 0x0FFFFFFFu; iq_pix[slot] = (uint16_t)((py << wshift) | px);
+        }
+        iq_count += __popcll(im);
+        if (iq_count >= WAVE) {
+            iq_count -= WAVE;
+            const int q = iq_pix[iq_count + lane];
+            if (!(d.debug_flags & 4)) ctx.pixel_interior(q & wmask, q >> wshift, iq_key[iq_count + lane]);
+        }
+        if (q_count >= WAVE) {
+            q_count -= WAVE;
+            const int q = queue[q_count + lane];
+            if (!(d.debug_flags & 2)) ctx.pixel_full(q & wmask, q >> wshift);
+        }
+    };
+    // may a box intrude into an otherwise uniform pixel?  centre ray against the footprint-inflated bounding spheres
+    auto box_may_touch = [&](int px, int py) {
+        float dc[3];
+        make_ray(cam, (float)px + 0.5f, (float)(H - 1 - py) + 0.5f, dc);
+        const float dd = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
+        bool touch = false;
+#pragma unroll
+        for (int bi = 0; bi < NBOX; bi++) {
+            const float b = dc[0] * ctx.cull_oc[bi][0] + dc[1] * ctx.cull_oc[bi][1] + dc[2] * ctx.cull_oc[bi][2];
+            if (cull_cc_px[bi] <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc_px[bi])) touch = true;
+        }
+        return touch;
+    };
+
     for (;;) {
         int item = 0;
         if (lane == 0) item = atomicAdd(cam_room_s + 1, 1);
@@ -1576,6 +1613,30 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         const int x0 = (item >> 2) * (TILE_CX - 1), row0 = (item & 3) * part_h;
         const int rows = (H - row0) < part_h ? (H - row0) : part_h;   // pixel rows of this item
         if (rows <= 0) continue;
+        if (!(d.debug_flags & (1 | 32))) {
+            // Item pre-test: the four corner rays of the whole item.  If they reach the same convex piece of a room
+            // surface through the same portals, so does every ray in between (the argument made for a pixel holds for
+            // any screen rectangle): all its pixels are interior pixels of that surface and the 4 passes are skipped.
+            const int wi = (W - x0) < (TILE_CX - 1) ? (W - x0) : (TILE_CX - 1);   // pixel columns of this item
+            float dv[3], th;
+            uint32_t path;
+            make_ray(cam, (float)(x0 + ((lane & 1) ? wi : 0)), (float)(H - (row0 + ((lane & 2) ? rows : 0))), dv);
+            const uint32_t key = trace_rooms<true>(rooms, n_rooms, ctx.cam_room, cam.eye, dv, th, path);
+            const uint32_t kind = key & 7u;
+            const bool same = key == (uint32_t)__builtin_amdgcn_readfirstlane((int)key) && path == (uint32_t)__builtin_amdgcn_readfirstlane((int)path) &&
+                              (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
+            if (__all(same)) {   // lanes 4..63 repeat lanes 0..3
+                const int col = lane & (TILE_CX - 1);
+                for (int r0 = 0; r0 < rows; r0 += TILE_CY) {
+                    const int px = x0 + col, py = row0 + r0 + lane / TILE_CX;
+                    const bool is_pixel = col < wi && py < row0 + rows;
+                    bool interior = is_pixel;
+                    if (interior && ctx.boxes_in_view && box_may_touch(px, py)) interior = false;
+                    emit(px, py, is_pixel, interior, key);
+                }
+                continue;
+            }
+        }
         uint32_t prev_key = 0, prev_path = 0;
         for (int p = 0; p < n_pass; p++) {
             const int crow = row0 + p * TILE_CY + cj;        // corner row (0 .. H), window y (up) = H - crow
@@ -1600,36 +1661,8 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             const bool is_pixel = ci < TILE_CX - 1 && px < W && py >= row0 && py < row0 + rows && !(p == 0 && cj == 0);
             bool interior = !(d.debug_flags & 1) && is_pixel && ok && key == k_br && key == k_tl && key == k_tr &&
                             path == p_br && path == p_tl && path == p_tr;
-            if (interior && ctx.boxes_in_view) {   // may a box intrude?  centre ray against the footprint-inflated bounding spheres
-                float dc[3];
-                make_ray(cam, (float)px + 0.5f, (float)(H - 1 - py) + 0.5f, dc);
-                const float dd = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
-#pragma unroll
-                for (int bi = 0; bi < NBOX; bi++) {
-                    const float b = dc[0] * ctx.cull_oc[bi][0] + dc[1] * ctx.cull_oc[bi][1] + dc[2] * ctx.cull_oc[bi][2];
-                    if (cull_cc_px[bi] <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc_px[bi])) interior = false;
-                }
-            }
-            const bool edge = is_pixel && !interior;
-            const unsigned long long em = __ballot(edge);
-            if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)((py << wshift) | px);
-            q_count += __popcll(em);
-            const unsigned long long im = __ballot(interior);
-            if (interior) {
-                const int slot = iq_count + __popcll(im & ((1ull << lane) - 1ull));
-                iq_key[slot] = key & 0x0FFFFFFFu; iq_pix[slot] = (uint16_t)((py << wshift) | px);
-            }
-            iq_count += __popcll(im);
-            if (iq_count >= WAVE) {
-                iq_count -= WAVE;
-                const int q = iq_pix[iq_count + lane];
-                if (!(d.debug_flags & 4)) ctx.pixel_interior(q & wmask, q >> wshift, iq_key[iq_count + lane]);
-            }
-            if (q_count >= WAVE) {
-                q_count -= WAVE;
-                const int q = queue[q_count + lane];
-                if (!(d.debug_flags & 2)) ctx.pixel_full(q & wmask, q >> wshift);
-            }
+            if (interior && ctx.boxes_in_view && box_may_touch(px, py)) interior = false;
+            emit(px, py, is_pixel, interior, key);
         }
     }
     // Leftovers (< 64 per wave and queue): pooled over the workgroup and dealt out again in full batches - interior
