@@ -1560,7 +1560,6 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     // none wasted).  Waves take them from an LDS counter as they become free, so a wave that drew cheap
     // (uniform) items does not idle while another one works through the edge-rich ones.
     const int part_h = (H + 3) / 4;                       // pixel rows per item
-    const int n_pass = (part_h + 1 + TILE_CY - 1) / TILE_CY;   // corner rows per item: part_h + 1
     const bool split_x = d.layout == MWB_LAYOUT_CWH;
     const int half_strips = (n_strips + 1) / 2;
     const int n_items = part < 0 ? n_strips * 4
@@ -1613,33 +1612,47 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         const int x0 = (item >> 2) * (TILE_CX - 1), row0 = (item & 3) * part_h;
         const int rows = (H - row0) < part_h ? (H - row0) : part_h;   // pixel rows of this item
         if (rows <= 0) continue;
+        int prow0 = row0, prows = rows;   // the rows left for the per-pixel corner passes
         if (!(d.debug_flags & (1 | 32))) {
-            // Item pre-test: the four corner rays of the whole item.  If they reach the same convex piece of a room
-            // surface through the same portals, so does every ray in between (the argument made for a pixel holds for
-            // any screen rectangle): all its pixels are interior pixels of that surface and the 4 passes are skipped.
+            // Item pre-test: corner rays of the whole item and of its upper / lower 8 rows (one trace, 8 lanes' worth).
+            // If the corner rays of a screen rectangle reach the same convex piece of a room surface through the same
+            // portals, so does every ray in between (the argument made for a pixel holds for any rectangle): all its
+            // pixels are interior pixels of that surface.  The whole item skips its 4 passes, a uniform half leaves 2.
             const int wi = (W - x0) < (TILE_CX - 1) ? (W - x0) : (TILE_CX - 1);   // pixel columns of this item
+            const int ha = rows < 8 ? rows : 8, hb = rows > 8 ? rows - 8 : 0;       // rows [0, ha) and [hb, rows)
+            const int q = lane & 7, qr = q >> 1;                                      // lanes 8..63 repeat lanes 0..7
+            const int crow = row0 + (qr == 0 ? 0 : qr == 1 ? hb : qr == 2 ? ha : rows);
             float dv[3], th;
             uint32_t path;
-            make_ray(cam, (float)(x0 + ((lane & 1) ? wi : 0)), (float)(H - (row0 + ((lane & 2) ? rows : 0))), dv);
+            make_ray(cam, (float)(x0 + ((q & 1) ? wi : 0)), (float)(H - crow), dv);
             const uint32_t key = trace_rooms<true>(rooms, n_rooms, ctx.cam_room, cam.eye, dv, th, path);
             const uint32_t kind = key & 7u;
-            const bool same = key == (uint32_t)__builtin_amdgcn_readfirstlane((int)key) && path == (uint32_t)__builtin_amdgcn_readfirstlane((int)path) &&
-                              (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
-            if (__all(same)) {   // lanes 4..63 repeat lanes 0..3
-                const int col = lane & (TILE_CX - 1);
-                for (int r0 = 0; r0 < rows; r0 += TILE_CY) {
-                    const int px = x0 + col, py = row0 + r0 + lane / TILE_CX;
-                    const bool is_pixel = col < wi && py < row0 + rows;
-                    bool interior = is_pixel;
-                    if (interior && ctx.boxes_in_view && box_may_touch(px, py)) interior = false;
-                    emit(px, py, is_pixel, interior, key);
-                }
-                continue;
+            const bool ok = (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
+            const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)key, 0), tp = (uint32_t)__builtin_amdgcn_readlane((int)path, 0);
+            const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)key, 2), bp = (uint32_t)__builtin_amdgcn_readlane((int)path, 2);
+            const unsigned tm = (unsigned)__ballot(ok && key == tk && path == tp) & 0xFFu;   // corner rows 0 and ha: lanes 0 1 4 5
+            const unsigned bm = (unsigned)__ballot(ok && key == bk && path == bp) & 0xFFu;   // corner rows hb and rows: lanes 2 3 6 7
+            const bool top_u = (tm & 0x33u) == 0x33u, bot_u = (bm & 0xCCu) == 0xCCu;
+            const bool all_u = top_u && bot_u && tk == bk && tp == bp;
+            int ur0 = 0, ur1 = 0;   // uniform rows [ur0, ur1) of the item
+            uint32_t ukey = 0;
+            if (all_u) { ur1 = rows; ukey = tk; prows = 0; }
+            else if (top_u && ha < rows) { ur1 = ha; ukey = tk; prow0 = row0 + ha; prows = rows - ha; }
+            else if (bot_u && hb > 0) { ur0 = hb; ur1 = rows; ukey = bk; prows = hb; }
+            const int col = lane & (TILE_CX - 1);
+            for (int r0 = ur0; r0 < ur1; r0 += TILE_CY) {
+                const int px = x0 + col, py = row0 + r0 + lane / TILE_CX;
+                const bool is_pixel = col < wi && py < row0 + ur1;
+                bool interior = is_pixel;
+                if (interior && ctx.boxes_in_view && box_may_touch(px, py)) interior = false;
+                emit(px, py, is_pixel, interior, ukey);
             }
+            if (prows <= 0) continue;
         }
+        const int n_pass_i = (prows + 1 + TILE_CY - 1) / TILE_CY;   // corner rows of the remaining rows: prows + 1
         uint32_t prev_key = 0, prev_path = 0;
-        for (int p = 0; p < n_pass; p++) {
-            const int crow = row0 + p * TILE_CY + cj;        // corner row (0 .. H), window y (up) = H - crow
+        for (int p = 0; p < n_pass_i; p++) {
+            const int crow = prow0 + p * TILE_CY + cj;        // corner row (0 .. H), window y (up) = H - crow
             float dv[3], th;
             uint32_t path;
             make_ray(cam, (float)(x0 + ci), (float)(H - crow), dv);
@@ -1658,7 +1671,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             const uint32_t p_tl = __shfl(cp, (lane - TILE_CX) & (WAVE - 1)), p_tr = __shfl(cp, (lane - TILE_CX + 1) & (WAVE - 1));
             prev_key = key; prev_path = path;
             const int px = x0 + ci, py = crow - 1;
-            const bool is_pixel = ci < TILE_CX - 1 && px < W && py >= row0 && py < row0 + rows && !(p == 0 && cj == 0);
+            const bool is_pixel = ci < TILE_CX - 1 && px < W && py >= prow0 && py < prow0 + prows && !(p == 0 && cj == 0);
             bool interior = !(d.debug_flags & 1) && is_pixel && ok && key == k_br && key == k_tl && key == k_tr &&
                             path == p_br && path == p_tl && path == p_tr;
             if (interior && ctx.boxes_in_view && box_may_touch(px, py)) interior = false;
