@@ -360,7 +360,14 @@ def math_kat():
 
 
 def main():
-    only = sys.argv[1:]   # optional task-name prefixes: regenerate just those fixtures
+    global HERE
+    args = sys.argv[1:]
+    if "--out" in args:   # write somewhere else (tests/test_fixtures_regenerate.py diffs that against the committed files)
+        i = args.index("--out")
+        HERE = args[i + 1]
+        os.makedirs(HERE, exist_ok=True)
+        args = args[:i] + args[i + 2:]
+    only = args   # optional task-name prefixes: regenerate just those fixtures
     for task, (cls, kwargs) in TASKS.items():
         if only and not any(task.startswith(o) for o in only):
             continue
