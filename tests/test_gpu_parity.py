@@ -208,6 +208,64 @@ def test_large_batch_properties():
     b.close(); small.close()
 
 
+@pytest.mark.parametrize("env_id,task,n,depth,dr", [
+    ("MiniWorld-Maze-v0", "Maze", 8192, True, False),          # BASELINE configs[2]: Maze, 8192 envs, RGB + depth
+    ("MiniWorld-FourRooms-v0", "FourRooms", 16384, False, True),   # BASELINE configs[3]: FourRooms + domain randomisation
+])
+def test_baseline_configs_at_full_size(oracle_mod, env_id, task, n, depth, dr):
+    """The BASELINE.json configurations at their full batch size, through size-independent properties: every env is
+    rendered by every step (a zeroed buffer comes back non-zero everywhere, also with the cost-ordered dispatch and
+    the half-frame tail), a step's frames equal a plain render of the same state, the first 16 envs equal a 16-env
+    batch with the same seeds (shard independence), a sample of envs equals the oracle (state bit-exact, obs +-1 LSB,
+    depth 1e-4), agents stay inside the world, spawns do not intersect (run_tests.py:51-72)."""
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    O = oracle_mod
+    b = BatchedMiniWorld(env_id, num_envs=n, seed=1, domain_rand=dr, want_depth=depth)
+    small = BatchedMiniWorld(env_id, num_envs=16, seed=1, domain_rand=dr, want_depth=depth)
+    sample = [0, 1, 777, n // 2, n - 2, n - 1]
+    refs = {i: O.OracleEnv(task, seed=1 + i, domain_rand=dr) for i in sample}
+    obs = b.reset()
+    small.reset()
+    for e in refs.values():
+        e.reset(render=False)
+    assert obs.shape == (n, 60, 80, 3) and int((obs.reshape(n, -1).max(dim=1).values == 0).sum()) == 0
+    st = b.get_state()
+    for i in range(0, n, 1021):
+        assert b.intersect(i, st["agent_pos"][i, 0], st["agent_pos"][i, 2]) == 0
+    g = torch.Generator().manual_seed(0)
+    for t in range(30):
+        a = torch.randint(0, 3, (n,), generator=g, dtype=torch.int32)
+        b.obs.zero_()
+        b.step(a)
+        small.step(a[:16])
+        for i, e in refs.items():
+            _, r, dn, _ = e.step(int(a[i]))
+            if dn:
+                e.reset(render=False)
+        assert int((b.obs.reshape(n, -1).max(dim=1).values == 0).sum()) == 0, (env_id, t, "an env was not rendered")
+    assert torch.equal(small.obs, b.obs[:16]) and torch.equal(small.reward64, b.reward64[:16])
+    if depth:
+        assert torch.equal(small.depth, b.depth[:16])
+    step_obs = b.obs.clone()
+    b.render()
+    assert torch.equal(step_obs, b.obs)
+    st = b.get_state()
+    lim = (-8.0, 8.0) if task == "FourRooms" else (0.0, 8 * 3.25)
+    assert np.all(st["agent_pos"][:, [0, 2]] >= lim[0]) and np.all(st["agent_pos"][:, [0, 2]] <= lim[1])
+    obs = b.obs.cpu().numpy()
+    dep = b.depth.cpu().numpy()[..., 0] if depth else None
+    for i, e in refs.items():
+        s = e.state()
+        assert list(st["agent_pos"][i]) == list(s.agent_pos) and st["agent_dir"][i] == s.agent_dir and st["rng_pos"][i] == s.rng_pos
+        ref, refd = e.render_obs(depth=True)
+        assert np.abs(obs[i].astype(np.int16) - ref.astype(np.int16)).max() <= 1, (env_id, i)
+        if depth:
+            assert np.abs(dep[i] - refd).max() <= 1e-4
+    assert 20 < b.obs.float().mean().item() < 235
+    b.close(); small.close()
+
+
 @pytest.mark.parametrize("env_id,task,args,mes", [c for c in CASES if c[1] in ("FourRooms", "Maze", "Hallway")])
 @pytest.mark.parametrize("dr", [0, 1])
 def test_random_view_sweep_matches_oracle(oracle_mod, env_id, task, args, mes, dr):
