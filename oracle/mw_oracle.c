@@ -193,11 +193,13 @@ struct MwoEnv {
     int n_segs;
     double (*wall_segs)[2][3];
     double room_probs[MWO_MAX_ROOMS], room_cdf[MWO_MAX_ROOMS];
-    Ent box, box2, agent;
-    int n_boxes; /* 1, or 2 for the two-box T-maze (red = box, blue = box2) */
-    int n_ents; /* placement order: box(0), [box2(1)], agent(last) */
-    double box_s[2]; /* edge length of each box (Box(size=s), entity.py:366-378) */
-    double box_color[3], box2_color[3];
+    Ent boxes[MWO_MAX_BOXES], agent;
+    int n_boxes; /* 1; 2 for the two-box T-maze (red, blue) and SimToRealPush (red, yellow); 6 for PutNext (COLOR_NAMES order) */
+    int n_ents; /* entities placed so far, in list order: the boxes, then the agent */
+    double box_s[MWO_MAX_BOXES]; /* edge length of each box (Box(size=s), entity.py:366-378) */
+    double box_colors[MWO_MAX_BOXES][3]; /* Box.color_vec after randomize (entity.py:381-383) */
+    int box_base[MWO_MAX_BOXES]; /* index into COLORS (entity.py:8-15) */
+    int carrying; /* index of the box agent.carrying refers to, or -1 (miniworld.py:682-702) */
     double goal_dist; /* SimToRealPush */
     /* T-maze family (envs/tmaze.py): goal alternation state */
     long long episode_count, task_step_count;
@@ -264,10 +266,11 @@ static void sample_param(MwoEnv *e, int use_rng, int name, double *out) {
 MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int domain_rand, const double *params) {
     MwoEnv *e = (MwoEnv *)calloc(1, sizeof(MwoEnv));
     e->task = task;
-    static const double dflt[8][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    if (task < 0 || task > MWO_SIM2REAL_PUSH) fail("unknown task");
+    static const double dflt[9][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}, {12, 0, 0, 0}};
+    if (task < 0 || task > MWO_PUTNEXT) fail("unknown task");
     for (int i = 0; i < 4; i++) e->task_args[i] = task_args ? task_args[i] : dflt[task][i];
-    e->n_boxes = (task == MWO_TMAZE_TWOBOX || task == MWO_SIM2REAL_PUSH) ? 2 : 1;
+    e->n_boxes = (task == MWO_TMAZE_TWOBOX || task == MWO_SIM2REAL_PUSH) ? 2 : task == MWO_PUTNEXT ? 6 : 1;
+    e->carrying = -1;
     if (max_episode_steps <= 0) {
         /* hallway.py:18, oneroom.py:14, fourrooms.py:15, maze.py:27 */
         if (task == MWO_HALLWAY) max_episode_steps = 250;
@@ -276,6 +279,7 @@ MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int
         else if (task == MWO_TMAZE || task == MWO_TMAZE_TWOBOX) max_episode_steps = 280; /* tmaze.py:20,142 */
         else if (task == MWO_SIM2REAL_GOTO) max_episode_steps = 100; /* simtorealgoto.py:30 */
         else if (task == MWO_SIM2REAL_PUSH) max_episode_steps = 150; /* simtorealpush.py:29 */
+        else if (task == MWO_PUTNEXT) max_episode_steps = 250; /* putnext.py:16 */
         else max_episode_steps = (int)e->task_args[0] * (int)e->task_args[1] * 24;
     }
     e->max_episode_steps = max_episode_steps;
@@ -539,24 +543,26 @@ int mwo_intersect_circle_segs(const double *point, double radius, const double *
 static int intersect(MwoEnv *e, const Ent *self, const double *pos, double radius) {
     double p[3] = {pos[0], 0, pos[2]};
     if (mwo_intersect_circle_segs(p, radius, &e->wall_segs[0][0][0], e->n_segs)) return 1;
-    const Ent *ents[3];
-    int ne = 0;
-    ents[ne++] = &e->box;
-    if (e->n_boxes == 2) ents[ne++] = &e->box2;
-    ents[ne++] = &e->agent;
-    for (int k = 0; k < e->n_ents && k < ne; k++) {
-        const Ent *o = ents[k];
+    for (int k = 0; k < e->n_ents && k <= e->n_boxes; k++) { /* self.entities in list order: the boxes, then the agent */
+        const Ent *o = k < e->n_boxes ? &e->boxes[k] : &e->agent;
         if (o == self) continue;
-        double d3[3] = {o->pos[0] - p[0], 0 - p[1], o->pos[2] - p[2]};
+        double d3[3] = {o->pos[0] - p[0], 0 - p[1], o->pos[2] - p[2]}; /* ent2's y is flattened too (miniworld.py:951-952) */
         double d = sqrt(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
         if (d < radius + o->radius) return 2 + k;
     }
     return 0;
 }
 
+/* ent: index in the entity list (boxes, then the agent = n_boxes); legacy callers pass 0 = first box, 1 = agent, 2 = second box */
 int mwo_intersect(MwoEnv *e, int ent, double x, double z, double radius) {
     double p[3] = {x, 0, z};
-    return intersect(e, ent == 0 ? &e->box : ent == 2 ? &e->box2 : &e->agent, p, radius);
+    const Ent *self = ent == 0 ? &e->boxes[0] : ent == 2 ? &e->boxes[1] : &e->agent;
+    return intersect(e, self, p, radius);
+}
+int mwo_intersect_ent(MwoEnv *e, int ent_index, double x, double z, double radius) {
+    double p[3] = {x, 0, z};
+    const Ent *self = ent_index < 0 ? NULL : ent_index < e->n_boxes ? &e->boxes[ent_index] : &e->agent;
+    return intersect(e, self, p, radius);
 }
 
 /* Room.point_inside, miniworld.py:220-232 */
@@ -599,12 +605,12 @@ static void place_entity(MwoEnv *e, Ent *ent, int has_dir, double dir, double mi
 
 /* entity.py:362-379 Box(color, size=s): radius = sqrt(sx^2 + sz^2) / 2, height = sy */
 static void size_box(MwoEnv *e, int b, double s) {
-    Ent *ent = b ? &e->box2 : &e->box;
+    Ent *ent = &e->boxes[b];
     e->box_s[b] = s;
     ent->radius = sqrt(s * s + s * s) / 2;
     ent->height = s;
 }
-static void new_box(MwoEnv *e) { size_box(e, 0, 0.8); size_box(e, 1, 0.8); }
+static void new_box(MwoEnv *e) { for (int b = 0; b < MWO_MAX_BOXES; b++) size_box(e, b, 0.8); }
 
 /* envs/maze.py:34-104 */
 typedef struct { int i, j; int order[4][2]; int next; } Frame;
@@ -646,7 +652,7 @@ static void gen_maze(MwoEnv *e) {
 #undef PUSH
     free(visited); free(stack);
     new_box(e);
-    place_entity(e, &e->box, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+    place_entity(e, &e->boxes[0], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
     place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
 }
 
@@ -657,7 +663,7 @@ static void gen_world(MwoEnv *e) {
         Room *room = add_rect_room(e, -1, -1 + length, -2, 2, TEXF_CONCRETE);
         double rmax = room->max_x;
         new_box(e);
-        place_entity(e, &e->box, 0, 0, rmax - 2, NOVAL, NOVAL, NOVAL);
+        place_entity(e, &e->boxes[0], 0, 0, rmax - 2, NOVAL, NOVAL, NOVAL);
         double dir = rs_uniform(&e->rng, -M_PI / 4, M_PI / 4);
         place_entity(e, &e->agent, 1, dir, NOVAL, rmax - 2, NOVAL, NOVAL);
         break;
@@ -666,7 +672,7 @@ static void gen_world(MwoEnv *e) {
         double size = e->task_args[0];
         add_rect_room(e, 0, size, 0, size, TEXF_CONCRETE);
         new_box(e);
-        place_entity(e, &e->box, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        place_entity(e, &e->boxes[0], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
         place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
         break;
     }
@@ -680,7 +686,7 @@ static void gen_world(MwoEnv *e) {
         connect_rooms(e, 2, 3, 2, -5, -3, 1, 2.2);
         connect_rooms(e, 3, 0, 1, -5, -3, 1, 2.2);
         new_box(e);
-        place_entity(e, &e->box, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        place_entity(e, &e->boxes[0], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
         place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
         break;
     }
@@ -693,16 +699,16 @@ static void gen_world(MwoEnv *e) {
         connect_rooms(e, 0, 1, 2, -2, 2, 0, 0);
         new_box(e);
         if (e->task == MWO_TMAZE_TWOBOX) {
-            place_entity(e, &e->box, 0, 0, 10, 10, -6, -6);
-            place_entity(e, &e->box2, 0, 0, 10, 10, 6, 6);
+            place_entity(e, &e->boxes[0], 0, 0, 10, 10, -6, -6);
+            place_entity(e, &e->boxes[1], 0, 0, 10, 10, 6, 6);
         } else if (e->task_args[0] != 0) { /* goal_pos given */
             double gx = e->task_args[1], gz = e->task_args[2];
             if (e->task_args[3] > 0) { gx = 10; gz = e->goal_idx ? 6 : -6; } /* TMazeDynamic.goals, tmaze.py:88 */
-            place_entity(e, &e->box, 0, 0, gx, gx, gz, gz);
+            place_entity(e, &e->boxes[0], 0, 0, gx, gx, gz, gz);
         } else if (rs_randint(&e->rng, 0, 2) == 0) /* RandGen.bool, random.py:26-31 */
-            place_entity_in(e, &e->box, 1, 0, 0, NOVAL, NOVAL, NOVAL, r2min + 2);
+            place_entity_in(e, &e->boxes[0], 1, 0, 0, NOVAL, NOVAL, NOVAL, r2min + 2);
         else
-            place_entity_in(e, &e->box, 1, 0, 0, NOVAL, NOVAL, r2max - 2, NOVAL);
+            place_entity_in(e, &e->boxes[0], 1, 0, 0, NOVAL, NOVAL, r2max - 2, NOVAL);
         double dir = rs_uniform(&e->rng, -M_PI / 4, M_PI / 4);
         place_entity_in(e, &e->agent, 0, 1, dir, NOVAL, NOVAL, NOVAL, NOVAL);
         break;
@@ -727,14 +733,24 @@ static void gen_world(MwoEnv *e) {
             e->goal_dist = 1.5 * (s1 + s2);
             double min_pos = 2 * e->params[MWO_P_BOT_RADIUS].hi[0], max_pos = size - 2 * e->params[MWO_P_BOT_RADIUS].hi[0];
             for (;;) { /* boxes can't start too close to each other */
-                place_entity(e, &e->box, 0, 0, min_pos, max_pos, min_pos, max_pos);
-                place_entity(e, &e->box2, 0, 0, min_pos, max_pos, min_pos, max_pos);
-                double dx = e->box.pos[0] - e->box2.pos[0], dy = e->box.pos[1] - e->box2.pos[1], dz = e->box.pos[2] - e->box2.pos[2];
+                place_entity(e, &e->boxes[0], 0, 0, min_pos, max_pos, min_pos, max_pos);
+                place_entity(e, &e->boxes[1], 0, 0, min_pos, max_pos, min_pos, max_pos);
+                double dx = e->boxes[0].pos[0] - e->boxes[1].pos[0], dy = e->boxes[0].pos[1] - e->boxes[1].pos[1], dz = e->boxes[0].pos[2] - e->boxes[1].pos[2];
                 if (sqrt((dx * dx + dy * dy) + dz * dz) > e->goal_dist) break;
                 e->n_ents = 0; /* entities.remove(box1), entities.remove(box2) */
             }
         } else {
-            place_entity(e, &e->box, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+            place_entity(e, &e->boxes[0], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        }
+        place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        break;
+    }
+    case MWO_PUTNEXT: { /* envs/putnext.py:22-43 */
+        double size = e->task_args[0];
+        add_rect_room(e, 0, size, 0, size, TEXF_CONCRETE);
+        for (int b = 0; b < 6; b++) { /* Box(color=color, size=self.rand.float(0.6, 0.85)): the size is drawn before the placement */
+            size_box(e, b, rs_uniform(&e->rng, 0.6, 0.85));
+            place_entity(e, &e->boxes[b], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
         }
         place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
         break;
@@ -762,6 +778,11 @@ void mwo_reset(MwoEnv *e) {
     e->n_ents = 0;
     memset(&e->agent, 0, sizeof(Ent));
     e->agent.radius = 0.4; e->agent.height = 1.6; /* entity.py:436-455 */
+    e->carrying = -1; /* a fresh Agent() carries nothing (entity.py:446) */
+    for (int b = 0; b < MWO_MAX_BOXES; b++) { memset(&e->boxes[b], 0, sizeof(Ent)); e->box_base[b] = 4; /* red */ }
+    if (e->task == MWO_TMAZE_TWOBOX) e->box_base[1] = 0;          /* blue, tmaze.py:168 */
+    else if (e->task == MWO_SIM2REAL_PUSH) e->box_base[1] = 5;    /* yellow, simtorealpush.py:93 */
+    else if (e->task == MWO_PUTNEXT) for (int b = 0; b < 6; b++) e->box_base[b] = b;   /* for color in COLOR_NAMES, putnext.py:31 */
     gen_world(e);
     int dr = e->domain_rand;
     sample_param(e, dr, MWO_P_SKY_COLOR, e->sky_color);
@@ -769,16 +790,14 @@ void mwo_reset(MwoEnv *e) {
     sample_param(e, dr, MWO_P_LIGHT_COLOR, e->light_color);
     sample_param(e, dr, MWO_P_LIGHT_AMBIENT, e->light_ambient);
     e->max_forward_step = e->params[MWO_P_FORWARD_STEP].hi[0];
-    /* Box.randomize, entity.py:381-383: COLORS['red'] + bias, clipped */
-    double bias[3];
-    sample_param(e, dr, MWO_P_OBJ_COLOR_BIAS, bias);
-    const double red[3] = {1.0, 0.0, 0.0};
-    for (int k = 0; k < 3; k++) { double v = red[k] + bias[k]; e->box_color[k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
-    if (e->n_boxes == 2) { /* entities are randomized in list order: red box, blue box, agent */
-        const double blue[3] = {0.0, 0.0, 1.0}, yellow[3] = {1.0, 1.0, 0.0}; /* COLORS, entity.py:8-15 */
-        const double *c2 = e->task == MWO_SIM2REAL_PUSH ? yellow : blue;
+    /* Box.randomize, entity.py:381-383: COLORS[color] + bias, clipped - entities are randomized in list order */
+    static const double COLORS[6][3] = {{0.0, 0.0, 1.0}, {0.0, 1.0, 0.0}, {0.39, 0.39, 0.39}, {0.44, 0.15, 0.76},
+                                        {1.0, 0.0, 0.0}, {1.00, 1.00, 0.00}}; /* COLOR_NAMES order: blue green grey purple red yellow */
+    for (int b = 0; b < e->n_boxes; b++) {
+        double bias[3];
         sample_param(e, dr, MWO_P_OBJ_COLOR_BIAS, bias);
-        for (int k = 0; k < 3; k++) { double v = c2[k] + bias[k]; e->box2_color[k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
+        const double *c = COLORS[e->box_base[b]];
+        for (int k = 0; k < 3; k++) { double v = c[k] + bias[k]; e->box_colors[b][k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
     }
     /* Agent.randomize, entity.py:486-492 */
     sample_param(e, dr, MWO_P_CAM_HEIGHT, &e->cam_height);
@@ -794,7 +813,18 @@ static int near_ent(MwoEnv *e, const Ent *b) {
     double dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     return dist < b->radius + e->agent.radius + 1.1 * e->max_forward_step;
 }
-static int near_box(MwoEnv *e) { return near_ent(e, &e->box); }
+static int near_box(MwoEnv *e) { return near_ent(e, &e->boxes[0]); }
+
+/* MiniWorldEnv._get_carry_pos, miniworld.py:594-606 */
+static void carry_pos(MwoEnv *e, const double *agent_pos, const Ent *ent, double *out) {
+    double dist = (e->agent.radius + ent->radius) + e->max_forward_step;
+    double dv[3] = {cos(e->agent.dir), 0, -sin(e->agent.dir)};
+    for (int k = 0; k < 3; k++) out[k] = agent_pos[k] + (dv[k] * 1.05) * dist;   /* agent_pos + self.agent.dir_vec * 1.05 * dist */
+    double y_pos = (e->cam_height - ent->height) - 0.3;
+    if (!(y_pos > 0)) y_pos = 0;   /* max(cam_height - ent.height - 0.3, 0) */
+    out[1] = out[1] + 1.0 * y_pos;  /* pos + Y_VEC * y_pos */
+    out[0] = out[0] + 0.0 * y_pos; out[2] = out[2] + 0.0 * y_pos;
+}
 
 /* MiniWorldEnv.step miniworld.py:658-716 + task rule (e.g. envs/maze.py:106-113) */
 void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
@@ -803,7 +833,7 @@ void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
         double dv[3] = {cos(e->agent.dir), 0, -sin(e->agent.dir)};
         double next_pos[3];
         for (int k = 0; k < 3; k++) next_pos[k] = e->agent.pos[k] + dv[k] * fwd_dist;
-        Ent *boxes[2] = {&e->box, &e->box2};
+        Ent *boxes[2] = {&e->boxes[0], &e->boxes[1]};
         for (int b = 0; b < 2; b++) {
             Ent *box = boxes[b];
             double vec[3] = {box->pos[0] - next_pos[0], box->pos[1] - next_pos[1], box->pos[2] - next_pos[2]};
@@ -823,33 +853,72 @@ void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
     sample_param(e, dr, MWO_P_FORWARD_STEP, &fwd_step);
     sample_param(e, dr, MWO_P_FORWARD_DRIFT, &fwd_drift);
     sample_param(e, dr, MWO_P_TURN_STEP, &turn_step);
+    Ent *carried = e->carrying >= 0 ? &e->boxes[e->carrying] : NULL;
     if (action == 2 || action == 3) { /* move_agent miniworld.py:608-633 */
         double fd = action == 2 ? fwd_step : -fwd_step;
         double dv[3] = {cos(e->agent.dir), 0, -sin(e->agent.dir)}; /* entity.py:72-80 */
         double rv[3] = {sin(e->agent.dir), 0, cos(e->agent.dir)};  /* entity.py:82-90 */
         double np_[3];
         for (int k = 0; k < 3; k++) np_[k] = (e->agent.pos[k] + dv[k] * fd) + rv[k] * fwd_drift;
-        if (!intersect(e, &e->agent, np_, e->agent.radius)) memcpy(e->agent.pos, np_, sizeof(np_));
+        if (!intersect(e, &e->agent, np_, e->agent.radius)) {
+            int ok = 1;
+            double cp[3];
+            if (carried) { /* the carried entity must fit where it would go (miniworld.py:622-629) */
+                carry_pos(e, np_, carried, cp);
+                if (intersect(e, carried, cp, carried->radius)) ok = 0;
+                else memcpy(carried->pos, cp, sizeof(cp));
+            }
+            if (ok) memcpy(e->agent.pos, np_, sizeof(np_));
+        }
     } else if (action == 0 || action == 1) { /* turn_agent miniworld.py:635-656 */
         double ta = action == 0 ? turn_step : -turn_step;
         ta *= (M_PI / 180);
+        double orig = e->agent.dir;
         e->agent.dir += ta;
+        if (carried) {
+            double cp[3];
+            carry_pos(e, e->agent.pos, carried, cp);
+            if (intersect(e, carried, cp, carried->radius)) e->agent.dir = orig;
+            else { memcpy(carried->pos, cp, sizeof(cp)); carried->dir = e->agent.dir; }
+        }
+    } else if (action == 4) { /* pickup, miniworld.py:682-689: the first entity within 1.2 r of a point 1.5 r ahead */
+        double dv[3] = {cos(e->agent.dir), 0, -sin(e->agent.dir)};
+        double tp[3];
+        for (int k = 0; k < 3; k++) tp[k] = e->agent.pos[k] + (dv[k] * 1.5) * e->agent.radius;
+        int hit = intersect(e, &e->agent, tp, 1.2 * e->agent.radius);
+        if (e->carrying < 0 && hit >= 2 && hit - 2 < e->n_boxes) e->carrying = hit - 2; /* Box.is_static is False (entity.py:40-46) */
+    } else if (action == 5) { /* drop, miniworld.py:692-695 */
+        if (e->carrying >= 0) { e->boxes[e->carrying].pos[1] = 0; e->carrying = -1; }
+    }
+    if (e->carrying >= 0) { /* miniworld.py:698-701 */
+        Ent *c = &e->boxes[e->carrying];
+        double cp[3];
+        carry_pos(e, e->agent.pos, c, cp);
+        memcpy(c->pos, cp, sizeof(cp));
+        c->dir = e->agent.dir;
     }
     double r = 0; int d = 0;
     if (e->step_count >= e->max_episode_steps) { d = 1; r = 0; }
     if (e->task == MWO_TMAZE_TWOBOX) { /* tmaze.py:196-208 / 299-320: goal box, then penalty box */
-        const Ent *boxes[2] = {&e->box, &e->box2};
+        const Ent *boxes[2] = {&e->boxes[0], &e->boxes[1]};
         if (near_ent(e, boxes[e->goal_idx])) { r += 1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps); d = 1; }
         if (near_ent(e, boxes[1 - e->goal_idx])) { r += -1 * (1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps)); d = 1; }
         e->feature[0] = e->feature[1] = 0;
         if (e->task_args[0] != 0) { /* feature = [near(blue), near(red)], tmaze.py:311-318 */
-            e->feature[0] = near_ent(e, &e->box2) ? 1 : 0;
-            e->feature[1] = near_ent(e, &e->box) ? 1 : 0;
+            e->feature[0] = near_ent(e, &e->boxes[1]) ? 1 : 0;
+            e->feature[1] = near_ent(e, &e->boxes[0]) ? 1 : 0;
             e->task_step_count += 1;
         }
     } else if (e->task == MWO_SIM2REAL_PUSH) { /* simtorealpush.py:129-133 */
-        double dx = e->box.pos[0] - e->box2.pos[0], dy = e->box.pos[1] - e->box2.pos[1], dz = e->box.pos[2] - e->box2.pos[2];
+        double dx = e->boxes[0].pos[0] - e->boxes[1].pos[0], dy = e->boxes[0].pos[1] - e->boxes[1].pos[1], dz = e->boxes[0].pos[2] - e->boxes[1].pos[2];
         if (sqrt((dx * dx + dy * dy) + dz * dz) < e->goal_dist) { r = 1; d = 1; }
+    } else if (e->task == MWO_PUTNEXT) { /* putnext.py:45-53: red (4) next to yellow (5), nothing carried */
+        if (e->carrying < 0) {
+            const Ent *a = &e->boxes[4], *b = &e->boxes[5];
+            double dd[3] = {a->pos[0] - b->pos[0], a->pos[1] - b->pos[1], a->pos[2] - b->pos[2]};
+            double dist = sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]);
+            if (dist < a->radius + b->radius + 1.1 * e->max_forward_step) { r += 1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps); d = 1; }
+        }
     } else if (near_box(e)) { r += 1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps); d = 1; }
     *reward = r; *done = d;
 }
@@ -885,7 +954,7 @@ static void camera(MwoEnv *e, double *cam_pos, double *cam_dir) {
 void mwo_get_state(MwoEnv *e, MwoState *s) {
     memset(s, 0, sizeof(*s));
     memcpy(s->agent_pos, e->agent.pos, 24); s->agent_dir = e->agent.dir;
-    memcpy(s->box_pos, e->box.pos, 24); s->box_dir = e->box.dir; memcpy(s->box_color, e->box_color, 24);
+    memcpy(s->box_pos, e->boxes[0].pos, 24); s->box_dir = e->boxes[0].dir; memcpy(s->box_color, e->box_colors[0], 24);
     s->cam_height = e->cam_height; s->cam_fwd_disp = e->cam_fwd_disp; s->cam_pitch = e->cam_pitch; s->cam_fov_y = e->cam_fov_y;
     memcpy(s->sky_color, e->sky_color, 24); memcpy(s->light_pos, e->light_pos, 24);
     memcpy(s->light_color, e->light_color, 24); memcpy(s->light_ambient, e->light_ambient, 24);
@@ -898,10 +967,15 @@ void mwo_get_state(MwoEnv *e, MwoState *s) {
     uint64_t sum = 0; for (int i = 0; i < 624; i++) sum += e->rng.key[i];
     s->rng_keysum = (uint32_t)(sum & 0xFFFFFFFFu);
     s->n_boxes = e->n_boxes; s->goal_idx = e->goal_idx;
-    memcpy(s->box2_pos, e->box2.pos, 24); s->box2_dir = e->box2.dir; memcpy(s->box2_color, e->box2_color, 24);
+    memcpy(s->box2_pos, e->boxes[1].pos, 24); s->box2_dir = e->boxes[1].dir; memcpy(s->box2_color, e->box_colors[1], 24);
     s->episode_count = e->episode_count; s->task_step_count = e->task_step_count;
     s->feature[0] = e->feature[0]; s->feature[1] = e->feature[1];
     s->box_size = e->box_s[0]; s->box2_size = e->box_s[1]; s->agent_radius = e->agent.radius; s->goal_dist = e->goal_dist;
+    for (int b = 0; b < MWO_MAX_BOXES; b++) {
+        memcpy(s->boxes_pos[b], e->boxes[b].pos, 24); s->boxes_dir[b] = e->boxes[b].dir;
+        memcpy(s->boxes_color[b], e->box_colors[b], 24); s->boxes_size[b] = b < e->n_boxes ? e->box_s[b] : 0;
+    }
+    s->carrying = e->carrying;
 }
 void mwo_set_counters(MwoEnv *e, long long episode_count, long long task_step_count, int goal_idx) {
     e->episode_count = episode_count; e->task_step_count = task_step_count; e->goal_idx = goal_idx;
@@ -910,9 +984,11 @@ void mwo_set_counters(MwoEnv *e, long long episode_count, long long task_step_co
 void mwo_set_agent(MwoEnv *e, double x, double z, double dir) { e->agent.pos[0] = x; e->agent.pos[1] = 0; e->agent.pos[2] = z; e->agent.dir = dir; }
 void mwo_set_step_count(MwoEnv *e, int sc) { e->step_count = sc; }
 void mwo_set_box(MwoEnv *e, int b, double x, double z, double dir) {
-    Ent *t = b ? &e->box2 : &e->box;
+    Ent *t = &e->boxes[b];
     t->pos[0] = x; t->pos[1] = 0; t->pos[2] = z; t->dir = dir;
 }
+void mwo_set_box_y(MwoEnv *e, int b, double y) { e->boxes[b].pos[1] = y; }
+void mwo_set_carrying(MwoEnv *e, int b) { e->carrying = b; }
 
 void mwo_get_geometry(MwoEnv *e, double *outline, double *heights, double *portals, int *portal_count, double *segs,
                       double *room_probs, double *qv, double *qn, float *qt, int *qoff, double *ftex, double *ctex, int *tex_ids) {
@@ -1202,7 +1278,7 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
     double ll = sqrt(lp[0] * lp[0] + lp[1] * lp[1] + lp[2] * lp[2]);
     for (int k = 0; k < 3; k++) {
         L.light_dir[k] = (float)(lp[k] / ll); L.amb[k] = (float)e->light_ambient[k]; L.diff[k] = (float)e->light_color[k];
-        L.sky[k] = (float)e->sky_color[k]; L.box_color[k] = (float)e->box_color[k];
+        L.sky[k] = (float)e->sky_color[k]; L.box_color[k] = (float)e->box_colors[0][k];
     }
     const float white[3] = {1, 1, 1};
     float lit_floor[3], lit_ceil[3], lit_wall[4][3];
@@ -1210,13 +1286,13 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
     { float n[3] = {0, -1, 0}; lit_color(&L, n, white, lit_ceil); }
     { static const float wn[4][3] = {{-1, 0, 0}, {0, 0, 1}, {1, 0, 0}, {0, 0, -1}};
       for (int k = 0; k < 4; k++) lit_color(&L, wn[k], white, lit_wall[k]); }
-    RBox bxs[2];
-    float lit_boxes[2][6][3];
+    RBox bxs[MWO_MAX_BOXES];
+    float lit_boxes[MWO_MAX_BOXES][6][3];
     for (int b = 0; b < e->n_boxes; b++) {
-        const Ent *be = b ? &e->box2 : &e->box;
+        const Ent *be = &e->boxes[b];
         RBox bx;
         float bcol[3];
-        for (int k = 0; k < 3; k++) { bx.pos[k] = (float)be->pos[k]; bcol[k] = b ? (float)e->box2_color[k] : L.box_color[k]; }
+        for (int k = 0; k < 3; k++) { bx.pos[k] = (float)be->pos[k]; bcol[k] = (float)e->box_colors[b][k]; }
         bx.c = (float)cos(be->dir); bx.s = (float)sin(be->dir);
         bx.half[0] = (float)(e->box_s[b] / 2); bx.half[2] = (float)(e->box_s[b] / 2); bx.half[1] = 0; bx.sy = (float)e->box_s[b];
         /* world normal of local normal n: R_y(dir) n = (nx c + nz s, ny, -nx s + nz c) */

@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 enum { MWO_HALLWAY = 0, MWO_ONEROOM = 1, MWO_FOURROOMS = 2, MWO_MAZE = 3, MWO_TMAZE = 4, MWO_TMAZE_TWOBOX = 5,
-       MWO_SIM2REAL_GOTO = 6, MWO_SIM2REAL_PUSH = 7 };
+       MWO_SIM2REAL_GOTO = 6, MWO_SIM2REAL_PUSH = 7, MWO_PUTNEXT = 8 };
 
 /* domain parameters, reference params.py:110-123, same order */
 enum {
@@ -34,6 +34,7 @@ enum {
     MWO_P_CAM_FOV_Y, MWO_P_CAM_HEIGHT, MWO_P_CAM_FWD_DISP, MWO_NPARAM
 };
 
+#define MWO_MAX_BOXES 6
 #define MWO_MAX_ROOMS 512
 #define MWO_MAX_PORTALS 2 /* per edge */
 #define MWO_MAX_TEX 32
@@ -48,7 +49,9 @@ int mwo_set_texture(int tex_id, int width, int height, int n_levels, const uint8
 /* task_args: Hallway {length}, OneRoom {size}, FourRooms {}, Maze {num_rows, num_cols, room_size},
  * TMaze {goal_pos given?, goal x, goal z, sub_task_length (> 0: TMazeDynamic)},
  * TMazeTwoBox {rule: 0 episode count (TMazeTwoBoxDynamic) / 1 step count + features (*Features*), -, -, sub_task_length},
- * SimToRealGoTo {} / SimToRealPush {} (envs/simtorealgoto.py, simtorealpush.py: pass their sim_params table and domain_rand = 1).
+ * SimToRealGoTo {} / SimToRealPush {} (envs/simtorealgoto.py, simtorealpush.py: pass their sim_params table and domain_rand = 1),
+ * PutNext {size} (envs/putnext.py: six boxes in COLOR_NAMES order - blue green grey purple red yellow - of random sizes; actions 0..7
+ * incl. pickup 4 / drop 5 with the carry physics of miniworld.py:594-702; done when red is next to yellow and nothing is carried).
  * params: MWO_NPARAM x 9 doubles (default[3], min[3], max[3]); NULL = reference defaults. */
 MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int domain_rand,
                    const double *params);
@@ -75,11 +78,17 @@ typedef struct {
     double feature[2]; /* info['feature'] of the last step (zeros for tasks without) */
     /* sim-to-real tasks: per-episode sizes */
     double box_size, box2_size, agent_radius, goal_dist;
+    /* all boxes in entity-list order (y = pos[1] > 0 while carried), and agent.carrying as a box index or -1 */
+    double boxes_pos[MWO_MAX_BOXES][3], boxes_dir[MWO_MAX_BOXES], boxes_color[MWO_MAX_BOXES][3], boxes_size[MWO_MAX_BOXES];
+    int carrying;
 } MwoState;
 void mwo_get_state(MwoEnv *e, MwoState *out);
 void mwo_set_agent(MwoEnv *e, double x, double z, double dir); /* test hook */
 void mwo_set_step_count(MwoEnv *e, int step_count);
-void mwo_set_box(MwoEnv *e, int box /*0 first, 1 second*/, double x, double z, double dir); /* test hook */
+void mwo_set_box(MwoEnv *e, int box /* index in the entity list */, double x, double z, double dir); /* test hook */
+void mwo_set_box_y(MwoEnv *e, int box, double y);
+void mwo_set_carrying(MwoEnv *e, int box /* or -1 */);
+int mwo_intersect_ent(MwoEnv *e, int ent_index /* -1 nobody, 0..B-1 box, B agent */, double x, double z, double radius);
 void mwo_set_counters(MwoEnv *e, long long episode_count, long long task_step_count, int goal_idx); /* test hook */
 /* geometry dumps (sizes from MwoState): outline R*4*2, heights R, portals R*4*MAXP*4 (nan pad),
  * portal_count R*4, segs S*4 (a.x a.z b.x b.z), room_probs R, quad verts Q*4*3, norms Q*4*3,

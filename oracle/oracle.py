@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(HERE, "libmw_oracle.so")
 TEX_DIR = os.path.join(os.path.dirname(HERE), "gym_miniworld_amd", "textures")
 
 TASKS = {"Hallway": 0, "OneRoom": 1, "FourRooms": 2, "Maze": 3, "TMaze": 4, "TMazeTwoBox": 5,
-         "SimToRealGoTo": 6, "SimToRealPush": 7}
+         "SimToRealGoTo": 6, "SimToRealPush": 7, "PutNext": 8}
+MAX_BOXES = 6
 # texture id table (family -> files), reference opengl.py:40-69 picks <name>_<i>.png
 TEX_FILES = ["floor_tiles_bw_1", "concrete_1", "concrete_2", "concrete_3", "concrete_4",
              "concrete_tiles_1", "brick_wall_1",
@@ -54,6 +55,8 @@ class MwoState(ctypes.Structure):
         ("feature", ctypes.c_double * 2),
         ("box_size", ctypes.c_double), ("box2_size", ctypes.c_double), ("agent_radius", ctypes.c_double),
         ("goal_dist", ctypes.c_double),
+        ("boxes_pos", (ctypes.c_double * 3) * 6), ("boxes_dir", ctypes.c_double * 6),
+        ("boxes_color", (ctypes.c_double * 3) * 6), ("boxes_size", ctypes.c_double * 6), ("carrying", ctypes.c_int),
     ]
 
 
@@ -76,6 +79,9 @@ def lib():
         L.mwo_set_agent.argtypes = [vp, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         L.mwo_set_step_count.argtypes = [vp, ctypes.c_int]
         L.mwo_set_box.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+        L.mwo_set_box_y.argtypes = [vp, ctypes.c_int, ctypes.c_double]
+        L.mwo_set_carrying.argtypes = [vp, ctypes.c_int]
+        L.mwo_intersect_ent.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         L.mwo_set_counters.argtypes = [vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int]
         L.mwo_get_geometry.argtypes = [vp] + [vp] * 13
         L.mwo_intersect.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
@@ -216,6 +222,15 @@ class OracleEnv:
 
     def set_box(self, b, x, z, d):
         self.L.mwo_set_box(self.h, int(b), x, z, d)
+
+    def set_box_y(self, b, y):
+        self.L.mwo_set_box_y(self.h, int(b), float(y))
+
+    def set_carrying(self, b):
+        self.L.mwo_set_carrying(self.h, int(b))
+
+    def intersect_ent(self, ent_index, x, z, radius):
+        return self.L.mwo_intersect_ent(self.h, int(ent_index), x, z, radius)
 
     def set_step_count(self, n):
         self.L.mwo_set_step_count(self.h, n)

@@ -28,6 +28,7 @@ from gym_miniworld.envs import FourRooms, Hallway, Maze, OneRoom  # noqa: E402
 from gym_miniworld.envs import (TMaze, TMazeDynamic, TMazeLeft, TMazeRight, TMazeTwoBoxDynamic,  # noqa: E402
                                 TMazeTwoBoxDynamicFeatures100K, TMazeTwoBoxDynamicFeaturesDebug)
 from gym_miniworld.envs import SimToRealGoTo, SimToRealPush  # noqa: E402
+from gym_miniworld.envs import PutNext  # noqa: E402
 from gym_miniworld.opengl import Texture  # noqa: E402
 from gym_miniworld import math as ref_math  # noqa: E402
 
@@ -272,6 +273,113 @@ def run_case(cls, kwargs, seed, dr, policy, n_steps):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Tasks with several boxes and the carry actions: PutNext.  Every box of the entity list is
+# recorded at every step (position incl. the carried height, heading), plus agent.carrying as an index.
+CARRY_TASKS = {"PutNext": (PutNext, {})}
+CARRY_PLAN = {"PutNext": [(0, 0, "putnext", 700), (1, 1, "putnext", 700), (2, 0, "random", 600), (3, 1, "random", 500),
+                          (4, 0, "grab", 500)]}
+
+
+def carry_index(env):
+    c = env.agent.carrying
+    return -1 if c is None else next(i for i, e in enumerate(env.entities) if e is c)
+
+
+def snapshot_boxes(env):
+    boxes = [e for e in env.entities if e is not env.agent]
+    a = env.agent
+    return {
+        "boxes_pos": np.array([b.pos for b in boxes], dtype=float), "boxes_dir": np.array([float(b.dir) for b in boxes]),
+        "boxes_color": np.array([b.color_vec for b in boxes], dtype=float), "boxes_size": np.array([float(b.size[0]) for b in boxes]),
+        "boxes_radius": np.array([float(b.radius) for b in boxes]), "boxes_height": np.array([float(b.height) for b in boxes]),
+        "carrying": np.array(carry_index(env)),
+        "agent_pos": np.array(a.pos, dtype=float), "agent_dir": np.array(float(a.dir)),
+        "cam": np.array([a.cam_height, a.cam_fwd_disp, a.cam_pitch, a.cam_fov_y], dtype=float),
+        "sky_color": np.array(env.sky_color, dtype=float), "light_pos": np.array(env.light_pos, dtype=float),
+        "light_color": np.array(env.light_color, dtype=float), "light_ambient": np.array(env.light_ambient, dtype=float),
+        "rng": rng_fingerprint(env), "wall_segs_sum": np.array(float(np.sum(env.wall_segs))),
+        "tex_names": np.array([[tex_basename(r.wall_tex), tex_basename(r.floor_tex), tex_basename(r.ceil_tex)] for r in env.rooms]),
+    }
+
+
+def carry_action(env, policy, arng):
+    A = env.actions
+    if policy == "random" or arng.random() < 0.06:
+        return int(arng.integers(0, env.action_space.n))
+    a = env.agent
+
+    def steer(tgt, stop_dist):
+        want = math.atan2(-(tgt[2] - a.pos[2]), tgt[0] - a.pos[0])
+        diff = (want - a.dir + math.pi) % (2 * math.pi) - math.pi
+        if abs(diff) > math.radians(9):
+            return int(A.turn_left if diff > 0 else A.turn_right), False
+        d = math.hypot(tgt[0] - a.pos[0], tgt[2] - a.pos[2])
+        return int(A.move_forward), d < stop_dist
+    if policy == "grab":   # pick up whatever is closest, carry it around (turns and back-ups included), drop it
+        if a.carrying is None:
+            b = min((e for e in env.entities if e is not a), key=lambda e: np.linalg.norm(e.pos - a.pos))
+            act, close = steer(b.pos, a.radius + b.radius + 0.25)
+            return int(A.pickup) if close else act
+        r = arng.random()
+        return int(A.drop) if r < 0.04 else int(arng.choice([A.turn_left, A.turn_right, A.move_forward, A.move_forward, A.move_back]))
+    # putnext: fetch the red box, carry it to the yellow one, put it down next to it
+    red, yel = env.red_box, env.yellow_box
+    if a.carrying is None:
+        act, close = steer(red.pos, a.radius + red.radius + 0.25)
+        return int(A.pickup) if close else act
+    if a.carrying is not red:
+        return int(A.drop)
+    if env.near(red, yel):
+        return int(A.drop)
+    act, _ = steer(yel.pos, 0.0)
+    return act
+
+
+def run_carry_case(cls, kwargs, seed, dr, policy, n_steps):
+    env = construct(cls, kwargs, dr)
+    env.seed(seed)
+    env.reset()
+    nb = len(env.entities) - 1
+    out = {"reset0/" + k: v for k, v in snapshot_boxes(env).items()}
+    out["reset0/wall_segs"] = np.concatenate([np.asarray(env.wall_segs)[:, 0, [0, 2]], np.asarray(env.wall_segs)[:, 1, [0, 2]]], axis=1)
+    arng = np.random.default_rng(2000 + seed)
+    rec = {"actions": np.zeros(n_steps, np.int32), "pos": np.zeros((n_steps, 3)), "dir": np.zeros(n_steps), "reward": np.zeros(n_steps),
+           "done": np.zeros(n_steps, np.uint8), "step_count": np.zeros(n_steps, np.int32), "rng": np.zeros((n_steps, 5), np.int64),
+           "boxes_pos": np.zeros((n_steps, nb, 3)), "boxes_dir": np.zeros((n_steps, nb)), "carrying": np.zeros(n_steps, np.int32),
+           "cam_pos": np.zeros((n_steps, 3)), "cam_dir": np.zeros((n_steps, 3))}
+    post = []
+    pickups = drops = 0
+    for t in range(n_steps):
+        a = carry_action(env, policy, arng)
+        before = carry_index(env)
+        _, r, d, _ = env.step(a)
+        after = carry_index(env)
+        pickups += before < 0 <= after
+        drops += after < 0 <= before
+        rec["actions"][t] = a
+        rec["pos"][t] = env.agent.pos; rec["dir"][t] = env.agent.dir
+        rec["reward"][t] = r; rec["done"][t] = d; rec["step_count"][t] = env.step_count
+        rec["rng"][t] = rng_fingerprint(env)
+        boxes = [e for e in env.entities if e is not env.agent]
+        rec["boxes_pos"][t] = [b.pos for b in boxes]; rec["boxes_dir"][t] = [b.dir for b in boxes]
+        rec["carrying"][t] = after
+        rec["cam_pos"][t] = env.agent.cam_pos; rec["cam_dir"][t] = env.agent.cam_dir
+        if d:
+            env.reset()
+            post.append((t, snapshot_boxes(env)))
+    for k, v in rec.items():
+        out["traj/" + k] = v
+    out["post/step"] = np.array([t for t, _ in post], dtype=np.int64)
+    for k in (post[0][1] if post else {}):
+        out["post/" + k] = np.array([s[k] for _, s in post])
+    out["meta/max_episode_steps"] = np.array(env.max_episode_steps)
+    out["meta/max_forward_step"] = np.array(env.max_forward_step)
+    out["meta/n_actions"] = np.array(env.action_space.n)
+    out["meta/pickups_drops"] = np.array([pickups, drops])
+    return out
+
+
 def capture_gl(cls, kwargs, seed, dr, pose=None):
     """One reset() under the call recorder -> structured polygon list (renderer *input* parity).
     With pose = (x, z, dir) the agent is then moved there and render_obs() is recorded again: the
@@ -395,6 +503,18 @@ def main():
             g["posed"] = pose is not None
             with open(os.path.join(HERE, "glstream_%s_dr%d.json" % (task, dr)), "w") as fh:
                 json.dump(g, fh, separators=(",", ":"))
+    for task, (cls, kwargs) in CARRY_TASKS.items():
+        if only and not any(task.startswith(o) for o in only):
+            continue
+        blob = {}
+        for (seed, dr, policy, n) in CARRY_PLAN[task]:
+            case = run_carry_case(cls, kwargs, seed, dr, policy, n)
+            tag = "s%d_dr%d_%s/" % (seed, dr, policy)
+            for k, v in case.items():
+                blob[tag + k] = v
+            print(task, tag, "dones:", int(case["traj/done"].sum()), "rewards>0:", int((case["traj/reward"] > 0).sum()),
+                  "pickups/drops:", case["meta/pickups_drops"].tolist())
+        np.savez_compressed(os.path.join(HERE, "state_%s.npz" % task), **blob)
     if only:
         return
     np.savez_compressed(os.path.join(HERE, "math_kat.npz"), **math_kat())
