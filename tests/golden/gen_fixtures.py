@@ -380,26 +380,7 @@ def run_carry_case(cls, kwargs, seed, dr, policy, n_steps):
     return out
 
 
-def capture_gl(cls, kwargs, seed, dr, pose=None):
-    """One reset() under the call recorder -> structured polygon list (renderer *input* parity).
-    With pose = (x, z, dir) the agent is then moved there and render_obs() is recorded again: the
-    camera calls of that second frame replace the first frame's (the polygons are the same)."""
-    env = construct(cls, kwargs, dr)
-    env.seed(seed)
-    deps.GL_LOG.clear()
-    deps.GL_LOG_ENABLED[0] = True
-    env.reset()
-    deps.GL_LOG_ENABLED[0] = False
-    log = list(deps.GL_LOG)
-    deps.GL_LOG.clear()
-    if pose is not None:
-        env.agent.pos = np.array([pose[0], 0.0, pose[1]])
-        env.agent.dir = pose[2]
-        deps.GL_LOG_ENABLED[0] = True
-        env.render_obs()
-        deps.GL_LOG_ENABLED[0] = False
-        log += [(n, a) for (n, a) in deps.GL_LOG if n in ("gluPerspective", "gluLookAt")]
-        deps.GL_LOG.clear()
+def parse_gl_log(log):
     polys, lights, misc = [], {}, {}
     cur = {"color": None, "normal": None, "texc": None, "tex_on": False, "mode": None, "xform": []}
     poly = None
@@ -438,6 +419,73 @@ def capture_gl(cls, kwargs, seed, dr, pose=None):
             poly = None
         elif name in ("gluPerspective", "gluLookAt", "glClearColor", "glClearDepth"):
             misc[name] = [float(x) for x in args]
+    return polys, lights, misc
+
+
+def capture_gl_carry(cls, kwargs, seed, dr, policy="putnext", max_steps=400):
+    """A frame with a CARRIED box: reset() under the recorder gives the rooms and lights (they live in the display list
+    _render_static compiles, miniworld.py:1014-1057); the agent then fetches a box (unrecorded steps of the fixture
+    policy); one more render_obs() under the recorder gives the boxes - the carried one translated to its carry height
+    and turned with the agent - and the camera (Box.render entity.py:385-408, miniworld.py:1076-1083)."""
+    env = construct(cls, kwargs, dr)
+    env.seed(seed)
+    deps.GL_LOG.clear()
+    deps.GL_LOG_ENABLED[0] = True
+    env.reset()
+    deps.GL_LOG_ENABLED[0] = False
+    reset_log = list(deps.GL_LOG)
+    deps.GL_LOG.clear()
+    arng = np.random.default_rng(3000 + seed)
+    actions = []
+    for t in range(max_steps):
+        a = carry_action(env, policy, arng)
+        actions.append(a)
+        _, _, d, _ = env.step(a)
+        assert not d
+        if env.agent.carrying is not None and t > 5 and actions[-3:].count(int(env.actions.move_forward)) >= 2:
+            break
+    assert env.agent.carrying is not None
+    deps.GL_LOG_ENABLED[0] = True
+    env.render_obs()
+    deps.GL_LOG_ENABLED[0] = False
+    frame_log = list(deps.GL_LOG)
+    deps.GL_LOG.clear()
+    rooms, lights, _ = parse_gl_log(reset_log)
+    boxes, _, misc = parse_gl_log(frame_log)
+    nb = len(env.entities) - 1
+    assert len(boxes) == nb and all(not p["tex_on"] for p in boxes)
+    st = snapshot_boxes(env)
+    return {
+        "task": cls.__name__, "kwargs": kwargs, "seed": seed, "domain_rand": int(dr), "actions": [int(a) for a in actions],
+        "lights": lights, "misc": misc, "polys": rooms[:len(rooms) - nb] + boxes,
+        "room_tex": [[tex_basename(r.wall_tex), tex_basename(r.floor_tex), tex_basename(r.ceil_tex)] for r in env.rooms],
+        "agent_pos": st["agent_pos"].tolist(), "agent_dir": float(st["agent_dir"]), "cam": st["cam"].tolist(),
+        "boxes_pos": st["boxes_pos"].tolist(), "boxes_dir": st["boxes_dir"].tolist(), "boxes_color": st["boxes_color"].tolist(),
+        "boxes_size": st["boxes_size"].tolist(), "carrying": int(st["carrying"]),
+    }
+
+
+def capture_gl(cls, kwargs, seed, dr, pose=None):
+    """One reset() under the call recorder -> structured polygon list (renderer *input* parity).
+    With pose = (x, z, dir) the agent is then moved there and render_obs() is recorded again: the
+    camera calls of that second frame replace the first frame's (the polygons are the same)."""
+    env = construct(cls, kwargs, dr)
+    env.seed(seed)
+    deps.GL_LOG.clear()
+    deps.GL_LOG_ENABLED[0] = True
+    env.reset()
+    deps.GL_LOG_ENABLED[0] = False
+    log = list(deps.GL_LOG)
+    deps.GL_LOG.clear()
+    if pose is not None:
+        env.agent.pos = np.array([pose[0], 0.0, pose[1]])
+        env.agent.dir = pose[2]
+        deps.GL_LOG_ENABLED[0] = True
+        env.render_obs()
+        deps.GL_LOG_ENABLED[0] = False
+        log += [(n, a) for (n, a) in deps.GL_LOG if n in ("gluPerspective", "gluLookAt")]
+        deps.GL_LOG.clear()
+    polys, lights, misc = parse_gl_log(log)
     ents = snapshot_entities(env)
     return {
         "task": cls.__name__, "kwargs": kwargs, "seed": seed, "domain_rand": int(dr),
@@ -515,6 +563,10 @@ def main():
             print(task, tag, "dones:", int(case["traj/done"].sum()), "rewards>0:", int((case["traj/reward"] > 0).sum()),
                   "pickups/drops:", case["meta/pickups_drops"].tolist())
         np.savez_compressed(os.path.join(HERE, "state_%s.npz" % task), **blob)
+        for dr in (0, 1):
+            g = capture_gl_carry(cls, kwargs, 1, dr)
+            with open(os.path.join(HERE, "glstream_%s_dr%d.json" % (task, dr)), "w") as fh:
+                json.dump(g, fh, separators=(",", ":"))
     if only:
         return
     np.savez_compressed(os.path.join(HERE, "math_kat.npz"), **math_kat())

@@ -128,3 +128,40 @@ def test_mip_chain_spec(oracle_mod):
     img3 = rng.integers(0, 256, size=(3, 3, 3), dtype=np.uint8)
     lv3 = O.build_mip_chain(img3)
     assert len(lv3) == 2 and np.array_equal(lv3[1][0, 0, :3], (img3.astype(int).sum(axis=(0, 1)) + 4) // 9)
+
+
+@pytest.mark.parametrize("dr", [0, 1])
+def test_putnext_frame_with_a_carried_box(oracle_mod, dr):
+    """PutNext after the agent has picked a box up (tests/golden/glstream_PutNext_dr*.json: the reference's own GL calls
+    for that frame): six boxes of six colours and sizes, the carried one lifted to its carry height and turned with the
+    agent (miniworld.py:594-606,698-701; Box.render entity.py:385-408) - inputs equal, and the oracle's frame equals
+    the brute-force rendition of the captured polygons."""
+    import soup_renderer as SR
+    O = oracle_mod
+    g = load_stream("PutNext", dr)
+    env = O.OracleEnv("PutNext", seed=g["seed"], domain_rand=dr)
+    env.reset(render=False)
+    for a in g["actions"]:
+        env.step(int(a))
+    s = env.state()
+    assert s.carrying == g["carrying"] >= 0 and s.n_boxes == 6
+    assert np.array_equal(np.array(s.boxes_pos), np.array(g["boxes_pos"])) and list(s.boxes_dir) == g["boxes_dir"]
+    assert np.array(s.boxes_pos)[s.carrying, 1] > 0.3
+    polys = g["polys"]
+    assert len(polys) == 3 + 6
+    for b, box in enumerate(polys[3:]):   # entity order = COLOR_NAMES order: blue green grey purple red yellow
+        assert not box["tex_on"] and box["color"] == list(s.boxes_color[b]) == g["boxes_color"][b]
+        assert box["xform"][0] == ["translate"] + list(s.boxes_pos[b])
+        assert box["xform"][1] == ["rotate", s.boxes_dir[b] * (180 / np.pi), 0.0, 1.0, 0.0]
+        v = np.array(box["verts"])
+        sz = s.boxes_size[b]
+        assert v[:, 0].min() == -sz / 2 and v[:, 0].max() == sz / 2 and v[:, 1].min() == 0 and v[:, 1].max() == sz
+    la = np.array(g["misc"]["gluLookAt"])
+    assert np.abs(la[0:3] - np.array(s.cam_pos)).max() <= 4.5e-16
+    tex = O.load_textures()
+    a = env.render_obs()
+    b = SR.render_stream(g, {O.TEX_FILES[i]: tex[i][2] for i in tex})
+    d = np.abs(a.astype(int) - b.astype(int))
+    assert (d.max(axis=2) > 1).mean() <= 2e-3, (int(d.max()), int((d.max(axis=2) > 1).sum()))
+    px = a.reshape(-1, 3).astype(int)
+    assert ((px[:, 0] > px[:, 1] + 60) & (px[:, 0] > px[:, 2] + 60)).mean() > 0.05   # the carried red box fills part of the view
