@@ -16,7 +16,7 @@ ABI_VERSION = 4
 MT_WORDS = 625
 
 TASK_IDS = {"Hallway": 0, "OneRoom": 1, "FourRooms": 2, "Maze": 3, "TMaze": 4, "TMazeTwoBox": 5,
-            "SimToRealGoTo": 6, "SimToRealPush": 7}
+            "SimToRealGoTo": 6, "SimToRealPush": 7, "PutNext": 8}
 LAYOUT_HWC, LAYOUT_CWH = 0, 1
 
 
@@ -46,7 +46,7 @@ class MwbState(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "agent_pos", "agent_dir", "box_pos", "box_dir", "box_color", "box_size", "cam", "sky_color", "light_pos",
         "light_color", "light_ambient", "step_count", "rng_pos", "rng_keysum", "n_rooms", "n_segs",
-        "goal_idx", "episode_count", "task_step_count", "goal_dist", "rng_state")]
+        "goal_idx", "episode_count", "task_step_count", "goal_dist", "rng_state", "carrying")]
 
 
 EXPORTS = [

@@ -51,6 +51,8 @@ ENV_SPECS = {
     # the sim-to-real rinks: own parameter table, domain randomisation forced on (simtorealgoto.py:27-33)
     "MiniWorld-SimToRealGoTo-v0": ("SimToRealGoTo", [], 0, sim_to_real_params, True),
     "MiniWorld-SimToRealPush-v0": ("SimToRealPush", [], 0, lambda: sim_to_real_params(push=True), True),
+    # several boxes + the carry actions, envs/putnext.py
+    "MiniWorld-PutNext-v0": ("PutNext", [12], 0, None, None),
 }
 
 
@@ -142,9 +144,12 @@ class BatchedMiniWorld:
         # the six small outputs above are parts of one allocation: a host-side consumer copies `pack` once per step
         self.pack = as_t(out.pack, (out.pack_bytes,), "|u1")
         self.pack_offsets = {k: int(getattr(out, k)) - int(out.pack) for k in ("reward64", "goal_pos", "reward", "feature", "ep_steps", "done")}
-        self.n_boxes = 2 if task in ("TMazeTwoBox", "SimToRealPush") else 1
+        self.n_boxes = int(self.L.mwb_num_boxes(self.h))   # 1; 2 (TMazeTwoBox, SimToRealPush); 6 (PutNext)
         self.agent_radius = 0.11 if task.startswith("SimToReal") else 0.4
-        self.n_actions = 4 if task == "SimToRealPush" else 3   # Discrete(move_back + 1), simtorealpush.py:37
+        # action_space: Discrete(move_forward + 1) in the navigation tasks (e.g. hallway.py:23), Discrete(move_back + 1)
+        # in SimToRealPush (simtorealpush.py:37), the base class' Discrete(len(Actions)) = 8 where the task does not
+        # narrow it (PutNext: miniworld.py:470)
+        self.n_actions = 4 if task == "SimToRealPush" else 8 if task == "PutNext" else 3
         self.has_features = task == "TMazeTwoBox" and ta[0] != 0
         self.has_goal_pos = task in ("TMaze", "TMazeTwoBox")
         self.max_episode_steps = self._max_steps(task, ta, max_episode_steps)
@@ -156,7 +161,7 @@ class BatchedMiniWorld:
         if mes:
             return int(mes)
         return {"Hallway": 250, "OneRoom": 180, "FourRooms": 250, "TMaze": 280, "TMazeTwoBox": 280,
-                "SimToRealGoTo": 100, "SimToRealPush": 150}.get(task) or int(ta[0] or 8) * int(ta[1] or 8) * 24
+                "SimToRealGoTo": 100, "SimToRealPush": 150, "PutNext": 250}.get(task) or int(ta[0] or 8) * int(ta[1] or 8) * 24
 
     def _load_textures(self):
         from PIL import Image
@@ -229,7 +234,8 @@ class BatchedMiniWorld:
                   "light_color": (3,), "light_ambient": (3,), "goal_dist": ()}
     _STATE_BOX = {"box_pos": (3,), "box_dir": (), "box_color": (3,), "box_size": ()}   # [count][B] + shape
     _STATE_INT = {"step_count": np.int32, "rng_pos": np.int32, "rng_keysum": np.uint32, "n_rooms": np.int32,
-                  "n_segs": np.int32, "goal_idx": np.int32, "episode_count": np.int64, "task_step_count": np.int64}
+                  "n_segs": np.int32, "goal_idx": np.int32, "episode_count": np.int64, "task_step_count": np.int64,
+                  "carrying": np.int32}
 
     def get_state(self, first=0, count=None, rng_state=False):
         """Host snapshot of the env range (mwb_get_state).  Box fields come as "boxes_pos" [count, B, 3],
@@ -256,7 +262,7 @@ class BatchedMiniWorld:
     def set_state(self, first, **fields):
         """Overwrite simulator state of envs first .. first+count-1 (mwb_set_state).  Keys as returned by
         get_state(): agent_pos [count,3], agent_dir, boxes_pos [count,B,3], boxes_dir, boxes_color, boxes_size,
-        cam, sky_color, light_*, step_count, goal_idx, episode_count, task_step_count, goal_dist,
+        cam, sky_color, light_*, step_count, goal_idx, episode_count, task_step_count, goal_dist, carrying,
         rng_state [count,625]."""
         st = _lib.MwbState()
         keep, count = [], None
@@ -268,7 +274,7 @@ class BatchedMiniWorld:
                 shape, dt = (-1,) + self._STATE_F64[name], np.float64
             elif name == "rng_state":
                 shape, dt = (-1, _lib.MT_WORDS), np.uint32
-            elif name in ("step_count", "goal_idx", "episode_count", "task_step_count"):
+            elif name in ("step_count", "goal_idx", "episode_count", "task_step_count", "carrying"):
                 shape, dt = (-1,), self._STATE_INT[name]
             else:
                 raise KeyError("set_state: %r is not a writable state field" % k)

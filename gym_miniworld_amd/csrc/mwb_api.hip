@@ -193,7 +193,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     if (!cfg || !out) return set_err(MWB_EINVAL, "mwb_create: null argument");
     if (cfg->abi_version != MWB_ABI_VERSION) return set_err(MWB_EINVAL, "mwb_create: abi_version mismatch");
     if (cfg->num_envs <= 0) return set_err(MWB_EINVAL, "mwb_create: num_envs must be > 0");
-    if (cfg->task < 0 || cfg->task > MWB_TASK_SIM2REAL_PUSH) return set_err(MWB_EINVAL, "mwb_create: unknown task");
+    if (cfg->task < 0 || cfg->task > MWB_TASK_PUTNEXT) return set_err(MWB_EINVAL, "mwb_create: unknown task");
     if (cfg->obs_width <= 0 || cfg->obs_height <= 0 || cfg->obs_width > 1024 || cfg->obs_height > 1024)
         return set_err(MWB_EINVAL, "mwb_create: bad observation size");
     if (cfg->layout != MWB_LAYOUT_HWC && cfg->layout != MWB_LAYOUT_CWH) return set_err(MWB_EINVAL, "mwb_create: bad layout");
@@ -211,9 +211,10 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     d.want_depth = cfg->want_depth ? 1 : 0; d.layout = cfg->layout; d.domain_rand = cfg->domain_rand ? 1 : 0;
     d.auto_reset = cfg->no_auto_reset ? 0 : 1;
     { const char *dbg = getenv("MWB_DEBUG"); d.debug_flags = dbg ? atoi(dbg) : 0; }
-    static const double dflt[8][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    static const double dflt[9][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}, {12, 0, 0, 0}};
     const bool sim2real = cfg->task == MWB_TASK_SIM2REAL_GOTO || cfg->task == MWB_TASK_SIM2REAL_PUSH;
-    d.n_boxes = (cfg->task == MWB_TASK_TMAZE_TWOBOX || cfg->task == MWB_TASK_SIM2REAL_PUSH) ? 2 : 1;
+    d.n_boxes = (cfg->task == MWB_TASK_TMAZE_TWOBOX || cfg->task == MWB_TASK_SIM2REAL_PUSH) ? 2 : cfg->task == MWB_TASK_PUTNEXT ? 6 : 1;
+    d.frame_words = MWB_FRAME_WORDS_FOR(d.n_boxes);
     d.n_tex = sim2real ? MWB_NUM_TEXTURES : 7;
     {   // the last ~0.6 round of resident workgroups (5 per CU x 256 CUs = 1280) of a bulk render launch drains in
         // half-frame units: measured best between 640 and 960 envs (+4 % at 8192 Maze envs); MWB_SPLIT overrides
@@ -232,6 +233,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
         else if (d.task == MWB_TASK_TMAZE || d.task == MWB_TASK_TMAZE_TWOBOX) mes = 280;   // tmaze.py:20,142
         else if (d.task == MWB_TASK_SIM2REAL_GOTO) mes = 100;   // simtorealgoto.py:30
         else if (d.task == MWB_TASK_SIM2REAL_PUSH) mes = 150;   // simtorealpush.py:29
+        else if (d.task == MWB_TASK_PUTNEXT) mes = 250;   // putnext.py:16
         else mes = (int)d.task_args[0] * (int)d.task_args[1] * 24;
     }
     d.max_episode_steps = mes;
@@ -246,6 +248,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
         if (d.task_args[3] < 0 || d.task_args[3] > 9e15) { delete h; return set_err(MWB_EINVAL, "TMaze: bad sub_task_length"); }
         d.R_max = 2; d.S_max = 8;
     } else if (sim2real) { d.R_max = 1; d.S_max = 4; }
+    else if (d.task == MWB_TASK_PUTNEXT) { if (!(d.task_args[0] >= 2)) { delete h; return set_err(MWB_EINVAL, "PutNext: size >= 2"); } d.R_max = 1; d.S_max = 4; }
     else {
         int rows = (int)d.task_args[0], cols = (int)d.task_args[1];
         if (rows < 1 || cols < 1 || rows * cols > 4096) { delete h; return set_err(MWB_EINVAL, "Maze: bad num_rows / num_cols"); }
@@ -255,10 +258,10 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     size_t N = (size_t)d.N;
     int rc = MWB_OK;
 #define A(ptr, n) if (rc == MWB_OK) rc = dev_alloc(h, &(ptr), (n))
-    A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N * d.n_boxes); A(d.box_z, N * d.n_boxes); A(d.box_dir, N * d.n_boxes);
+    A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N * d.n_boxes); A(d.box_z, N * d.n_boxes); A(d.box_y, N * d.n_boxes); A(d.box_dir, N * d.n_boxes); A(d.carrying, N);
     A(d.box_color, N * d.n_boxes * 3); A(d.box_size, N * d.n_boxes); A(d.goal_dist, N); A(d.episode_count, N); A(d.task_step_count, N); A(d.goal_idx, N); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
     A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.reset_set, N); A(d.reset_list, N); A(d.reset_count, (size_t)1);
-    A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * MWB_ROOM_WORDS); A(d.segs, N * d.S_max * 4); A(d.frame, N * MWB_FRAME_WORDS);
+    A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * MWB_ROOM_WORDS); A(d.segs, N * d.S_max * 4); A(d.frame, N * d.frame_words);
     A(d.obs, N * d.W * d.H * 3);
     if (d.want_depth) { A(d.depth, N * d.W * d.H); }
     {   // the small per-step outputs share one allocation (one D2H copy for a host-side consumer); 16-byte aligned parts
@@ -299,6 +302,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
             return set_err(MWB_EHIP, "mwb_create: hipMemcpy failed");
         }
     }
+    if (hipMemset(d.carrying, 0xFF, N * sizeof(int32_t)) != hipSuccess) { mwb_destroy(h); return set_err(MWB_EHIP, "mwb_create: hipMemset failed"); }   // -1: nothing carried
     d.tex_desc = h->tex_desc_dev;
     h->texels_dev = nullptr; d.texels = nullptr;
     h->seeded = false; h->textures_dirty = false; h->have_textures = false;
@@ -646,16 +650,18 @@ extern "C" int mwb_get_state(mwb_handle *h, int first, int count, mwb_state *o) 
         for (int i = 0; i < count; i++) { o->agent_pos[i * 3] = a[i]; o->agent_pos[i * 3 + 1] = 0.0; o->agent_pos[i * 3 + 2] = b[i]; }
     }
     if (o->box_pos) {
-        std::vector<double> bx((size_t)count * B), bz((size_t)count * B);
+        std::vector<double> bx((size_t)count * B), bz((size_t)count * B), by((size_t)count * B);
         if ((rc = fetch_boxes(bx.data(), d.box_x, N, B, first, count, 1))) return rc;
         if ((rc = fetch_boxes(bz.data(), d.box_z, N, B, first, count, 1))) return rc;
-        for (size_t i = 0; i < (size_t)count * B; i++) { o->box_pos[i * 3] = bx[i]; o->box_pos[i * 3 + 1] = 0.0; o->box_pos[i * 3 + 2] = bz[i]; }
+        if ((rc = fetch_boxes(by.data(), d.box_y, N, B, first, count, 1))) return rc;
+        for (size_t i = 0; i < (size_t)count * B; i++) { o->box_pos[i * 3] = bx[i]; o->box_pos[i * 3 + 1] = by[i]; o->box_pos[i * 3 + 2] = bz[i]; }
     }
     if ((rc = fetch(o->agent_dir, d.agent_dir, first, count, 1))) return rc;
     if ((rc = fetch_boxes(o->box_dir, d.box_dir, N, B, first, count, 1))) return rc;
     if ((rc = fetch_boxes(o->box_color, d.box_color, N, B, first, count, 3))) return rc;
     if ((rc = fetch_boxes(o->box_size, d.box_size, N, B, first, count, 1))) return rc;
     if ((rc = fetch(o->goal_dist, d.goal_dist, first, count, 1))) return rc;
+    if ((rc = fetch(o->carrying, d.carrying, first, count, 1))) return rc;
     if ((rc = fetch(o->goal_idx, d.goal_idx, first, count, 1))) return rc;
     if ((rc = fetch(o->episode_count, d.episode_count, first, count, 1))) return rc;
     if ((rc = fetch(o->task_step_count, d.task_step_count, first, count, 1))) return rc;
@@ -688,6 +694,9 @@ extern "C" int mwb_set_state(mwb_handle *h, int first, int count, const mwb_stat
     if (in->goal_idx)
         for (int i = 0; i < count; i++)
             if (in->goal_idx[i] < 0 || in->goal_idx[i] > 1) return set_err(MWB_EINVAL, "mwb_set_state: goal_idx must be 0 or 1");
+    if (in->carrying)
+        for (int i = 0; i < count; i++)
+            if (in->carrying[i] < -1 || in->carrying[i] >= h->dev.n_boxes) return set_err(MWB_EINVAL, "mwb_set_state: carrying must be -1 or a box index");
     if (in->rng_state)
         for (int i = 0; i < count; i++)
             if (in->rng_state[(size_t)i * MWB_MT_WORDS + 624] > 624u) return set_err(MWB_EINVAL, "mwb_set_state: MT19937 position must be 0..624");
@@ -703,9 +712,10 @@ extern "C" int mwb_set_state(mwb_handle *h, int first, int count, const mwb_stat
         if ((rc = store(b.data(), d.agent_z, first, count, 1))) return rc;
     }
     if (in->box_pos) {
-        std::vector<double> bx((size_t)count * B), bz((size_t)count * B);
-        for (size_t i = 0; i < (size_t)count * B; i++) { bx[i] = in->box_pos[i * 3]; bz[i] = in->box_pos[i * 3 + 2]; }
+        std::vector<double> bx((size_t)count * B), bz((size_t)count * B), by((size_t)count * B);
+        for (size_t i = 0; i < (size_t)count * B; i++) { bx[i] = in->box_pos[i * 3]; by[i] = in->box_pos[i * 3 + 1]; bz[i] = in->box_pos[i * 3 + 2]; }
         if ((rc = store_boxes(bx.data(), d.box_x, N, B, first, count, 1))) return rc;
+        if ((rc = store_boxes(by.data(), d.box_y, N, B, first, count, 1))) return rc;
         if ((rc = store_boxes(bz.data(), d.box_z, N, B, first, count, 1))) return rc;
     }
     if ((rc = store(in->agent_dir, d.agent_dir, first, count, 1))) return rc;
@@ -713,6 +723,7 @@ extern "C" int mwb_set_state(mwb_handle *h, int first, int count, const mwb_stat
     if ((rc = store_boxes(in->box_color, d.box_color, N, B, first, count, 3))) return rc;
     if ((rc = store_boxes(in->box_size, d.box_size, N, B, first, count, 1))) return rc;
     if ((rc = store(in->goal_dist, d.goal_dist, first, count, 1))) return rc;
+    if ((rc = store(in->carrying, d.carrying, first, count, 1))) return rc;
     if ((rc = store(in->goal_idx, d.goal_idx, first, count, 1))) return rc;
     if ((rc = store(in->episode_count, d.episode_count, first, count, 1))) return rc;
     if ((rc = store(in->task_step_count, d.task_step_count, first, count, 1))) return rc;

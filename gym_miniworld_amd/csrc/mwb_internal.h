@@ -6,7 +6,7 @@
 //   rooms: per-env room table, N x R_max x MWB_ROOM_WORDS (24) f32 words (render kernel stages it in LDS)
 //   segs : collision segments, S_max x 4 x N f64 (a.x a.z b.x b.z; segment-major, env-minor so that
 //          one-env-per-lane reads coalesce), reference order per env
-//   frame: per-env render constants (camera basis, lit colours, box frame), N x FRAME_WORDS f32
+//   frame: per-env render constants (camera basis, lit colours, box frames), N x frame_words f32
 //   tex  : RGBA8 mip pyramids of the 7 textures, shared by all envs (L2 / Infinity Cache resident)
 //   out  : obs u8 [N,H,W,3] or [N,3,W,H], depth f32 [N,H,W], reward f32/f64 [N], done u8 [N]
 #pragma once
@@ -18,8 +18,8 @@
 #define MWB_MT_WORDS 625   // 624 key words + pos
 #define MWB_MAX_TEX MWB_NUM_TEXTURES
 #define MWB_MAX_LEVELS 12
-#define MWB_MAX_BOXES 2
-#define MWB_FRAME_WORDS 104
+#define MWB_MAX_BOXES 6
+// frame constants: 36 fixed words, then one block of FC_BOX_STRIDE words per box; d.frame_words = that, rounded up to 4
 
 // room table: 24 f32 words (96 B) per room; ints stored as bit patterns
 //   0-3  min_x max_x min_z max_z
@@ -55,20 +55,21 @@
 #define FC_LIT_FLOOR 17
 #define FC_LIT_CEIL 20
 #define FC_LIT_WALL 23   // 4 x 3
+#define FC_BOX_IN_VIEW 35      // != 0 if some box's footprint-inflated sphere can meet the view cone
 // per-box block of FC_BOX_STRIDE words starting at FC_LIT_BOX; box b at + b * FC_BOX_STRIDE
 #define FC_BOX_STRIDE 34
-#define FC_LIT_BOX 35    // 6 x 3
-#define FC_BOX_POS 53
-#define FC_BOX_C 56
-#define FC_BOX_S 57
-#define FC_BOX_HX 58
-#define FC_BOX_HZ 59
-#define FC_BOX_SY 60
-#define FC_BOX_LO 61     // ray origin in box-local axes (3)
-#define FC_CULL_OC 64    // box bounding-sphere centre minus eye (3)
-#define FC_CULL_CC 67    // |oc|^2 - R^2
-#define FC_CULL_CC_PIXEL 68   // same with R grown by a pixel footprint
-#define FC_BOX_IN_VIEW 103     // (last word of the frame constants) != 0 if some box's footprint-inflated sphere can meet the view cone
+#define FC_LIT_BOX 36    // 6 x 3
+#define FC_BOX_POS 54
+#define FC_BOX_C 57
+#define FC_BOX_S 58
+#define FC_BOX_HX 59
+#define FC_BOX_HZ 60
+#define FC_BOX_SY 61
+#define FC_BOX_LO 62     // ray origin in box-local axes (3)
+#define FC_CULL_OC 65    // box bounding-sphere centre minus eye (3)
+#define FC_CULL_CC 68    // |oc|^2 - R^2
+#define FC_CULL_CC_PIXEL 69   // same with R grown by a pixel footprint
+#define MWB_FRAME_WORDS_FOR(n_boxes) ((36 + FC_BOX_STRIDE * (n_boxes) + 3) & ~3)
 
 struct MwbTexDesc {
     int w, h, n_levels;
@@ -83,7 +84,8 @@ struct MwbParam { double def[3], lo[3], hi[3]; };
 struct MwbDev {
     int N, task, W, H, want_depth, layout, domain_rand, max_episode_steps;
     int R_max, S_max, auto_reset;
-    int n_boxes;       // 1, or 2 for MWB_TASK_TMAZE_TWOBOX (box 0 red, box 1 blue) and SIM2REAL_PUSH (red, yellow)
+    int n_boxes;       // 1; 2 for MWB_TASK_TMAZE_TWOBOX (box 0 red, box 1 blue) and SIM2REAL_PUSH (red, yellow); 6 for PUTNEXT (COLOR_NAMES order)
+    int frame_words;   // MWB_FRAME_WORDS_FOR(n_boxes)
     int n_tex;         // leading texture slots the task can draw (7, or MWB_NUM_TEXTURES for the sim-to-real rinks)
     int split_envs;    // the last split_envs envs of a bulk render launch are rendered by two half-frame workgroups each
     int no_ceiling;    // the task's rooms have no ceiling (sim-to-real rinks): selects the NOCEIL render kernels
@@ -94,6 +96,8 @@ struct MwbDev {
     // sim state (f64 SoA)
     double *agent_x, *agent_z, *agent_dir;
     double *box_x, *box_z, *box_dir;   // [n_boxes][N]
+    double *box_y;          // [n_boxes][N] 0 on the floor, the carry height while carried (miniworld.py:603-604)
+    int32_t *carrying;      // [N] agent.carrying as a box index, or -1 (miniworld.py:682-702)
     double *box_color;      // [n_boxes][N][3]
     double *box_size;       // [n_boxes][N] Box edge length (0.8 unless the task draws it per episode)
     double *goal_dist;      // [N] SimToRealPush
@@ -109,7 +113,7 @@ struct MwbDev {
     uint32_t *rng;          // [N][625]
     float *rooms;           // [N][R_max][MWB_ROOM_WORDS]
     double *segs;           // [S_max][4][N]
-    float *frame;           // [N][MWB_FRAME_WORDS]
+    float *frame;           // [N][frame_words]
     const uint32_t *texels;
     const MwbTexDesc *tex_desc;   // [MWB_MAX_TEX] in device memory
     // outputs

@@ -134,8 +134,11 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
     const bool live = in_range && !dummy;
     int sc = 0, a = -1;
     double ax = 0, az = 0, adir = 0, nx = 0, nz = 0, turn_step = 0;
-    const int NB = d.n_boxes;   // 1, or 2 in the two-box T-maze (entity order: red box, blue box, agent)
-    double bx[MWB_MAX_BOXES] = {0, 0}, bz[MWB_MAX_BOXES] = {0, 0}, brad[MWB_MAX_BOXES] = {0, 0};
+    const int NB = d.n_boxes;   // entity order: the boxes (red; red, blue / yellow; PutNext's six), then the agent
+    double bx[MWB_MAX_BOXES], bz[MWB_MAX_BOXES], by[MWB_MAX_BOXES], brad[MWB_MAX_BOXES], bsz[MWB_MAX_BOXES];
+#pragma unroll
+    for (int b = 0; b < MWB_MAX_BOXES; b++) { bx[b] = 0; bz[b] = 0; by[b] = 0; brad[b] = 0; bsz[b] = 0; }
+    int carried = -1;   // agent.carrying as a box index
     const double arad = d.agent_radius;
     if (blockIdx.x == 0 && threadIdx.x == 0 && d.order_state[1]) {   // adopt the dispatch order completed beside the last pass
         d.order_state[0] ^= 1; d.order_state[1] = 0;                  // (nothing reads the maps while step_kernel runs)
@@ -150,8 +153,13 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
         if (live) {
             a = actions[e];
             ax = d.agent_x[e]; az = d.agent_z[e]; adir = d.agent_dir[e];
-            bx[0] = d.box_x[e]; bz[0] = d.box_z[e]; brad[0] = box_radius(d.box_size[e]);
-            if (NB > 1) { bx[1] = d.box_x[(size_t)d.N + e]; bz[1] = d.box_z[(size_t)d.N + e]; brad[1] = box_radius(d.box_size[(size_t)d.N + e]); }
+#pragma unroll
+            for (int b = 0; b < MWB_MAX_BOXES; b++)
+                if (b < NB) {
+                    const size_t be = (size_t)b * d.N + e;
+                    bx[b] = d.box_x[be]; bz[b] = d.box_z[be]; by[b] = d.box_y[be]; bsz[b] = d.box_size[be]; brad[b] = box_radius(bsz[b]);
+                }
+            carried = d.carrying[e];
             MtSerial g;
             const bool use_rng = d.domain_rand || d.task == MWB_TASK_SIM2REAL_PUSH;
             if (use_rng) g.load(d.rng + (size_t)e * MWB_MT_WORDS);
@@ -244,30 +252,114 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
     }
     __syncthreads();
     if (part != 0 || !live) return;
+    // ---- the rest of MiniWorldEnv.step for this env, sequential (wave 0, lane = env) -------------------------------
+    const double max_fwd = d.params[MWB_P_FORWARD_STEP].hi[0];   // self.max_forward_step, miniworld.py:569
+    // register-resident lookups by a run-time box index (select chains: no indexed scratch arrays)
+    auto pick = [&](const double (&v)[MWB_MAX_BOXES], int i) {
+        double r_ = v[0];
+#pragma unroll
+        for (int b = 1; b < MWB_MAX_BOXES; b++) r_ = (i == b) ? v[b] : r_;
+        return r_;
+    };
+    // MiniWorldEnv.intersect(ent, pos, radius), miniworld.py:933-959, for an entity other than the moving agent's own
+    // wall test: walls (all segments, serial: only the carried-entity and pickup tests come here), then the entities
+    // in list order except `self_idx` (a box index, or NB for the agent).  Returns 0 none, 1 wall, 2 + k entity k.
+    auto intersect_serial = [&](int self_idx, double px, double pz, double radius, bool test_walls) {
+        if (test_walls) {
+            const int ns = d.n_segs[e];
+            for (int i = 0; i < ns; i++) {
+                double q[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) q[c] = d.segs[(size_t)(i * 4 + c) * d.N + e];
+                if (seg_hit(q, px, pz, radius)) return 1;
+            }
+        }
+        int res = 0;
+#pragma unroll
+        for (int b = MWB_MAX_BOXES - 1; b >= 0; b--) {   // descending, so that the lowest index wins
+            const double ddx = bx[b] - px, ddz = bz[b] - pz;
+            const bool h = b < NB && b != self_idx && sqrt(ddx * ddx + 0.0 + ddz * ddz) < radius + brad[b];
+            res = h ? 2 + b : res;
+        }
+        if (!res && self_idx != NB) {   // the agent is the last entity of the list
+            const double ddx = ax - px, ddz = az - pz;
+            if (sqrt(ddx * ddx + 0.0 + ddz * ddz) < radius + arad) res = 2 + NB;
+        }
+        return res;
+    };
+    // MiniWorldEnv._get_carry_pos(agent_pos, ent), miniworld.py:594-606, for the carried box
+    auto carry_pos = [&](double agx, double agz, double dir, double &cx, double &cy, double &cz) {
+        const double er = pick(brad, carried);
+        const double dist = (arad + er) + max_fwd;
+        const double c = ref_cos(dir), s_ = ref_sin(dir);
+        cx = agx + (c * 1.05) * dist; cz = agz + ((-s_) * 1.05) * dist;
+        const double eh = pick(bsz, carried);
+        double yp = (d.cam[e * 4 + 0] - eh) - 0.3;   // max(self.agent.cam_height - ent.height - 0.3, 0)
+        yp = yp > 0 ? yp : 0;
+        cy = (0.0 + (0.0 * 1.05) * dist) + 1.0 * yp;
+        cx = cx + 0.0 * yp; cz = cz + 0.0 * yp;   // pos + Y_VEC * y_pos
+    };
+    auto store_carried = [&](double cx, double cy, double cz, bool set_dir) {
+#pragma unroll
+        for (int b = 0; b < MWB_MAX_BOXES; b++)
+            if (b == carried) {
+                bx[b] = cx; by[b] = cy; bz[b] = cz;
+                const size_t be = (size_t)b * d.N + e;
+                d.box_x[be] = cx; d.box_y[be] = cy; d.box_z[be] = cz;
+                if (set_dir) d.box_dir[be] = adir;
+            }
+    };
     if (a == 2 || a == 3) {
-        bool hit = s_hit[lane] != 0;
-        for (int b = 0; b < NB && !hit; b++) {   // entity test, miniworld.py:946-957 (boxes are the only other entities)
-            double ddx = bx[b] - nx, ddz = bz[b] - nz;
-            double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
-            hit = dist < arad + brad[b];
+        // intersect(self.agent, next_pos, radius): the parallel wall test above, then the boxes in list order
+        bool hit = s_hit[lane] != 0 || intersect_serial(NB, nx, nz, arad, false) != 0;
+        if (!hit && carried >= 0) {   // the carried entity must fit where it would go (miniworld.py:622-629)
+            double cx, cy, cz;
+            carry_pos(nx, nz, adir, cx, cy, cz);
+            if (intersect_serial(carried, cx, cz, pick(brad, carried), true)) hit = true;
+            else store_carried(cx, cy, cz, false);
         }
         if (!hit) { ax = nx; az = nz; d.agent_x[e] = ax; d.agent_z[e] = az; }
     } else if (a == 0 || a == 1) {   // turn_agent, miniworld.py:635-656
         double ta = (a == 0) ? turn_step : -turn_step;
         ta *= (3.141592653589793 / 180);
+        const double orig = adir;
         adir += ta;
+        if (carried >= 0) {
+            double cx, cy, cz;
+            carry_pos(ax, az, adir, cx, cy, cz);
+            if (intersect_serial(carried, cx, cz, pick(brad, carried), true)) adir = orig;
+            else store_carried(cx, cy, cz, true);
+        }
         d.agent_dir[e] = adir;
+    } else if (a == 4) {   // pickup, miniworld.py:682-689: the first entity within 1.2 r of a point 1.5 r ahead of the agent
+        const double c = ref_cos(adir), s_ = ref_sin(adir);
+        const double tx = ax + (c * 1.5) * arad, tz = az + ((-s_) * 1.5) * arad;
+        const int hit = intersect_serial(NB, tx, tz, 1.2 * arad, true);
+        if (carried < 0 && hit >= 2) carried = hit - 2;   // a Box is not static (entity.py:40-46)
+    } else if (a == 5) {   // drop, miniworld.py:692-695
+        if (carried >= 0) {
+#pragma unroll
+            for (int b = 0; b < MWB_MAX_BOXES; b++)
+                if (b == carried) { by[b] = 0.0; d.box_y[(size_t)b * d.N + e] = 0.0; }
+            carried = -1;
+        }
     }
+    if (carried >= 0) {   // miniworld.py:698-701: the carried entity follows the agent
+        double cx, cy, cz;
+        carry_pos(ax, az, adir, cx, cy, cz);
+        store_carried(cx, cy, cz, true);
+    }
+    d.carrying[e] = carried;
     double r = 0.0;
     int done = 0;
     if (sc >= d.max_episode_steps) { done = 1; r = 0.0; }   // miniworld.py:708-711
     {   // near(box), miniworld.py:961-971, then the task rule (e.g. envs/maze.py:106-113)
-        const double max_forward_step = d.params[MWB_P_FORWARD_STEP].hi[0];   // miniworld.py:569
+        const double max_forward_step = max_fwd;
         bool near[MWB_MAX_BOXES];
 #pragma unroll
-        for (int b = 0; b < MWB_MAX_BOXES; b++) {
-            double ddx = bx[b] - ax, ddz = bz[b] - az;
-            double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
+        for (int b = 0; b < MWB_MAX_BOXES; b++) {   // np.linalg.norm(ent0.pos - ent1.pos): a carried box is off the floor
+            double ddx = bx[b] - ax, ddy = by[b] - 0.0, ddz = bz[b] - az;
+            double dist = sqrt((ddx * ddx + ddy * ddy) + ddz * ddz);
             near[b] = b < NB && dist < brad[b] + arad + 1.1 * max_forward_step;
         }
         const double rw = 1.0 - 0.2 * ((double)sc / d.max_episode_steps);   // _reward, miniworld.py:1012
@@ -284,6 +376,11 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
         } else if (d.task == MWB_TASK_SIM2REAL_PUSH) {   // simtorealpush.py:129-133: the boxes are close enough
             const double ddx = bx[0] - bx[1], ddz = bz[0] - bz[1];
             if (sqrt((ddx * ddx + 0.0) + ddz * ddz) < d.goal_dist[e]) { r = 1.0; done = 1; }
+        } else if (d.task == MWB_TASK_PUTNEXT) {   // putnext.py:45-53: red (box 4) next to yellow (box 5), nothing carried
+            if (carried < 0) {
+                const double ddx = bx[4] - bx[5], ddy = by[4] - by[5], ddz = bz[4] - bz[5];
+                if (sqrt((ddx * ddx + ddy * ddy) + ddz * ddz) < brad[4] + brad[5] + 1.1 * max_forward_step) { r += rw; done = 1; }
+            }
         } else {
             if (near[0]) { r += rw; done = 1; }
             if (d.task == MWB_TASK_TMAZE) { d.goal_pos[e * 3] = bx[0]; d.goal_pos[e * 3 + 1] = 0.0; d.goal_pos[e * 3 + 2] = bz[0]; }
@@ -543,8 +640,9 @@ struct WorldGen {
         bool has_dir = false, has_min_x = false, has_max_x = false, has_min_z = false, has_max_z = false;
         double dir = 0, min_x = 0, max_x = 0, min_z = 0, max_z = 0;
         int n_others = 0;
-        double other_x[MWB_MAX_BOXES] = {0, 0}, other_z[MWB_MAX_BOXES] = {0, 0}, other_radius = 0;
+        double other_x[MWB_MAX_BOXES] = {0, 0, 0, 0, 0, 0}, other_z[MWB_MAX_BOXES] = {0, 0, 0, 0, 0, 0}, other_radius = 0;
         double other_radius2 = -1;   // radius of the second other entity when it differs (sim-to-real boxes)
+        double other_r[MWB_MAX_BOXES] = {-1, -1, -1, -1, -1, -1};   // per-entity radii where given (>= 0), else the two above
     };
     __device__ void place_entity(double radius, bool has_other, double other_x, double other_z, double other_radius,
                                  bool has_dir, double dir_in, bool has_min_x, double min_x, bool has_max_x, double max_x,
@@ -586,7 +684,8 @@ struct WorldGen {
             for (int k = 0; k < opt.n_others; k++) {
                 double ddx = opt.other_x[k] - px, ddz = opt.other_z[k] - pz;
                 double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
-                if (dist < radius + ((k == 1 && opt.other_radius2 >= 0) ? opt.other_radius2 : opt.other_radius)) blocked = true;
+                const double orad = opt.other_r[k] >= 0 ? opt.other_r[k] : ((k == 1 && opt.other_radius2 >= 0) ? opt.other_radius2 : opt.other_radius);
+                if (dist < radius + orad) blocked = true;
             }
             if (blocked) continue;
             out_dir = has_dir ? dir_in : rng.uniform(-3.141592653589793, 3.141592653589793);
@@ -627,6 +726,8 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     double box_x = 0, box_z = 0, box_dir = 0, ag_x = 0, ag_z = 0, ag_dir = 0;
     double box2_x = 0, box2_z = 0, box2_dir = 0;
     double brad = box_radius(0.8), brad2 = brad, box_s = 0.8, box2_s = d.n_boxes > 1 ? 0.8 : 0.0, goal_dist = 0.0;
+    double pn_x[MWB_MAX_BOXES] = {0, 0, 0, 0, 0, 0}, pn_z[MWB_MAX_BOXES] = {0, 0, 0, 0, 0, 0}, pn_dir[MWB_MAX_BOXES] = {0, 0, 0, 0, 0, 0},
+           pn_s[MWB_MAX_BOXES] = {0, 0, 0, 0, 0, 0};   // PutNext's six boxes
     const double arad = d.agent_radius;
     // reset() overrides of the T-maze family run before MiniWorldEnv.reset (every lane computes the same)
     int goal_idx = d.goal_idx[e];
@@ -721,6 +822,20 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         a.n_others = d.n_boxes; a.other_radius = brad;
         a.other_x[0] = box_x; a.other_z[0] = box_z; a.other_x[1] = box2_x; a.other_z[1] = box2_z;
         w.place_entity_ex(arad, a, ag_x, ag_z, ag_dir);
+    } else if (d.task == MWB_TASK_PUTNEXT) {   // envs/putnext.py:22-43
+        const double size = d.task_args[0];
+        w.add_rect_room(0, size, 0, size, TEXF_CONCRETE);
+        WorldGen::PlaceOpt o;
+        for (int b = 0; b < 6; b++) {   // for color in COLOR_NAMES: Box(color, size=self.rand.float(0.6, 0.85)); place_entity(box)
+            pn_s[b] = w.rng.uniform(0.6, 0.85);            // drawn before the placement (and, for the first box, before
+            if (b == 0) w.gen_static_data(dr, d.S_max);    // the texture draws of _gen_static_data, miniworld.py:865-866)
+            const double rb = box_radius(pn_s[b]);
+            o.n_others = b;
+            w.place_entity_ex(rb, o, pn_x[b], pn_z[b], pn_dir[b]);
+            o.other_x[b] = pn_x[b]; o.other_z[b] = pn_z[b]; o.other_r[b] = rb;
+        }
+        o.n_others = 6;
+        w.place_entity_ex(arad, o, ag_x, ag_z, ag_dir);
     } else if (d.task == MWB_TASK_HALLWAY) {   // envs/hallway.py:25-42
         double length = d.task_args[0];
         int r = w.add_rect_room(-1, -1 + length, -2, 2, TEXF_CONCRETE);
@@ -801,14 +916,13 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         w.place_entity(arad, true, box_x, box_z, brad, false, 0, false, 0, false, 0, ag_x, ag_z, ag_dir);
     }
     // miniworld.py:561-573: sky / light, then entity.randomize in list order (box, agent)
-    double sky[3], lpos[3], lcol[3], lamb[3], bias[3], cam[4];
+    double sky[3], lpos[3], lcol[3], lamb[3], cam[4];
+    double biases[MWB_MAX_BOXES][3];
     sample_param(w.rng, d.params[MWB_P_SKY_COLOR], 3, dr, sky);
     sample_param(w.rng, d.params[MWB_P_LIGHT_POS], 3, dr, lpos);
     sample_param(w.rng, d.params[MWB_P_LIGHT_COLOR], 3, dr, lcol);
     sample_param(w.rng, d.params[MWB_P_LIGHT_AMBIENT], 3, dr, lamb);
-    sample_param(w.rng, d.params[MWB_P_OBJ_COLOR_BIAS], 3, dr, bias);
-    double bias2[3] = {0, 0, 0};
-    if (d.n_boxes > 1) sample_param(w.rng, d.params[MWB_P_OBJ_COLOR_BIAS], 3, dr, bias2);   // entities randomize in list order
+    for (int b = 0; b < d.n_boxes; b++) sample_param(w.rng, d.params[MWB_P_OBJ_COLOR_BIAS], 3, dr, biases[b]);   // entities randomize in list order
     sample_param(w.rng, d.params[MWB_P_CAM_HEIGHT], 1, dr, &cam[0]);
     sample_param(w.rng, d.params[MWB_P_CAM_FWD_DISP], 1, dr, &cam[1]);
     sample_param(w.rng, d.params[MWB_P_CAM_PITCH], 1, dr, &cam[2]);
@@ -820,25 +934,28 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     if (lane == 0) {
         st[624] = (uint32_t)w.rng.pos;
         d.agent_x[e] = ag_x; d.agent_z[e] = ag_z; d.agent_dir[e] = ag_dir;
-        d.box_x[e] = box_x; d.box_z[e] = box_z; d.box_dir[e] = box_dir;
-        const double red[3] = {1.0, 0.0, 0.0};   // COLORS['red'] + bias, clipped (entity.py:381-383)
+        // COLORS in COLOR_NAMES order (entity.py:8-18): blue green grey purple red yellow; Box.randomize adds the bias and clips
+        const double COLORS[6][3] = {{0.0, 0.0, 1.0}, {0.0, 1.0, 0.0}, {0.39, 0.39, 0.39}, {0.44, 0.15, 0.76}, {1.0, 0.0, 0.0}, {1.00, 1.00, 0.00}};
+        const size_t N = (size_t)d.N;
+        for (int b = 0; b < d.n_boxes; b++) {
+            int base = 4;   // red
+            double x = box_x, z = box_z, dir = box_dir, sz = box_s;
+            if (d.task == MWB_TASK_PUTNEXT) { base = b; x = pn_x[b]; z = pn_z[b]; dir = pn_dir[b]; sz = pn_s[b]; }
+            else if (b == 1) { base = d.task == MWB_TASK_SIM2REAL_PUSH ? 5 : 0; x = box2_x; z = box2_z; dir = box2_dir; sz = box2_s; }   // yellow / blue
+            const size_t be = (size_t)b * N + e;
+            d.box_x[be] = x; d.box_z[be] = z; d.box_y[be] = 0.0; d.box_dir[be] = dir; d.box_size[be] = sz;
+            for (int k = 0; k < 3; k++) {
+                const double v = COLORS[base][k] + biases[b][k];
+                d.box_color[be * 3 + k] = v < 0 ? 0 : (v > 1 ? 1 : v);
+            }
+        }
         for (int k = 0; k < 3; k++) {
-            double v = red[k] + bias[k];
-            d.box_color[e * 3 + k] = v < 0 ? 0 : (v > 1 ? 1 : v);
             d.sky_color[e * 3 + k] = sky[k]; d.light_pos[e * 3 + k] = lpos[k];
             d.light_color[e * 3 + k] = lcol[k]; d.light_ambient[e * 3 + k] = lamb[k];
         }
-        if (d.n_boxes > 1) {   // the blue box, second plane of the box arrays
-            const size_t N = (size_t)d.N;
-            d.box_x[N + e] = box2_x; d.box_z[N + e] = box2_z; d.box_dir[N + e] = box2_dir; d.box_size[N + e] = box2_s;
-            const double blue[3] = {0.0, 0.0, 1.0}, yellow[3] = {1.0, 1.0, 0.0};   // COLORS, entity.py:8-15
-            for (int k = 0; k < 3; k++) {
-                double v = (d.task == MWB_TASK_SIM2REAL_PUSH ? yellow[k] : blue[k]) + bias2[k];
-                d.box_color[(N + e) * 3 + k] = v < 0 ? 0 : (v > 1 ? 1 : v);
-            }
-        }
+        d.carrying[e] = -1;   // a fresh Agent() carries nothing (entity.py:446)
         d.goal_idx[e] = goal_idx; d.episode_count[e] = episode_count;
-        d.box_size[e] = box_s; d.goal_dist[e] = goal_dist;
+        d.goal_dist[e] = goal_dist;
         for (int k = 0; k < 4; k++) d.cam[e * 4 + k] = cam[k];
         d.step_count[e] = 0;
         d.n_rooms[e] = w.fail ? -1 : w.n_rooms;
@@ -909,7 +1026,7 @@ __device__ __forceinline__ void lit_color(const float *L, const float *amb, cons
 }
 
 __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
-    float *fc = d.frame + (size_t)e * MWB_FRAME_WORDS;
+    float *fc = d.frame + (size_t)e * d.frame_words;
     double adir = d.agent_dir[e];
     double cam_h = d.cam[e * 4 + 0], cam_fd = d.cam[e * 4 + 1], cam_pitch = d.cam[e * 4 + 2], fov = d.cam[e * 4 + 3];
     double rot_y[9], rot_z[9], disp[3], t[3], cd[3];
@@ -955,7 +1072,7 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     float any_in_view = 0.0f;
     for (int bi = 0; bi < d.n_boxes; bi++) {   // one block of FC_BOX_STRIDE words per box
     const size_t be = (size_t)bi * d.N + e;
-    fc = d.frame + (size_t)e * MWB_FRAME_WORDS + bi * FC_BOX_STRIDE;
+    fc = d.frame + (size_t)e * d.frame_words + bi * FC_BOX_STRIDE;
     float bcol[3];
     for (int k = 0; k < 3; k++) bcol[k] = (float)d.box_color[be * 3 + k];
     double bdir = d.box_dir[be];
@@ -963,7 +1080,7 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     const float ln[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
     for (int k = 0; k < 6; k++)   // world normal = R_y(dir) n_local (glRotatef about +Y)
         lit_color(L, amb, dif, ln[k][0] * bc + ln[k][2] * bs, ln[k][1], -ln[k][0] * bs + ln[k][2] * bc, bcol, fc + FC_LIT_BOX + 3 * k);
-    float bpos[3] = {(float)d.box_x[be], 0.0f, (float)d.box_z[be]};
+    float bpos[3] = {(float)d.box_x[be], (float)d.box_y[be], (float)d.box_z[be]};   // y > 0 while the box is carried
     const double bsz = d.box_size[be];   // Box.render: extents +-sx/2, 0..sy, +-sz/2 (entity.py:385-408)
     float hx = (float)(bsz / 2), hz = (float)(bsz / 2), sy = (float)bsz;
     fc[FC_BOX_POS] = bpos[0]; fc[FC_BOX_POS + 1] = bpos[1]; fc[FC_BOX_POS + 2] = bpos[2];
@@ -971,7 +1088,7 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     float ro[3] = {eye[0] - bpos[0], eye[1] - bpos[1], eye[2] - bpos[2]};
     fc[FC_BOX_LO] = ro[0] * bc - ro[2] * bs; fc[FC_BOX_LO + 1] = ro[1]; fc[FC_BOX_LO + 2] = ro[0] * bs + ro[2] * bc;
     // conservative bounding sphere of the box for ray culling (radius inflated 2 %)
-    float oc[3] = {bpos[0] - eye[0], 0.5f * sy - eye[1], bpos[2] - eye[2]};
+    float oc[3] = {bpos[0] - eye[0], (bpos[1] + 0.5f * sy) - eye[1], bpos[2] - eye[2]};
     float R = 1.02f * sqrtf(hx * hx + 0.25f * sy * sy + hz * hz);
     fc[FC_CULL_OC] = oc[0]; fc[FC_CULL_OC + 1] = oc[1]; fc[FC_CULL_OC + 2] = oc[2];
     float oc2 = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2];
@@ -993,7 +1110,7 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
         }
     }
     }   // boxes
-    (d.frame + (size_t)e * MWB_FRAME_WORDS)[FC_BOX_IN_VIEW] = any_in_view;
+    (d.frame + (size_t)e * d.frame_words)[FC_BOX_IN_VIEW] = any_in_view;
 }
 
 // Counting sort of the envs by the measured render cost of a recent frame, most expensive first (256 buckets of
@@ -1485,7 +1602,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     if (n_rooms < 0) n_rooms = 0;
     float *rooms = (float *)smem;
     size_t off = ((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15;
-    float *fc = (float *)(smem + off); off += MWB_FRAME_WORDS * 4;
+    float *fc = (float *)(smem + off); off += (size_t)d.frame_words * 4;
     TexLds *tex = (TexLds *)(smem + off); off += sizeof(TexLds) * d.n_tex;
     int *cam_room_s = (int *)(smem + off); off += 16 + 2 * (THREADS / WAVE) * sizeof(int);   // + leftover counts
     uint16_t *queues = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
@@ -1497,8 +1614,8 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         const float4 *src = (const float4 *)(d.rooms + (size_t)e * d.R_max * MWB_ROOM_WORDS);
         float4 *dst = (float4 *)rooms;
         for (int i = tid; i < n_rooms * (MWB_ROOM_WORDS / 4); i += THREADS) dst[i] = src[i];
-        const float *fsrc = d.frame + (size_t)e * MWB_FRAME_WORDS;
-        for (int i = tid; i < MWB_FRAME_WORDS; i += THREADS) fc[i] = fsrc[i];
+        const float *fsrc = d.frame + (size_t)e * d.frame_words;
+        for (int i = tid; i < d.frame_words; i += THREADS) fc[i] = fsrc[i];
         const uint32_t *tsrc = (const uint32_t *)d.tex_desc;
         uint32_t *tdst = (uint32_t *)tex;
         for (int i = tid; i < (int)(sizeof(TexLds) / 4) * d.n_tex; i += THREADS) tdst[i] = tsrc[i];
@@ -1832,7 +1949,7 @@ size_t mwb_reset_lds_bytes(const MwbDev &d) {
     return (b + 15) & ~(size_t)15;
 }
 size_t mwb_render_lds_bytes(const MwbDev &d) {
-    size_t b = (((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15) + MWB_FRAME_WORDS * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
+    size_t b = (((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15) + (size_t)d.frame_words * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
                (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)d.W * d.H * 3;
     b += (size_t)(d.debug_flags >> 8) * 1024;   // MWB_DEBUG bits 8+: KiB of LDS padding (occupancy experiments)
     return (b + 15) & ~(size_t)15;
@@ -1858,10 +1975,11 @@ int mwb_prepare_kernels(const MwbDev &d) {
     }
     if (r > 64 * 1024 && hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r) != hipSuccess) return -2;
     if (q > 64 * 1024) {   // large mazes, or any task at a large observation size (the W*H*3 frame is in LDS too)
-        const void *fns[2][3] = {{(const void *)render_kernel<RENDER_THREADS, 0, 1>, (const void *)render_kernel<RENDER_THREADS, 1, 1>, (const void *)render_kernel<RENDER_THREADS, 2, 1>},
-                                 {(const void *)render_kernel<RENDER_THREADS, 0, 2>, (const void *)render_kernel<RENDER_THREADS, 1, 2>, (const void *)render_kernel<RENDER_THREADS, 2, 2>}};
+        const void *fns[3][3] = {{(const void *)render_kernel<RENDER_THREADS, 0, 1>, (const void *)render_kernel<RENDER_THREADS, 1, 1>, (const void *)render_kernel<RENDER_THREADS, 2, 1>},
+                                 {(const void *)render_kernel<RENDER_THREADS, 0, 2>, (const void *)render_kernel<RENDER_THREADS, 1, 2>, (const void *)render_kernel<RENDER_THREADS, 2, 2>},
+                                 {(const void *)render_kernel<RENDER_THREADS, 0, 6>, (const void *)render_kernel<RENDER_THREADS, 1, 6>, (const void *)render_kernel<RENDER_THREADS, 2, 6>}};
         for (int m = 0; m < 3; m++)
-            if (hipFuncSetAttribute(fns[d.n_boxes == 2 ? 1 : 0][m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess) return -2;
+            if (hipFuncSetAttribute(fns[d.n_boxes == 6 ? 2 : d.n_boxes == 2 ? 1 : 0][m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess) return -2;
     }
     return 0;
 }
@@ -1882,6 +2000,12 @@ void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
         if (mode == 1) render_kernel<RENDER_THREADS, 1, 2><<<gl, b, lds, s>>>(d);
         else if (mode == 2) render_kernel<RENDER_THREADS, 2, 2><<<g, b, lds, s>>>(d);
         else render_kernel<RENDER_THREADS, 0, 2><<<g, b, lds, s>>>(d);
+        return;
+    }
+    if (d.n_boxes == 6) {   // PutNext
+        if (mode == 1) render_kernel<RENDER_THREADS, 1, 6><<<gl, b, lds, s>>>(d);
+        else if (mode == 2) render_kernel<RENDER_THREADS, 2, 6><<<g, b, lds, s>>>(d);
+        else render_kernel<RENDER_THREADS, 0, 6><<<g, b, lds, s>>>(d);
         return;
     }
     if (mode == 1) render_kernel<RENDER_THREADS, 1, 1><<<gl, b, lds, s>>>(d);

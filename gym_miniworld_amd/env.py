@@ -52,6 +52,7 @@ class MiniWorldEnv:
         self.max_episode_steps = self._b.max_episode_steps
         self.params = self._b.params
         self.agent, self.box = _Ent(self._b.agent_radius, 1.6), _Ent(float(np.sqrt(0.8 * 0.8 + 0.8 * 0.8) / 2), 0.8)
+        self.agent.carrying = None
         self.entities = [self.box, self.agent]
         if self._b.n_boxes == 2:   # the two-box T-maze, tmaze.py:166-169
             self.red_box, self.blue_box = self.box, _Ent(self.box.radius, 0.8)
@@ -60,6 +61,12 @@ class MiniWorldEnv:
             self.goal_box_idx, self.penalty_box_idx = 0, 1
             if self._b.task == "SimToRealPush":   # simtorealpush.py:88-99
                 self.box1, self.box2 = self.red_box, self.blue_box
+        elif self._b.n_boxes > 2:   # PutNext: one box per colour in COLOR_NAMES order (putnext.py:31-38, entity.py:18)
+            self.boxes = [self.box] + [_Ent(self.box.radius, 0.8) for _ in range(self._b.n_boxes - 1)]
+            for b, name in zip(self.boxes, ("blue", "green", "grey", "purple", "red", "yellow")):
+                b.color = name
+            self.red_box, self.yellow_box = self.boxes[4], self.boxes[5]
+            self.entities = self.boxes + [self.agent]
         self.rooms, self.step_count = [], 0
         self._seeded = False
         if seed is not None:
@@ -96,6 +103,13 @@ class MiniWorldEnv:
             self.goal_dist = float(st["goal_dist"][0])
             self.goal_box_idx = int(st["goal_idx"][0])
             self.penalty_box_idx = 1 - self.goal_box_idx
+        if self._b.n_boxes > 2:
+            for k, b in enumerate(self.boxes):
+                b.pos, b.dir, b.color_vec = st["boxes_pos"][0, k].copy(), float(st["boxes_dir"][0, k]), st["boxes_color"][0, k].copy()
+                sk = float(st["boxes_size"][0, k])
+                b.radius, b.height, b.size = float(np.sqrt(sk * sk + sk * sk) / 2), sk, np.array([sk, sk, sk])
+        c = int(st["carrying"][0])
+        self.agent.carrying = None if c < 0 else (self.boxes[c] if hasattr(self, "boxes") else self.box)
         (self.agent.cam_height, self.agent.cam_fwd_disp, self.agent.cam_pitch, self.agent.cam_fov_y) = st["cam"][0]
         self.sky_color, self.light_pos = st["sky_color"][0], st["light_pos"][0]
         self.light_color, self.light_ambient = st["light_color"][0], st["light_ambient"][0]

@@ -50,7 +50,12 @@ enum { MWB_TASK_HALLWAY = 0,   /* envs/hallway.py   task_args = {length}        
         * RNG draw for the box's new heading), move_back is allowed (Discrete(4)), reward 1 when the boxes are
         * within goal_dist = 1.5 (size1 + size2).  task_args = {} */
        MWB_TASK_SIM2REAL_GOTO = 6,
-       MWB_TASK_SIM2REAL_PUSH = 7 };
+       MWB_TASK_SIM2REAL_PUSH = 7,
+       /* envs/putnext.py: one size x size room with six boxes - COLOR_NAMES order (entity.py:18): blue, green,
+        * grey, purple, red, yellow - of sizes drawn per episode; the full MiniWorldEnv action set Discrete(8) incl. pickup (4)
+        * and drop (5) with the carry physics of miniworld.py:594-606,622-631,645-654,682-702 (toggle 6 and done 7 do
+        * nothing); reward + done once the red box is next to the yellow one and nothing is carried.  task_args = {size} */
+       MWB_TASK_PUTNEXT = 8 };
 
 /* observation layouts */
 enum { MWB_LAYOUT_HWC = 0,  /* [N,H,W,3]  MiniWorldEnv.observation_space, miniworld.py:473-478 */
@@ -109,7 +114,7 @@ typedef struct mwb_outputs {
 typedef struct mwb_state {
     double *agent_pos;  /* [count][3] Entity.pos (entity.py:22-24), y = 0 */
     double *agent_dir;  /* [count]    Entity.dir                          */
-    double *box_pos;    /* [count][B][3] */
+    double *box_pos;    /* [count][B][3]  y > 0 while the box is carried (miniworld.py:603-604) */
     double *box_dir;    /* [count][B]    */
     double *box_color;  /* [count][B][3] Box.color_vec (entity.py:381-383)   */
     double *box_size;   /* [count][B] Box.size[0] (entity.py:366-378): 0.8 unless the task draws it per episode */
@@ -125,6 +130,7 @@ typedef struct mwb_state {
     int64_t *task_step_count; /* [count] tmaze.py:240 */
     double *goal_dist;      /* [count] simtorealpush.py:84 */
     uint32_t *rng_state;    /* [count][625] RandomState.get_state(): the 624 key words, then the position */
+    int32_t *carrying;      /* [count] agent.carrying as an index into the boxes, or -1 (miniworld.py:682-702) */
 } mwb_state;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
@@ -162,7 +168,8 @@ int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream);
 /* replaces: VecEnv.step_async+step_wait (vec_env/subproc_vec_env.py:58-75, worker 5-14,26-31 ->
  * MiniWorldEnv.step miniworld.py:658-716 + task rule e.g. envs/maze.py:106-113), including the
  * worker's auto-reset and the fork's `mask` ('dummy') semantics.
- * actions: device i32[num_envs]; skip_mask: device u8[num_envs] or NULL (mask[i]!=0 -> env i is not
+ * actions: device i32[num_envs], MiniWorldEnv.Actions values 0..7 (miniworld.py:437-454: turn_left, turn_right, move_forward,
+ * move_back, pickup, drop, toggle, done - every task executes all of them as the base class does); skip_mask: device u8[num_envs] or NULL (mask[i]!=0 -> env i is not
  * stepped, reward -99, done 0, observation re-rendered). */
 int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask_dev, void *stream);
 /* replaces: MiniWorldEnv.render_obs / render_depth (miniworld.py:1160-1220) for the whole batch */

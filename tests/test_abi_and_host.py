@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_struct_layout_matches_header(built):
     # mwb_config: 10 int32, 4 doubles, 2 int32, 13*9 doubles
     assert ctypes.sizeof(built.MwbConfig) == 10 * 4 + 4 * 8 + 2 * 4 + 13 * 9 * 8
-    assert ctypes.sizeof(built.MwbOutputs) == 14 * 8 and ctypes.sizeof(built.MwbState) == 21 * 8
+    assert ctypes.sizeof(built.MwbOutputs) == 14 * 8 and ctypes.sizeof(built.MwbState) == 22 * 8
 
 
 def test_create_fails_loudly_without_gpu_or_with_bad_args(built):
