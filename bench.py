@@ -33,11 +33,14 @@ WORKLOADS = {
     # the sim-to-real rink with box pushing (no ceiling, own params, always randomised, Discrete(4) incl. move_back
     # is available but the shared action stream stays on {0, 1, 2}); 14 400 B obs + ~0.8 KB state incl. the RNG words
     "sim2real_push8192": ("MiniWorld-SimToRealPush-v0", 8192, False, True, 15200),
+    # six boxes + the carry actions; 14 400 B obs + ~0.6 KB state (six box poses / sizes / colours)
+    # + 96 B room + 960 B frame constants.  The shared action stream stays on {0, 1, 2} (nothing gets picked up).
+    "putnext8192": ("MiniWorld-PutNext-v0", 8192, False, False, 16000),
 }
 ORACLE_TASK = {"MiniWorld-Maze-v0": ("Maze", None), "MiniWorld-OneRoom-v0": ("OneRoom", None),
                "MiniWorld-FourRooms-v0": ("FourRooms", None), "MiniWorld-Hallway-v0": ("Hallway", None),
                "MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0": ("TMazeTwoBox", [1, 0, 0, 100000]),
-               "MiniWorld-SimToRealPush-v0": ("SimToRealPush", None)}
+               "MiniWorld-SimToRealPush-v0": ("SimToRealPush", None), "MiniWorld-PutNext-v0": ("PutNext", None)}
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ACTION_SEED = 12345
 

@@ -123,6 +123,9 @@ __device__ __forceinline__ double box_radius(double size) {
 // the only loop, up to 256 segments in Maze - is split over all waves (wave p takes the 8-segment batches
 // p, p + STEP_PARTS, ...), which turns one long dependent load chain per env into STEP_PARTS short ones.
 #define STEP_PARTS 8
+// NBX = the task's number of boxes (1, 2 or 6): a template parameter so that the one-box tasks do not carry six-wide
+// select chains through the sequential part
+template <int NBX>
 __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const int32_t *__restrict__ actions,
                                                                 const uint8_t *__restrict__ skip) {
     __shared__ double s_nx[64], s_nz[64];
@@ -134,10 +137,10 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
     const bool live = in_range && !dummy;
     int sc = 0, a = -1;
     double ax = 0, az = 0, adir = 0, nx = 0, nz = 0, turn_step = 0;
-    const int NB = d.n_boxes;   // entity order: the boxes (red; red, blue / yellow; PutNext's six), then the agent
-    double bx[MWB_MAX_BOXES], bz[MWB_MAX_BOXES], by[MWB_MAX_BOXES], brad[MWB_MAX_BOXES], bsz[MWB_MAX_BOXES];
+    constexpr int NB = NBX;   // entity order: the boxes (red; red, blue / yellow; PutNext's six), then the agent
+    double bx[NBX], bz[NBX], by[NBX], brad[NBX], bsz[NBX];
 #pragma unroll
-    for (int b = 0; b < MWB_MAX_BOXES; b++) { bx[b] = 0; bz[b] = 0; by[b] = 0; brad[b] = 0; bsz[b] = 0; }
+    for (int b = 0; b < NBX; b++) { bx[b] = 0; bz[b] = 0; by[b] = 0; brad[b] = 0; bsz[b] = 0; }
     int carried = -1;   // agent.carrying as a box index
     const double arad = d.agent_radius;
     if (blockIdx.x == 0 && threadIdx.x == 0 && d.order_state[1]) {   // adopt the dispatch order completed beside the last pass
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
             a = actions[e];
             ax = d.agent_x[e]; az = d.agent_z[e]; adir = d.agent_dir[e];
 #pragma unroll
-            for (int b = 0; b < MWB_MAX_BOXES; b++)
+            for (int b = 0; b < NBX; b++)
                 if (b < NB) {
                     const size_t be = (size_t)b * d.N + e;
                     bx[b] = d.box_x[be]; bz[b] = d.box_z[be]; by[b] = d.box_y[be]; bsz[b] = d.box_size[be]; brad[b] = box_radius(bsz[b]);
@@ -163,7 +166,7 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
             MtSerial g;
             const bool use_rng = d.domain_rand || d.task == MWB_TASK_SIM2REAL_PUSH;
             if (use_rng) g.load(d.rng + (size_t)e * MWB_MT_WORDS);
-            if (d.task == MWB_TASK_SIM2REAL_PUSH && a == 2) {
+            if (NBX == 2 && d.task == MWB_TASK_SIM2REAL_PUSH && a == 2) {
                 // "Very crude approximation [of] the physics of box pushing", simtorealpush.py:109-125, before
                 // MiniWorldEnv.step: a box the nominal forward move would touch is shoved away by the vector
                 // from that position to the box, unless it would then hit a wall, the other box or the agent,
@@ -255,10 +258,10 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
     // ---- the rest of MiniWorldEnv.step for this env, sequential (wave 0, lane = env) -------------------------------
     const double max_fwd = d.params[MWB_P_FORWARD_STEP].hi[0];   // self.max_forward_step, miniworld.py:569
     // register-resident lookups by a run-time box index (select chains: no indexed scratch arrays)
-    auto pick = [&](const double (&v)[MWB_MAX_BOXES], int i) {
+    auto pick = [&](const double (&v)[NBX], int i) {
         double r_ = v[0];
 #pragma unroll
-        for (int b = 1; b < MWB_MAX_BOXES; b++) r_ = (i == b) ? v[b] : r_;
+        for (int b = 1; b < NBX; b++) r_ = (i == b) ? v[b] : r_;
         return r_;
     };
     // MiniWorldEnv.intersect(ent, pos, radius), miniworld.py:933-959, for an entity other than the moving agent's own
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
         }
         int res = 0;
 #pragma unroll
-        for (int b = MWB_MAX_BOXES - 1; b >= 0; b--) {   // descending, so that the lowest index wins
+        for (int b = NBX - 1; b >= 0; b--) {   // descending, so that the lowest index wins
             const double ddx = bx[b] - px, ddz = bz[b] - pz;
             const bool h = b < NB && b != self_idx && sqrt(ddx * ddx + 0.0 + ddz * ddz) < radius + brad[b];
             res = h ? 2 + b : res;
@@ -301,7 +304,7 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
     };
     auto store_carried = [&](double cx, double cy, double cz, bool set_dir) {
 #pragma unroll
-        for (int b = 0; b < MWB_MAX_BOXES; b++)
+        for (int b = 0; b < NBX; b++)
             if (b == carried) {
                 bx[b] = cx; by[b] = cy; bz[b] = cz;
                 const size_t be = (size_t)b * d.N + e;
@@ -339,7 +342,7 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
     } else if (a == 5) {   // drop, miniworld.py:692-695
         if (carried >= 0) {
 #pragma unroll
-            for (int b = 0; b < MWB_MAX_BOXES; b++)
+            for (int b = 0; b < NBX; b++)
                 if (b == carried) { by[b] = 0.0; d.box_y[(size_t)b * d.N + e] = 0.0; }
             carried = -1;
         }
@@ -355,31 +358,32 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
     if (sc >= d.max_episode_steps) { done = 1; r = 0.0; }   // miniworld.py:708-711
     {   // near(box), miniworld.py:961-971, then the task rule (e.g. envs/maze.py:106-113)
         const double max_forward_step = max_fwd;
-        bool near[MWB_MAX_BOXES];
+        bool near[NBX];
 #pragma unroll
-        for (int b = 0; b < MWB_MAX_BOXES; b++) {   // np.linalg.norm(ent0.pos - ent1.pos): a carried box is off the floor
+        for (int b = 0; b < NBX; b++) {   // np.linalg.norm(ent0.pos - ent1.pos): a carried box is off the floor
             double ddx = bx[b] - ax, ddy = by[b] - 0.0, ddz = bz[b] - az;
             double dist = sqrt((ddx * ddx + ddy * ddy) + ddz * ddz);
             near[b] = b < NB && dist < brad[b] + arad + 1.1 * max_forward_step;
         }
         const double rw = 1.0 - 0.2 * ((double)sc / d.max_episode_steps);   // _reward, miniworld.py:1012
-        if (d.task == MWB_TASK_TMAZE_TWOBOX) {   // tmaze.py:196-208 / 299-320: goal box first, then the penalty box
+        constexpr int I1 = NBX > 1 ? 1 : 0, I4 = NBX > 5 ? 4 : 0, I5 = NBX > 5 ? 5 : 0;   // box indices of the 2- / 6-box rules
+        if (NBX == 2 && d.task == MWB_TASK_TMAZE_TWOBOX) {   // tmaze.py:196-208 / 299-320: goal box first, then the penalty box
             const int g = d.goal_idx[e];
-            const bool near_goal = g ? near[1] : near[0], near_penalty = g ? near[0] : near[1];
+            const bool near_goal = g ? near[I1] : near[0], near_penalty = g ? near[0] : near[I1];
             if (near_goal) { r += rw; done = 1; }
             if (near_penalty) { r += -1 * rw; done = 1; }
             if (d.task_args[0] != 0) {   // the *Features* classes: feature = [near(blue), near(red)], and their step counter
-                d.feature[e * 2] = near[1] ? 1.0f : 0.0f; d.feature[e * 2 + 1] = near[0] ? 1.0f : 0.0f;
+                d.feature[e * 2] = near[I1] ? 1.0f : 0.0f; d.feature[e * 2 + 1] = near[0] ? 1.0f : 0.0f;
                 d.task_step_count[e] += 1;
             }
-            d.goal_pos[e * 3] = g ? bx[1] : bx[0]; d.goal_pos[e * 3 + 1] = 0.0; d.goal_pos[e * 3 + 2] = g ? bz[1] : bz[0];   // info['goal_pos']
-        } else if (d.task == MWB_TASK_SIM2REAL_PUSH) {   // simtorealpush.py:129-133: the boxes are close enough
-            const double ddx = bx[0] - bx[1], ddz = bz[0] - bz[1];
+            d.goal_pos[e * 3] = g ? bx[I1] : bx[0]; d.goal_pos[e * 3 + 1] = 0.0; d.goal_pos[e * 3 + 2] = g ? bz[I1] : bz[0];   // info['goal_pos']
+        } else if (NBX == 2 && d.task == MWB_TASK_SIM2REAL_PUSH) {   // simtorealpush.py:129-133: the boxes are close enough
+            const double ddx = bx[0] - bx[I1], ddz = bz[0] - bz[I1];
             if (sqrt((ddx * ddx + 0.0) + ddz * ddz) < d.goal_dist[e]) { r = 1.0; done = 1; }
-        } else if (d.task == MWB_TASK_PUTNEXT) {   // putnext.py:45-53: red (box 4) next to yellow (box 5), nothing carried
+        } else if (NBX == 6 && d.task == MWB_TASK_PUTNEXT) {   // putnext.py:45-53: red (box 4) next to yellow (box 5), nothing carried
             if (carried < 0) {
-                const double ddx = bx[4] - bx[5], ddy = by[4] - by[5], ddz = bz[4] - bz[5];
-                if (sqrt((ddx * ddx + ddy * ddy) + ddz * ddz) < brad[4] + brad[5] + 1.1 * max_forward_step) { r += rw; done = 1; }
+                const double ddx = bx[I4] - bx[I5], ddy = by[I4] - by[I5], ddz = bz[I4] - bz[I5];
+                if (sqrt((ddx * ddx + ddy * ddy) + ddz * ddz) < brad[I4] + brad[I5] + 1.1 * max_forward_step) { r += rw; done = 1; }
             }
         } else {
             if (near[0]) { r += rw; done = 1; }
@@ -1956,7 +1960,10 @@ size_t mwb_render_lds_bytes(const MwbDev &d) {
 }
 
 void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *skip, hipStream_t s) {
-    hipLaunchKernelGGL(step_kernel, dim3((d.N + 63) / 64), dim3(64 * STEP_PARTS), 0, s, d, actions, skip);
+    const dim3 g((d.N + 63) / 64), b(64 * STEP_PARTS);
+    if (d.n_boxes == 1) hipLaunchKernelGGL(step_kernel<1>, g, b, 0, s, d, actions, skip);
+    else if (d.n_boxes == 2) hipLaunchKernelGGL(step_kernel<2>, g, b, 0, s, d, actions, skip);
+    else hipLaunchKernelGGL(step_kernel<MWB_MAX_BOXES>, g, b, 0, s, d, actions, skip);
 }
 __global__ void clear_list_kernel(MwbDev d) { d.reset_count[0] = 0; }
 
