@@ -286,9 +286,10 @@ def main():
                        "gather_tuning_s": None if gather is None else gather.tuned},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload),
+                         "traffic_source": "committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (profiles/r*_pmc_traffic.json, scripts/profile_workload.sh); not re-measured in this run",
                          "kernel": "render_kernel", "kernel_ms": render_ms,
                          "algorithmic_bytes_per_launch": alg_bytes * count,
-                         "note": "nominally HBM-bound path; the practical limiter is VALU issue plus LDS / texel latency (VALU pipes ~54 % busy at 5 waves/SIMD, DESIGN.md 4)"},
+                         "note": "nominally HBM-bound path; the practical limiter is VALU issue (DESIGN.md 4: issue-slot accounting from the committed SQ counter passes)"},
             "kernel_ms": {k: kt[k] for k in ("step", "reset", "prep", "render")},
         }
         if world == 1 and not args.no_vecenv:

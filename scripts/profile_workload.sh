@@ -7,7 +7,7 @@ TAG=${1:-r01}; WL=${2:-maze8192}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 P=gpurun_out/prof_$WL
 rm -rf "$P"
-W="--workload $WL --no-cpu-baseline"
+W="--workload $WL --no-cpu-baseline --no-vecenv"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 bench.py $W --steps 100 --warmup 20 > $P.trace.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/pmc_fetch -- python3 bench.py $W --steps 20 --warmup 5 > $P.fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/pmc_write -- python3 bench.py $W --steps 20 --warmup 5 > $P.write.log 2>&1
