@@ -146,6 +146,7 @@ typedef struct {
 } Quad;
 
 typedef struct {
+    int n_edges;               /* num_walls: 4, or 3 for YMaze's triangular hub */
     double outline[4][3];      /* miniworld.py:90-97, y = 0 */
     double min_x, max_x, min_z, max_z, mid_x, mid_z, area;
     double edge_dirs[4][3], edge_norms[4][3];
@@ -266,8 +267,8 @@ static void sample_param(MwoEnv *e, int use_rng, int name, double *out) {
 MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int domain_rand, const double *params) {
     MwoEnv *e = (MwoEnv *)calloc(1, sizeof(MwoEnv));
     e->task = task;
-    static const double dflt[9][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}, {12, 0, 0, 0}};
-    if (task < 0 || task > MWO_PUTNEXT) fail("unknown task");
+    static const double dflt[10][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}, {12, 0, 0, 0}, {0, 0, 0, 0}};
+    if (task < 0 || task > MWO_YMAZE) fail("unknown task");
     for (int i = 0; i < 4; i++) e->task_args[i] = task_args ? task_args[i] : dflt[task][i];
     e->n_boxes = (task == MWO_TMAZE_TWOBOX || task == MWO_SIM2REAL_PUSH) ? 2 : task == MWO_PUTNEXT ? 6 : 1;
     e->carrying = -1;
@@ -280,6 +281,7 @@ MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int
         else if (task == MWO_SIM2REAL_GOTO) max_episode_steps = 100; /* simtorealgoto.py:30 */
         else if (task == MWO_SIM2REAL_PUSH) max_episode_steps = 150; /* simtorealpush.py:29 */
         else if (task == MWO_PUTNEXT) max_episode_steps = 250; /* putnext.py:16 */
+        else if (task == MWO_YMAZE) max_episode_steps = 280; /* ymaze.py:21 */
         else max_episode_steps = (int)e->task_args[0] * (int)e->task_args[1] * 24;
     }
     e->max_episode_steps = max_episode_steps;
@@ -315,14 +317,15 @@ static double norm3(const double *v) { /* np.linalg.norm(axis=1): sqrt(add.reduc
 }
 
 /* Room.__init__, miniworld.py:75-138 */
-static Room *add_room(MwoEnv *e, const double outline2[4][2], double wall_height, int wall_tex, int floor_tex, int ceil_tex, int no_ceiling) {
+static Room *add_room_n(MwoEnv *e, const double outline2[4][2], int n_edges, double wall_height, int wall_tex, int floor_tex, int ceil_tex, int no_ceiling) {
     if (e->static_done) fail("cannot add rooms after static data is generated");
     if (e->n_rooms >= MWO_MAX_ROOMS) fail("too many rooms");
     Room *r = &e->rooms[e->n_rooms++];
     memset(r, 0, sizeof(*r));
-    for (int i = 0; i < 4; i++) { r->outline[i][0] = outline2[i][0]; r->outline[i][1] = 0; r->outline[i][2] = outline2[i][1]; }
+    r->n_edges = n_edges;
+    for (int i = 0; i < n_edges; i++) { r->outline[i][0] = outline2[i][0]; r->outline[i][1] = 0; r->outline[i][2] = outline2[i][1]; }
     r->min_x = r->max_x = r->outline[0][0]; r->min_z = r->max_z = r->outline[0][2];
-    for (int i = 1; i < 4; i++) {
+    for (int i = 1; i < n_edges; i++) {
         if (r->outline[i][0] < r->min_x) r->min_x = r->outline[i][0];
         if (r->outline[i][0] > r->max_x) r->max_x = r->outline[i][0];
         if (r->outline[i][2] < r->min_z) r->min_z = r->outline[i][2];
@@ -330,8 +333,8 @@ static Room *add_room(MwoEnv *e, const double outline2[4][2], double wall_height
     }
     r->mid_x = (r->max_x + r->min_x) / 2; r->mid_z = (r->max_z + r->min_z) / 2;
     r->area = (r->max_x - r->min_x) * (r->max_z - r->min_z);
-    for (int i = 0; i < 4; i++) {
-        const double *p0 = r->outline[i], *p1 = r->outline[(i + 1) % 4];
+    for (int i = 0; i < n_edges; i++) {
+        const double *p0 = r->outline[i], *p1 = r->outline[(i + 1) % n_edges];
         double d[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
         double n = norm3(d);
         for (int k = 0; k < 3; k++) r->edge_dirs[i][k] = d[k] / n;
@@ -347,6 +350,10 @@ static Room *add_room(MwoEnv *e, const double outline2[4][2], double wall_height
     return r;
 }
 
+static Room *add_room(MwoEnv *e, const double outline2[4][2], double wall_height, int wall_tex, int floor_tex, int ceil_tex, int no_ceiling) {
+    return add_room_n(e, outline2, 4, wall_height, wall_tex, floor_tex, ceil_tex, no_ceiling);
+}
+
 /* add_rect_room, miniworld.py:718-743 */
 static Room *add_rect_room(MwoEnv *e, double min_x, double max_x, double min_z, double max_z, int wall_tex) {
     double o[4][2] = {{max_x, max_z}, {max_x, min_z}, {min_x, min_z}, {min_x, max_z}};
@@ -356,7 +363,7 @@ static Room *add_rect_room(MwoEnv *e, double min_x, double max_x, double min_z, 
 /* Room.add_portal, miniworld.py:140-218.  mode 0: start/end given; 1: min_x/max_x; 2: min_z/max_z */
 static void add_portal(Room *r, int edge, int mode, double a, double b, int has_max_y, double max_y_in, double *start_out, double *end_out) {
     double max_y = has_max_y ? max_y_in : r->wall_height, min_y = 0;
-    const double *p0 = r->outline[edge], *p1 = r->outline[(edge + 1) % 4];
+    const double *p0 = r->outline[edge], *p1 = r->outline[(edge + 1) % r->n_edges];
     double diff[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
     /* 1-D np.linalg.norm = sqrt(dot(x,x)); exact for the axis-aligned edges of every configured task */
     double e_len = sqrt(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
@@ -389,8 +396,8 @@ static void add_portal(Room *r, int edge, int mode, double a, double b, int has_
 static void connect_rooms(MwoEnv *e, int ia, int ib, int mode, double lo, double hi, int has_max_y, double max_y) {
     Room *A = &e->rooms[ia], *B = &e->rooms[ib];
     int idx_a = -1, idx_b = -1;
-    for (int i = 0; i < 4 && idx_a < 0; i++)
-        for (int j = 0; j < 4; j++) {
+    for (int i = 0; i < A->n_edges && idx_a < 0; i++)
+        for (int j = 0; j < B->n_edges; j++) {
             const double *na = A->edge_norms[i], *nb = B->edge_norms[j];
             double dotn = na[0] * nb[0] + na[1] * nb[1] + na[2] * nb[2];
             if (dotn > -0.9) continue;
@@ -472,16 +479,16 @@ static void room_gen_static(MwoEnv *e, Room *r, int use_rng) {
     r->floor_tex = tex_get(e, r->floor_tex_name, use_rng);
     r->ceil_tex = tex_get(e, r->ceil_tex_name, use_rng);
     /* gen_texcs_floor, miniworld.py:48-68 */
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < r->n_edges; i++) {
         r->floor_texcs[i][0] = r->outline[i][0] * (512.0 / tex_width(r->floor_tex));
         r->floor_texcs[i][1] = r->outline[i][2] * (512.0 / tex_height(r->floor_tex));
-        const double *cv = r->outline[3 - i]; /* np.flip(outline, axis=0) */
+        const double *cv = r->outline[r->n_edges - 1 - i]; /* np.flip(outline, axis=0) */
         r->ceil_texcs[i][0] = (cv[0] + r->wall_height * 0) * (512.0 / tex_width(r->ceil_tex));
         r->ceil_texcs[i][1] = (cv[2] + r->wall_height * 0) * (512.0 / tex_height(r->ceil_tex));
     }
     GenCtx g = {r, NULL, 0, 0, NULL, 0, 0};
-    for (int w = 0; w < 4; w++) {
-        const double *p0 = r->outline[w], *p1 = r->outline[(w + 1) % 4];
+    for (int w = 0; w < r->n_edges; w++) {
+        const double *p0 = r->outline[w], *p1 = r->outline[(w + 1) % r->n_edges];
         double d[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
         double wall_width = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
         double side[3] = {d[0] / wall_width, d[1] / wall_width, d[2] / wall_width};
@@ -567,7 +574,7 @@ int mwo_intersect_ent(MwoEnv *e, int ent_index, double x, double z, double radiu
 
 /* Room.point_inside, miniworld.py:220-232 */
 static int point_inside(const Room *r, const double *p) {
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < r->n_edges; i++) {
         double ap[3] = {p[0] - r->outline[i][0], p[1] - r->outline[i][1], p[2] - r->outline[i][2]};
         const double *n = r->edge_norms[i];
         double dot = (n[0] * ap[0] + n[1] * ap[1]) + n[2] * ap[2];
@@ -611,6 +618,9 @@ static void size_box(MwoEnv *e, int b, double s) {
     ent->height = s;
 }
 static void new_box(MwoEnv *e) { for (int b = 0; b < MWO_MAX_BOXES; b++) size_box(e, b, 0.8); }
+
+/* one row of np.dot(A (N x 3), M (3 x 3)) as numpy's BLAS computes it: see the note at its definition */
+static void mat_row_dot(const double *v, const double *m, double *out);
 
 /* envs/maze.py:34-104 */
 typedef struct { int i, j; int order[4][2]; int next; } Frame;
@@ -753,6 +763,38 @@ static void gen_world(MwoEnv *e) {
             place_entity(e, &e->boxes[b], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
         }
         place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        break;
+    }
+    case MWO_YMAZE: { /* envs/ymaze.py:28-83 */
+        const double main_o[4][2] = {{-9.15, -2}, {-9.15, 2}, {-1.15, 2}, {-1.15, -2}};
+        add_room(e, main_o, 2.74, TEXF_CONCRETE, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES, 0);
+        const double hub_o[4][2] = {{-1.15, -2}, {-1.15, 2}, {2.31, 0}, {0, 0}};
+        add_room_n(e, hub_o, 3, 2.74, TEXF_CONCRETE, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES, 0);
+        const double Yv[3] = {0, 1, 0};
+        for (int arm = 0; arm < 2; arm++) { /* np.dot(main_outline, gen_rot_matrix(Y, -+120 deg)) */
+            double m[9], o[4][2];
+            mwo_gen_rot_matrix(Yv, (arm == 0 ? -120 : 120) * (M_PI / 180), m);
+            for (int i = 0; i < 4; i++) {
+                const double v[3] = {main_o[i][0], 0, main_o[i][1]};
+                double out[3];
+                mat_row_dot(v, m, out);
+                o[i][0] = out[0]; o[i][1] = out[2];
+            }
+            add_room(e, o, 2.74, TEXF_CONCRETE, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES, 0);
+        }
+        connect_rooms(e, 0, 1, 2, -2, 2, 0, 0);
+        connect_rooms(e, 2, 1, 2, -1.995, 0, 0, 0);
+        connect_rooms(e, 3, 1, 2, 0, 1.995, 0, 0);
+        new_box(e);
+        if (e->task_args[0] != 0) { /* goal_pos given (YMazeLeft / YMazeRight, ymaze.py:97-103) */
+            double gx = e->task_args[1], gz = e->task_args[2];
+            place_entity(e, &e->boxes[0], 0, 0, gx, gx, gz, gz);
+        } else if (rs_randint(&e->rng, 0, 2) == 0) /* RandGen.bool */
+            place_entity_in(e, &e->boxes[0], 2, 0, 0, NOVAL, NOVAL, NOVAL, e->rooms[2].min_z + 2.5);
+        else
+            place_entity_in(e, &e->boxes[0], 3, 0, 0, NOVAL, NOVAL, e->rooms[3].max_z - 2.5, NOVAL);
+        double dir = rs_uniform(&e->rng, -M_PI / 4, M_PI / 4);
+        place_entity_in(e, &e->agent, 0, 1, dir, NOVAL, NOVAL, NOVAL, NOVAL);
         break;
     }
     default: fail("unknown task");
@@ -934,6 +976,13 @@ void mwo_gen_rot_matrix(const double *axis_in, double angle, double *m) {
     m[6] = 2 * (b * d - a * c); m[7] = 2 * (c * d + a * b); m[8] = a * a + d * d - b * b - c * c;
 }
 
+#ifndef MAT_ROW_DOT_EXPR
+#define MAT_ROW_DOT_EXPR ((v[0] * m[j] + v[1] * m[3 + j]) + v[2] * m[6 + j])
+#endif
+static void mat_row_dot(const double *v, const double *m, double *out) {
+    for (int j = 0; j < 3; j++) out[j] = MAT_ROW_DOT_EXPR;
+}
+
 static void vec_mat(const double *v, const double *m, double *out) { /* np.dot(v, M) */
     for (int j = 0; j < 3; j++) out[j] = (v[0] * m[0 * 3 + j] + v[1] * m[1 * 3 + j]) + v[2] * m[2 * 3 + j];
 }
@@ -995,7 +1044,7 @@ void mwo_get_geometry(MwoEnv *e, double *outline, double *heights, double *porta
     int q = 0;
     for (int i = 0; i < e->n_rooms; i++) {
         Room *r = &e->rooms[i];
-        for (int k = 0; k < 4; k++) { outline[(i * 4 + k) * 2] = r->outline[k][0]; outline[(i * 4 + k) * 2 + 1] = r->outline[k][2]; }
+        for (int k = 0; k < 4; k++) { outline[(i * 4 + k) * 2] = k < r->n_edges ? r->outline[k][0] : NAN; outline[(i * 4 + k) * 2 + 1] = k < r->n_edges ? r->outline[k][2] : NAN; }
         heights[i] = r->wall_height;
         for (int ed = 0; ed < 4; ed++) {
             portal_count[i * 4 + ed] = r->n_portals[ed];
@@ -1013,8 +1062,9 @@ void mwo_get_geometry(MwoEnv *e, double *outline, double *heights, double *porta
                 qt[(q * 4 + v) * 2] = r->quads[k].texcs[v][0]; qt[(q * 4 + v) * 2 + 1] = r->quads[k].texcs[v][1];
             }
         for (int v = 0; v < 4; v++) {
-            ftex[(i * 4 + v) * 2] = r->floor_texcs[v][0]; ftex[(i * 4 + v) * 2 + 1] = r->floor_texcs[v][1];
-            ctex[(i * 4 + v) * 2] = r->ceil_texcs[v][0]; ctex[(i * 4 + v) * 2 + 1] = r->ceil_texcs[v][1];
+            const int in = v < r->n_edges;
+            ftex[(i * 4 + v) * 2] = in ? r->floor_texcs[v][0] : NAN; ftex[(i * 4 + v) * 2 + 1] = in ? r->floor_texcs[v][1] : NAN;
+            ctex[(i * 4 + v) * 2] = in ? r->ceil_texcs[v][0] : NAN; ctex[(i * 4 + v) * 2 + 1] = in ? r->ceil_texcs[v][1] : NAN;
         }
         tex_ids[i * 3] = r->wall_tex; tex_ids[i * 3 + 1] = r->floor_tex; tex_ids[i * 3 + 2] = r->ceil_tex;
     }

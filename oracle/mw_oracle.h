@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 enum { MWO_HALLWAY = 0, MWO_ONEROOM = 1, MWO_FOURROOMS = 2, MWO_MAZE = 3, MWO_TMAZE = 4, MWO_TMAZE_TWOBOX = 5,
-       MWO_SIM2REAL_GOTO = 6, MWO_SIM2REAL_PUSH = 7, MWO_PUTNEXT = 8 };
+       MWO_SIM2REAL_GOTO = 6, MWO_SIM2REAL_PUSH = 7, MWO_PUTNEXT = 8, MWO_YMAZE = 9 };
 
 /* domain parameters, reference params.py:110-123, same order */
 enum {

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "libmw_oracle.so")
 TEX_DIR = os.path.join(os.path.dirname(HERE), "gym_miniworld_amd", "textures")
 
 TASKS = {"Hallway": 0, "OneRoom": 1, "FourRooms": 2, "Maze": 3, "TMaze": 4, "TMazeTwoBox": 5,
-         "SimToRealGoTo": 6, "SimToRealPush": 7, "PutNext": 8}
+         "SimToRealGoTo": 6, "SimToRealPush": 7, "PutNext": 8, "YMaze": 9}
 MAX_BOXES = 6
 # texture id table (family -> files), reference opengl.py:40-69 picks <name>_<i>.png
 TEX_FILES = ["floor_tiles_bw_1", "concrete_1", "concrete_2", "concrete_3", "concrete_4",

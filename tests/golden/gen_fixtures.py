@@ -29,6 +29,7 @@ from gym_miniworld.envs import (TMaze, TMazeDynamic, TMazeLeft, TMazeRight, TMaz
                                 TMazeTwoBoxDynamicFeatures100K, TMazeTwoBoxDynamicFeaturesDebug)
 from gym_miniworld.envs import SimToRealGoTo, SimToRealPush  # noqa: E402
 from gym_miniworld.envs import PutNext  # noqa: E402
+from gym_miniworld.envs import YMaze, YMazeLeft, YMazeRight  # noqa: E402
 from gym_miniworld.opengl import Texture  # noqa: E402
 from gym_miniworld import math as ref_math  # noqa: E402
 
@@ -49,7 +50,9 @@ TASKS = {
     "TMazeTwoBoxFeaturesDebug": (TMazeTwoBoxDynamicFeaturesDebug, {}),
 }
 TASKS.update({"SimToRealGoTo": (SimToRealGoTo, {}), "SimToRealPush": (SimToRealPush, {})})   # no-ceiling rinks, own params
-NO_KWARGS = {"TMazeLeft", "TMazeRight", "TMazeDynamic3"}   # constructors without **kwargs: no domain_rand
+# non-rectangular rooms: a triangular hub, two arms rotated by 120 degrees, two sliver-shaped connectors
+TASKS.update({"YMaze": (YMaze, {}), "YMazeLeft": (YMazeLeft, {}), "YMazeRight": (YMazeRight, {})})
+NO_KWARGS = {"TMazeLeft", "TMazeRight", "TMazeDynamic3", "YMazeLeft", "YMazeRight"}   # constructors without **kwargs: no domain_rand
 
 # (seed, domain_rand, policy, n_steps)
 PLAN = {
@@ -75,6 +78,9 @@ PLAN = {
     # these two classes force domain_rand=True themselves (simtorealgoto.py:31, simtorealpush.py:30)
     "SimToRealGoTo": [(0, 1, "random", 400), (1, 1, "greedy", 400), (2, 1, "forward", 300)],
     "SimToRealPush": [(0, 1, "random", 500), (1, 1, "push", 900), (2, 1, "greedy", 600), (3, 1, "push", 900)],
+    "YMaze": [(0, 0, "random", 600), (1, 0, "greedy", 500), (2, 1, "greedy", 500), (3, 1, "random", 600), (7, 0, "forward", 400)],
+    "YMazeLeft": [(0, 0, "greedy", 400), (1, 0, "random", 500)],
+    "YMazeRight": [(0, 0, "greedy", 400), (1, 0, "forward", 400)],
 }
 
 
@@ -94,13 +100,16 @@ def rng_fingerprint(env):
 
 def snapshot_world(env):
     R = len(env.rooms)
-    outline = np.stack([np.stack([r.outline[:, 0], r.outline[:, 2]], axis=1) for r in env.rooms])  # R,4,2
+    def pad4(a):   # rooms are quadrilaterals except YMaze's triangular hub: its missing fourth row is NaN
+        a = np.asarray(a)
+        return a if a.shape[0] == 4 else np.concatenate([a.astype(float), np.full((4 - a.shape[0],) + a.shape[1:], np.nan)])
+    outline = np.stack([pad4(np.stack([r.outline[:, 0], r.outline[:, 2]], axis=1)) for r in env.rooms])  # R,4,2
     heights = np.array([r.wall_height for r in env.rooms])
     pmax = max(1, max(len(p) for r in env.rooms for p in r.portals))
     portals = np.full((R, 4, pmax, 4), np.nan)
     pcount = np.zeros((R, 4), dtype=np.int32)
     for i, r in enumerate(env.rooms):
-        for e in range(4):
+        for e in range(r.num_walls):
             pcount[i, e] = len(r.portals[e])
             for k, p in enumerate(r.portals[e]):
                 portals[i, e, k] = [p["start_pos"], p["end_pos"], p["min_y"], p["max_y"]]
@@ -114,13 +123,17 @@ def snapshot_world(env):
         "wall_verts": np.concatenate([r.wall_verts for r in env.rooms]),
         "wall_norms": np.concatenate([r.wall_norms for r in env.rooms]),
         "wall_texcs": np.concatenate([r.wall_texcs for r in env.rooms]).astype(np.float32),
-        "floor_texcs": np.stack([r.floor_texcs for r in env.rooms]),
-        "ceil_texcs": np.stack([r.ceil_texcs for r in env.rooms]),
+        "floor_texcs": np.stack([pad4(r.floor_texcs) for r in env.rooms]),
+        "ceil_texcs": np.stack([pad4(r.ceil_texcs) for r in env.rooms]),
         "tex_names": np.array([[tex_basename(r.wall_tex), tex_basename(r.floor_tex), tex_basename(r.ceil_tex)]
                                for r in env.rooms]),
         "tex_width": np.array([[r.wall_tex.width, r.floor_tex.width, r.ceil_tex.width] for r in env.rooms],
                               dtype=np.int32),
     }
+    if any(r.num_walls != 4 for r in env.rooms):
+        d["n_edges"] = np.array([r.num_walls for r in env.rooms], dtype=np.int32)
+        d["edge_dirs"] = np.stack([pad4(r.edge_dirs[:, [0, 2]]) for r in env.rooms])
+        d["edge_norms"] = np.stack([pad4(r.edge_norms[:, [0, 2]]) for r in env.rooms])
     d.update(snapshot_entities(env))
     return d
 
@@ -192,6 +205,8 @@ def choose_action(env, policy, arng):
     tgt = b.pos
     if type(env).__name__.startswith("TMaze") and a.pos[0] < 9.2:
         tgt = np.array([10.0, 0.0, 0.0])   # leave the stem of the T before heading for the arm
+    if type(env).__name__.startswith("YMaze") and a.pos[0] < 0.3:
+        tgt = np.array([0.7, 0.0, 0.0])    # through the hub of the Y first
     want = math.atan2(-(tgt[2] - a.pos[2]), tgt[0] - a.pos[0])
     diff = (want - a.dir + math.pi) % (2 * math.pi) - math.pi
     if abs(diff) > math.radians(10):
@@ -545,8 +560,12 @@ def main():
                 continue
             if task.startswith("SimToReal") and dr == 0:
                 continue
+            if task in ("YMazeLeft", "YMazeRight"):
+                continue
             # the two-box scene is captured from inside the bar of the T, with both boxes in view
             pose = (11.5, 7.6, 2.13) if task == "TMazeTwoBoxFeatures" else None
+            if task == "YMaze" and dr == 1:
+                pose = (0.4, 0.3, 1.0)   # from inside the triangular hub, looking up the left arm past a sliver-shaped connector
             g = capture_gl(cls, kwargs, 1, dr, pose)
             g["posed"] = pose is not None
             with open(os.path.join(HERE, "glstream_%s_dr%d.json" % (task, dr)), "w") as fh:
