@@ -155,6 +155,7 @@ typedef struct {
     int wall_tex_name, floor_tex_name, ceil_tex_name; /* texture family ids */
     int n_portals[4];
     Portal portals[4][MWO_MAX_PORTALS];
+    int nbr[4]; /* room behind the (single) portal of each edge, -1 none: recorded by connect_rooms for the polygon renderer */
     /* static data (miniworld.py:234-388) */
     int wall_tex, floor_tex, ceil_tex; /* concrete texture ids */
     int n_quads, n_segs;
@@ -323,6 +324,7 @@ static Room *add_room_n(MwoEnv *e, const double outline2[4][2], int n_edges, dou
     Room *r = &e->rooms[e->n_rooms++];
     memset(r, 0, sizeof(*r));
     r->n_edges = n_edges;
+    for (int i = 0; i < 4; i++) r->nbr[i] = -1;
     for (int i = 0; i < n_edges; i++) { r->outline[i][0] = outline2[i][0]; r->outline[i][1] = 0; r->outline[i][2] = outline2[i][1]; }
     r->min_x = r->max_x = r->outline[0][0]; r->min_z = r->max_z = r->outline[0][2];
     for (int i = 1; i < n_edges; i++) {
@@ -418,7 +420,7 @@ static void connect_rooms(MwoEnv *e, int ia, int ib, int mode, double lo, double
         d[k] = B->outline[idx_b][k] + B->edge_dirs[idx_b][k] * eb;
     }
     double ad[3] = {a[0] - d[0], a[1] - d[1], a[2] - d[2]};
-    if (sqrt(ad[0] * ad[0] + ad[1] * ad[1] + ad[2] * ad[2]) < 0.001) return;
+    if (sqrt(ad[0] * ad[0] + ad[1] * ad[1] + ad[2] * ad[2]) < 0.001) { A->nbr[idx_a] = ib; B->nbr[idx_b] = ia; return; }
     double ba[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, dc[3] = {d[0] - c[0], d[1] - c[1], d[2] - c[2]};
     double len_a = sqrt(ba[0] * ba[0] + ba[1] * ba[1] + ba[2] * ba[2]);
     double len_b = sqrt(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]);
@@ -428,6 +430,8 @@ static void connect_rooms(MwoEnv *e, int ia, int ib, int mode, double lo, double
     Room *R = add_room(e, o, my, wall_tex, floor_tex, ceil_tex, noc);
     add_portal(R, 1, 0, 0, len_a, 0, 0, NULL, NULL);
     add_portal(R, 3, 0, 0, len_b, 0, 0, NULL, NULL);
+    A = &e->rooms[ia]; B = &e->rooms[ib];
+    A->nbr[idx_a] = e->n_rooms - 1; B->nbr[idx_b] = e->n_rooms - 1; R->nbr[1] = ia; R->nbr[3] = ib;
 }
 
 /* Texture.get, opengl.py:40-69: variant 1 unless rng, then rng.int(0, n) */
@@ -1191,6 +1195,117 @@ static Hit trace_rooms(const RRoom *rr, int n_rooms, int room, const float *o, c
     return h;
 }
 
+/* ---- rooms that are convex polygons with 3 or 4 arbitrary edges (YMaze: a triangular hub, arms rotated by 120 degrees,
+ * sliver-shaped connectors; envs/ymaze.py:28-83).  Same spec as above with the slab distances of an axis-aligned rectangle
+ * replaced by ray / edge-plane distances: for edge i with start p, unit direction dir and inward unit normal n (float32 of the
+ * state half's float64 values), a ray (o, d) leaves through it if den = fmaf(n.z, d.z, n.x d.x) < 0, at
+ * t = fmaf(n.z, p.z - o.z, n.x (p.x - o.x)) / den (one correctly rounded division); the exit edge is the first one, in edge
+ * order, with the smallest t; the crossing point's distance along the edge is hc = fmaf(dir.z, hz - p.z, dir.x (hx - p.x)) with
+ * (hx, hz) = fmaf(t, d, o), which is also the wall texture's u coordinate (Room._gen_static_data: seg_start runs from edge_p0).
+ * A room whose outline runs the other way round (the connector rooms connect_rooms builds between YMaze's hub and arms do:
+ * miniworld.py:826 lists their corners clockwise there) has all its polygons facing away from its inside - floor downwards,
+ * ceiling upwards, walls outwards - so with back-face culling on (miniworld.py:498-499) nothing of it is drawn for a viewer
+ * inside the world.  Geometrically such a connector has NEGATIVE width - YMaze's arms overlap the hub by a centimetre, the
+ * connector spans the overlap back to front - so the traversal by-passes it: a portal that leads into a culled connector leads
+ * on to the room behind the connector's other portal, and a culled room never holds the eye. */
+typedef struct { float px, pz, dx, dz, nx, nz, lo, hi, max_y; int nbr; } PEdge;
+typedef struct { int ne; float height; int wall_tex, floor_tex, ceil_tex, no_ceiling, culled; PEdge e[4]; } PRoom;
+
+static int build_prooms(MwoEnv *e, PRoom *pr) {
+    for (int i = 0; i < e->n_rooms; i++) {
+        Room *r = &e->rooms[i]; PRoom *o = &pr[i];
+        o->ne = r->n_edges; o->height = (float)r->wall_height;
+        o->wall_tex = r->wall_tex; o->floor_tex = r->floor_tex; o->ceil_tex = r->ceil_tex; o->no_ceiling = r->no_ceiling;
+        double cx = 0, cz = 0, inward = 0;
+        for (int k = 0; k < r->n_edges; k++) { cx += r->outline[k][0] / r->n_edges; cz += r->outline[k][2] / r->n_edges; }
+        for (int k = 0; k < r->n_edges; k++) inward += r->edge_norms[k][0] * (cx - r->outline[k][0]) + r->edge_norms[k][2] * (cz - r->outline[k][2]);
+        o->culled = inward < 0;   /* "inward" normals point away from the centroid: reversed winding */
+        for (int k = 0; k < r->n_edges; k++) {
+            PEdge *pe = &o->e[k];
+            pe->px = (float)r->outline[k][0]; pe->pz = (float)r->outline[k][2];
+            pe->dx = (float)r->edge_dirs[k][0]; pe->dz = (float)r->edge_dirs[k][2];
+            pe->nx = (float)r->edge_norms[k][0]; pe->nz = (float)r->edge_norms[k][2];
+            pe->lo = pe->hi = pe->max_y = 0; pe->nbr = -1;
+            if (r->n_portals[k] > 1) fail("render: at most one portal per edge");
+            if (r->n_portals[k] == 1) {
+                if (r->portals[k][0].min_y != 0) fail("render: portals start at the floor");
+                pe->lo = (float)r->portals[k][0].start; pe->hi = (float)r->portals[k][0].end; pe->max_y = (float)r->portals[k][0].max_y;
+                pe->nbr = r->nbr[k];
+                if (pe->nbr < 0) fail("render: portal without a neighbour room");
+            }
+        }
+    }
+    for (int i = 0; i < e->n_rooms; i++)   /* by-pass culled connectors */
+        for (int k = 0; k < pr[i].ne; k++) {
+            int c = pr[i].e[k].nbr;
+            if (c < 0 || !pr[c].culled || pr[i].culled) continue;
+            int onward = -1;
+            for (int q = 0; q < pr[c].ne; q++)
+                if (e->rooms[c].n_portals[q] == 1 && e->rooms[c].nbr[q] != i) onward = e->rooms[c].nbr[q];
+            if (onward < 0 || pr[onward].culled) fail("render: a culled connector must lead on to a regular room");
+            pr[i].e[k].nbr = onward;
+        }
+    return e->n_rooms;
+}
+
+static Hit trace_rooms_poly(const PRoom *pr, int n_rooms, int room, const float *o, const float *d) {
+    Hit h = {0, -1, -1, INFINITY};
+    if (room < 0) return h;
+    float iy = d[1] != 0 ? 1.0f / d[1] : 0.0f;
+    for (int iter = 0; iter < n_rooms + 1; iter++) {
+        const PRoom *r = &pr[room];
+        float ts = INFINITY; int s = -1;
+        for (int k = 0; k < r->ne; k++) {
+            const PEdge *pe = &r->e[k];
+            float den = fmaf(pe->nz, d[2], pe->nx * d[0]);
+            if (den < 0) {
+                float num = fmaf(pe->nz, pe->pz - o[2], pe->nx * (pe->px - o[0]));
+                float t = num / den;
+                if (t < ts) { ts = t; s = k; }
+            }
+        }
+        if (d[1] < 0) { float tf = (0.0f - o[1]) * iy; if (tf <= ts) { if (r->culled) return h; h.kind = 1; h.room = room; h.t = tf; return h; } }
+        if (d[1] > 0) {
+            float tc = (r->height - o[1]) * iy;
+            if (tc <= ts) { if (r->no_ceiling || r->culled) return h; h.kind = 2; h.room = room; h.t = tc; return h; }
+        }
+        if (!(ts < INFINITY)) return h;
+        const PEdge *pe = &r->e[s];
+        float hx = fmaf(ts, d[0], o[0]), hz = fmaf(ts, d[2], o[2]);
+        float hc = fmaf(pe->dz, hz - pe->pz, pe->dx * (hx - pe->px));
+        float y = fmaf(ts, d[1], o[1]);
+        if (pe->nbr >= 0 && pe->lo < hc && hc < pe->hi && 0.0f < y && y < pe->max_y) { room = pe->nbr; continue; }
+        if (r->culled) return h;
+        h.kind = 3; h.room = room; h.side = s; h.t = ts; return h;
+    }
+    return h;
+}
+
+static int surf_texcoord_poly(const PRoom *pr, const Hit *h, const float *o, const float *d, float *s, float *t) {
+    const PRoom *r = &pr[h->room];
+    float tt;
+    if (h->kind == 1 || h->kind == 2) {
+        float py = h->kind == 1 ? 0.0f : r->height;
+        if (d[1] == 0) return 0;
+        tt = (py - o[1]) / d[1];
+        if (!(tt > 0)) return 0;
+        int tex = h->kind == 1 ? r->floor_tex : r->ceil_tex;
+        float sc_s = (float)(512.0 / tex_width(tex)), sc_t = (float)(512.0 / tex_height(tex));
+        *s = (o[0] + tt * d[0]) * sc_s; *t = (o[2] + tt * d[2]) * sc_t;
+        return 1;
+    }
+    const PEdge *pe = &r->e[h->side];
+    float sc_s = (float)(512.0 / tex_width(r->wall_tex)), sc_t = (float)(512.0 / tex_height(r->wall_tex));
+    float den = fmaf(pe->nz, d[2], pe->nx * d[0]);
+    if (den == 0) return 0;
+    tt = fmaf(pe->nz, pe->pz - o[2], pe->nx * (pe->px - o[0])) / den;
+    if (!(tt > 0)) return 0;
+    float hx = o[0] + tt * d[0], hz = o[2] + tt * d[2], y = o[1] + tt * d[1];
+    float hc = fmaf(pe->dz, hz - pe->pz, pe->dx * (hx - pe->px));
+    *s = hc * sc_s; *t = y * sc_t;
+    return 1;
+}
+
 typedef struct { float pos[3], c, s, half[3], sy; } RBox;
 
 /* returns face index 0..5 (-x,+x,-y,+y,-z,+z in box-local axes) or -1; *t_out = entry t */
@@ -1307,8 +1422,10 @@ static int surf_texcoord(const RRoom *rr, const Hit *h, const float *o, const fl
 }
 
 void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
+    const int poly = e->task == MWO_YMAZE;   /* rooms with arbitrary edges: the polygon formulation */
     RRoom *rr = (RRoom *)malloc(sizeof(RRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));   /* per call: thread-safe */
-    int n_rooms = build_rrooms(e, rr);
+    PRoom *pr = (PRoom *)malloc(sizeof(PRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));
+    int n_rooms = poly ? build_prooms(e, pr) : build_rrooms(e, rr);
     /* camera: gluPerspective(fov_y, W/H, 0.04, 100), gluLookAt(cam_pos, cam_pos+cam_dir, +Y) */
     double cp[3], cd[3];
     camera(e, cp, cd);
@@ -1355,8 +1472,17 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
     }
     /* room containing the eye */
     int cam_room = -1;
-    for (int i = 0; i < n_rooms && cam_room < 0; i++)
-        if (c.eye[0] >= rr[i].min_x && c.eye[0] <= rr[i].max_x && c.eye[2] >= rr[i].min_z && c.eye[2] <= rr[i].max_z) cam_room = i;
+    for (int i = 0; i < n_rooms && cam_room < 0; i++) {
+        if (!poly) { if (c.eye[0] >= rr[i].min_x && c.eye[0] <= rr[i].max_x && c.eye[2] >= rr[i].min_z && c.eye[2] <= rr[i].max_z) cam_room = i; }
+        else {   /* first room, in creation order, whose every edge has the eye on its inner side (bounds inclusive) */
+            int in = !pr[i].culled;
+            for (int k = 0; k < pr[i].ne; k++) {
+                const PEdge *pe = &pr[i].e[k];
+                if (!(fmaf(pe->nz, c.eye[2] - pe->pz, pe->nx * (c.eye[0] - pe->px)) >= 0.0f)) in = 0;
+            }
+            if (in) cam_room = i;
+        }
+    }
     const float n_ = 0.04f, f_ = 100.0f;
     const float zA = (f_ + n_) / (f_ - n_), zB = (2.0f * f_ * n_) / (f_ - n_);
     for (int py = 0; py < H; py++)
@@ -1366,7 +1492,7 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
             for (int k = 0; k < 8; k++) {
                 float d[3];
                 make_ray(&c, cx + SAMPLE_X[k] * 0.0625f, cy + SAMPLE_Y[k] * 0.0625f, d);
-                hits[k] = trace_rooms(rr, n_rooms, cam_room, c.eye, d);
+                hits[k] = poly ? trace_rooms_poly(pr, n_rooms, cam_room, c.eye, d) : trace_rooms(rr, n_rooms, cam_room, c.eye, d);
                 for (int b = 0; b < e->n_boxes; b++) { /* entity order; a later box wins only when strictly nearer */
                     float tb; int fc = trace_box(&bxs[b], c.eye, d, &tb);
                     if (fc >= 0 && tb < hits[k].t) { hits[k].kind = 4; hits[k].t = tb; hits[k].room = b; hits[k].side = fc; }
@@ -1387,15 +1513,29 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
                 else if (h->kind == 4) { const float *lb = lit_boxes[h->room][h->side]; col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2]; }
                 else {
                     float s0, t0, s1, t1, s2, t2;
-                    int tex = h->kind == 1 ? rr[h->room].floor_tex : h->kind == 2 ? rr[h->room].ceil_tex : rr[h->room].wall_tex;
-                    const float *lit = h->kind == 1 ? lit_floor : h->kind == 2 ? lit_ceil : lit_wall[h->side];
-                    int okc = surf_texcoord(rr, h, c.eye, dc, &s0, &t0);
+                    int tex;
+                    const float *lit;
+                    float lit_edge[3];
+                    if (!poly) {
+                        tex = h->kind == 1 ? rr[h->room].floor_tex : h->kind == 2 ? rr[h->room].ceil_tex : rr[h->room].wall_tex;
+                        lit = h->kind == 1 ? lit_floor : h->kind == 2 ? lit_ceil : lit_wall[h->side];
+                    } else {
+                        tex = h->kind == 1 ? pr[h->room].floor_tex : h->kind == 2 ? pr[h->room].ceil_tex : pr[h->room].wall_tex;
+                        lit = h->kind == 1 ? lit_floor : lit_ceil;
+                        if (h->kind == 3) {   /* flat face with the edge's inward normal */
+                            float n[3] = {pr[h->room].e[h->side].nx, 0.0f, pr[h->room].e[h->side].nz};
+                            lit_color(&L, n, white, lit_edge);
+                            lit = lit_edge;
+                        }
+                    }
+#define SURF_TC(ray, ps, pt) (poly ? surf_texcoord_poly(pr, h, c.eye, ray, ps, pt) : surf_texcoord(rr, h, c.eye, ray, ps, pt))
+                    int okc = SURF_TC(dc, &s0, &t0);
                     int valid = 1;
                     if (!okc) { /* centre ray misses the plane: shade at the sample's own hit point */
                         float d[3]; make_ray(&c, cx + SAMPLE_X[k] * 0.0625f, cy + SAMPLE_Y[k] * 0.0625f, d);
-                        surf_texcoord(rr, h, c.eye, d, &s0, &t0); valid = 0; s1 = s2 = s0; t1 = t2 = t0;
+                        SURF_TC(d, &s0, &t0); valid = 0; s1 = s2 = s0; t1 = t2 = t0;
                     } else {
-                        valid = surf_texcoord(rr, h, c.eye, dx, &s1, &t1) && surf_texcoord(rr, h, c.eye, dy, &s2, &t2);
+                        valid = SURF_TC(dx, &s1, &t1) && SURF_TC(dy, &s2, &t2);
                     }
                     float texel[3];
                     sample_texture(tex, s0, t0, s1, t1, s2, t2, valid, texel);
@@ -1424,6 +1564,7 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
             }
         }
     free(rr);
+    free(pr);
 }
 
 /* ====================================================================== bench helper */
