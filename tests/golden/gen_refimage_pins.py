@@ -34,7 +34,10 @@ CASES = {
     "hallway": ("Hallway", (-0.02, -0.03), 1, "hallway_0.jpg"),
     "oneroom": ("OneRoom", (0.63, 8.42), 30, "oneroom_0.jpg"),
     "tmaze": ("TMaze", (3.41, -0.31), 359, "tmaze_0.jpg"),
+    # ymaze_0.jpg shows the TOP view in the main area; only its 80x60 observation inset is the path pinned here
+    "ymaze": ("YMaze", (-5.64, 0.48), 5, "ymaze_0.jpg"),
 }
+INSET_ONLY = {"ymaze"}
 # window = 24-pixel title bar + 1-pixel frame left / right / below around the 1056x600 client area (the crop that
 # minimises the fit residual of all three screenshots; one pixel off in either direction doubles it)
 MAIN = (slice(24, 624), slice(1, 801))       # the 800x600 human view inside the 1058x625 screenshot
@@ -64,7 +67,7 @@ def fit_pose(task, hx, hz, hang, ref, mask):
     from scipy.optimize import minimize
     from oracle import oracle as O
     H, W, _ = ref.shape
-    e = O.OracleEnv(task, seed=1, obs_width=W, obs_height=H)
+    e = O.OracleEnv(task, seed=1, obs_width=W, obs_height=H, task_args=[0, 0, 0, 0] if task == "YMaze" else None)
     e.reset(render=False)
     a0 = math.radians(hang + 0.5)
     e.set_box(0, hx - 0.6 * math.cos(a0), hz + 0.6 * math.sin(a0), 0.0)   # behind the camera: not in view
@@ -92,8 +95,12 @@ def main():
     for name, (task, (hx, hz), hang, fn) in CASES.items():
         im = np.asarray(Image.open(os.path.join(IMAGES, fn)).convert("RGB")).astype(np.float64)
         main_view = im[MAIN]
-        ref400 = box_down(main_view, 2)
-        cost, pose = fit_pose(task, hx, hz, hang, ref400, non_box_mask(ref400, 5))
+        inset_f = np.asarray(Image.fromarray(im[INSET].astype(np.uint8)).resize((80, 60), Image.BOX)).astype(np.float64)
+        if name in INSET_ONLY:
+            cost, pose = fit_pose(task, hx, hz, hang, inset_f, non_box_mask(inset_f, 2))
+        else:
+            ref400 = box_down(main_view, 2)
+            cost, pose = fit_pose(task, hx, hz, hang, ref400, non_box_mask(ref400, 5))
         main160 = box_down(main_view, 5)
         main80 = box_down(main_view, 10)
         inset = np.asarray(Image.fromarray(im[INSET].astype(np.uint8)).resize((80, 60), Image.BOX)).astype(np.float64)
@@ -108,7 +115,7 @@ def main():
         out = os.path.join(HERE, "refimg_%s.npz" % name)
         np.savez_compressed(
             out, task=task, hud_pos=np.array([hx, hz]), hud_angle=hang, fit_pose=np.array(pose), fit_cost=cost,
-            main160=np.rint(main160).astype(np.uint8), main80=np.rint(main80).astype(np.uint8),
+            main160=np.rint(main160).astype(np.uint8), main80=np.rint(main80).astype(np.uint8), inset_only=name in INSET_ONLY,
             inset80=np.rint(inset).astype(np.uint8), mask160=non_box_mask(main160, 3), mask80=non_box_mask(main80, 2),
             mask_inset=non_box_mask(inset, 2), box_faces=faces)
         print("%-8s pose %.4f %.4f %.3f deg  cost %.2f  box faces %s -> %s" %

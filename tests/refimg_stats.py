@@ -12,8 +12,8 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ("hallway", "oneroom", "tmaze")
-ENV_IDS = {"hallway": "MiniWorld-Hallway-v0", "oneroom": "MiniWorld-OneRoom-v0", "tmaze": "MiniWorld-TMaze-v0"}
+CASES = ("hallway", "oneroom", "tmaze", "ymaze")   # ymaze: the observation inset only (its main area shows the top view)
+ENV_IDS = {"hallway": "MiniWorld-Hallway-v0", "oneroom": "MiniWorld-OneRoom-v0", "tmaze": "MiniWorld-TMaze-v0", "ymaze": "MiniWorld-YMaze-v0"}
 
 # (fixture key, mask key, width, height, block edge, tolerances)
 #   mean_abs   mean over unmasked pixels of the largest channel difference
@@ -35,6 +35,11 @@ VIEWS = (
 def load(name):
     d = np.load(os.path.join(GOLDEN, "refimg_%s.npz" % name))
     return {k: d[k] for k in d.files}
+
+
+def views(fx):
+    """the views a fixture pins: all three, or the observation inset alone"""
+    return [v for v in VIEWS if v[0] == "inset80"] if bool(fx.get("inset_only", False)) else list(VIEWS)
 
 
 def hidden_box_pose(fx):

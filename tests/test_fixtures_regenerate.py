@@ -44,6 +44,7 @@ def test_reference_image_pins_round_trip(tmp_path):
         fx = np.load(os.path.join(GOLDEN, "refimg_%s.npz" % name))
         im = np.asarray(Image.open(os.path.join(G.IMAGES, fn)).convert("RGB")).astype(np.float64)
         main_view = im[G.MAIN]
+        assert bool(fx["inset_only"]) == (name in G.INSET_ONLY)
         assert np.array_equal(np.rint(G.box_down(main_view, 5)).astype(np.uint8), fx["main160"]), name
         assert np.array_equal(np.rint(G.box_down(main_view, 10)).astype(np.uint8), fx["main80"]), name
         assert np.array_equal(G.non_box_mask(G.box_down(main_view, 5), 3), fx["mask160"]), name

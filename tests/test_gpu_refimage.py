@@ -32,7 +32,7 @@ def _render(fx, env_id, W, H, box=None, depth=False):
 def test_hip_render_matches_the_reference_screenshot(name):
     fx = RS.load(name)
     assert RS.pose_inside_hud_interval(fx)
-    for key, mkey, W, H, block, tol in RS.VIEWS:
+    for key, mkey, W, H, block, tol in RS.views(fx):
         img, _ = _render(fx, RS.ENV_IDS[name], W, H)
         RS.check(RS.stats(img, fx[key], fx[mkey], block), tol, "%s/%s" % (name, key))
 
