@@ -12,11 +12,12 @@ LIB_PATH = os.environ.get("MWB_LIB") or os.path.join(HERE, "libmwbatch.so")   # 
 
 NPARAM = 13
 ROOM_WORDS = 24
+POLY_ROOM_WORDS = 52   # MWB_TASK_YMAZE (include/miniworld_batch.h)
 ABI_VERSION = 4
 MT_WORDS = 625
 
 TASK_IDS = {"Hallway": 0, "OneRoom": 1, "FourRooms": 2, "Maze": 3, "TMaze": 4, "TMazeTwoBox": 5,
-            "SimToRealGoTo": 6, "SimToRealPush": 7, "PutNext": 8}
+            "SimToRealGoTo": 6, "SimToRealPush": 7, "PutNext": 8, "YMaze": 9}
 LAYOUT_HWC, LAYOUT_CWH = 0, 1
 
 
@@ -53,7 +54,7 @@ EXPORTS = [
     "mwb_create", "mwb_destroy", "mwb_last_error", "mwb_abi_version", "mwb_set_texture", "mwb_seed", "mwb_reset",
     "mwb_step", "mwb_render", "mwb_get_outputs", "mwb_get_state", "mwb_set_agent", "mwb_intersect",
     "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read", "mwb_stack_enable", "mwb_stack_update", "mwb_check", "mwb_seed_key",
-    "mwb_set_task_state", "mwb_set_domain_rand", "mwb_num_textures", "mwb_debug_wg_times", "mwb_set_state", "mwb_num_boxes",
+    "mwb_set_task_state", "mwb_set_domain_rand", "mwb_num_textures", "mwb_debug_wg_times", "mwb_set_state", "mwb_num_boxes", "mwb_room_words",
 ]
 
 _lib = None
@@ -88,6 +89,7 @@ def load():
     L.mwb_get_state.argtypes = [vp, i32, i32, ctypes.POINTER(MwbState)]
     L.mwb_set_state.argtypes = [vp, i32, i32, ctypes.POINTER(MwbState)]
     L.mwb_num_boxes.argtypes = [vp]
+    L.mwb_room_words.argtypes = [vp]
     L.mwb_set_agent.argtypes = [vp, i32, i32, vp, vp, vp]
     L.mwb_set_task_state.argtypes = [vp, i32, i32, vp, vp, vp]
     L.mwb_set_domain_rand.argtypes = [vp, i32]

@@ -53,6 +53,10 @@ ENV_SPECS = {
     "MiniWorld-SimToRealPush-v0": ("SimToRealPush", [], 0, lambda: sim_to_real_params(push=True), True),
     # several boxes + the carry actions, envs/putnext.py
     "MiniWorld-PutNext-v0": ("PutNext", [12], 0, None, None),
+    # rooms that are general convex polygons, envs/ymaze.py; task_args {goal given, x, z}
+    "MiniWorld-YMaze-v0": ("YMaze", [0, 0, 0], 0, None, None),
+    "MiniWorld-YMazeLeft-v0": ("YMaze", [1, 3.9, -7.0], 0, None, None),    # ymaze.py:96-98
+    "MiniWorld-YMazeRight-v0": ("YMaze", [1, 3.9, 7.0], 0, None, None),    # ymaze.py:100-102
 }
 
 
@@ -151,7 +155,7 @@ class BatchedMiniWorld:
         # narrow it (PutNext: miniworld.py:470)
         self.n_actions = 4 if task == "SimToRealPush" else 8 if task == "PutNext" else 3
         self.has_features = task == "TMazeTwoBox" and ta[0] != 0
-        self.has_goal_pos = task in ("TMaze", "TMazeTwoBox")
+        self.has_goal_pos = task in ("TMaze", "TMazeTwoBox", "YMaze")   # tmaze.py:66,206, ymaze.py:92
         self.max_episode_steps = self._max_steps(task, ta, max_episode_steps)
         if seed is not None:
             self.seed(seed)
@@ -161,7 +165,7 @@ class BatchedMiniWorld:
         if mes:
             return int(mes)
         return {"Hallway": 250, "OneRoom": 180, "FourRooms": 250, "TMaze": 280, "TMazeTwoBox": 280,
-                "SimToRealGoTo": 100, "SimToRealPush": 150, "PutNext": 250}.get(task) or int(ta[0] or 8) * int(ta[1] or 8) * 24
+                "SimToRealGoTo": 100, "SimToRealPush": 150, "PutNext": 250, "YMaze": 280}.get(task) or int(ta[0] or 8) * int(ta[1] or 8) * 24
 
     def _load_textures(self):
         from PIL import Image
@@ -317,7 +321,9 @@ class BatchedMiniWorld:
         return r.value
 
     def get_geometry(self, env, max_rooms=512, max_segs=2048):
-        rooms = np.zeros((max_rooms, _lib.ROOM_WORDS), np.float32)
+        """(rooms [n_rooms, mwb_room_words] f32, segs [n_segs, 4] f64) of one env as the kernels see them: the rectangle
+        room table, or for YMaze the polygon one (layouts: include/miniworld_batch.h at mwb_get_geometry)."""
+        rooms = np.zeros((max_rooms, int(self.L.mwb_room_words(self.h))), np.float32)
         segs = np.zeros((max_segs, 4), np.float64)
         nr, ns = ctypes.c_int(), ctypes.c_int()
         _lib.check(self.L.mwb_get_geometry(self.h, env, rooms.ctypes.data_as(ctypes.c_void_p), max_rooms,

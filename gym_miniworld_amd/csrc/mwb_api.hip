@@ -193,7 +193,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     if (!cfg || !out) return set_err(MWB_EINVAL, "mwb_create: null argument");
     if (cfg->abi_version != MWB_ABI_VERSION) return set_err(MWB_EINVAL, "mwb_create: abi_version mismatch");
     if (cfg->num_envs <= 0) return set_err(MWB_EINVAL, "mwb_create: num_envs must be > 0");
-    if (cfg->task < 0 || cfg->task > MWB_TASK_PUTNEXT) return set_err(MWB_EINVAL, "mwb_create: unknown task");
+    if (cfg->task < 0 || cfg->task > MWB_TASK_YMAZE) return set_err(MWB_EINVAL, "mwb_create: unknown task");
     if (cfg->obs_width <= 0 || cfg->obs_height <= 0 || cfg->obs_width > 1024 || cfg->obs_height > 1024)
         return set_err(MWB_EINVAL, "mwb_create: bad observation size");
     if (cfg->layout != MWB_LAYOUT_HWC && cfg->layout != MWB_LAYOUT_CWH) return set_err(MWB_EINVAL, "mwb_create: bad layout");
@@ -211,7 +211,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     d.want_depth = cfg->want_depth ? 1 : 0; d.layout = cfg->layout; d.domain_rand = cfg->domain_rand ? 1 : 0;
     d.auto_reset = cfg->no_auto_reset ? 0 : 1;
     { const char *dbg = getenv("MWB_DEBUG"); d.debug_flags = dbg ? atoi(dbg) : 0; }
-    static const double dflt[9][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}, {12, 0, 0, 0}};
+    static const double dflt[10][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}, {12, 0, 0, 0}, {0, 0, 0, 0}};
     const bool sim2real = cfg->task == MWB_TASK_SIM2REAL_GOTO || cfg->task == MWB_TASK_SIM2REAL_PUSH;
     d.n_boxes = (cfg->task == MWB_TASK_TMAZE_TWOBOX || cfg->task == MWB_TASK_SIM2REAL_PUSH) ? 2 : cfg->task == MWB_TASK_PUTNEXT ? 6 : 1;
     d.frame_words = MWB_FRAME_WORDS_FOR(d.n_boxes);
@@ -223,6 +223,8 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
         d.split_envs = split < 0 ? 0 : (split > cfg->num_envs ? cfg->num_envs : split);
     }
     d.no_ceiling = sim2real ? 1 : 0;
+    d.poly = cfg->task == MWB_TASK_YMAZE ? 1 : 0;
+    d.room_words = d.poly ? MWB_POLY_ROOM_WORDS : MWB_ROOM_WORDS;
     d.agent_radius = sim2real ? 0.11 : 0.4;   // simtorealgoto.py:50 / entity.py:451
     for (int i = 0; i < 4; i++) d.task_args[i] = cfg->task_args[i] != 0 ? cfg->task_args[i] : dflt[cfg->task][i];
     int mes = cfg->max_episode_steps;
@@ -234,6 +236,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
         else if (d.task == MWB_TASK_SIM2REAL_GOTO) mes = 100;   // simtorealgoto.py:30
         else if (d.task == MWB_TASK_SIM2REAL_PUSH) mes = 150;   // simtorealpush.py:29
         else if (d.task == MWB_TASK_PUTNEXT) mes = 250;   // putnext.py:16
+        else if (d.task == MWB_TASK_YMAZE) mes = 280;     // ymaze.py:21
         else mes = (int)d.task_args[0] * (int)d.task_args[1] * 24;
     }
     d.max_episode_steps = mes;
@@ -248,6 +251,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
         if (d.task_args[3] < 0 || d.task_args[3] > 9e15) { delete h; return set_err(MWB_EINVAL, "TMaze: bad sub_task_length"); }
         d.R_max = 2; d.S_max = 8;
     } else if (sim2real) { d.R_max = 1; d.S_max = 4; }
+    else if (d.task == MWB_TASK_YMAZE) { d.R_max = 6; d.S_max = 24; }   // corridor, hub, two arms, two connectors (the third pair of portals meets directly)
     else if (d.task == MWB_TASK_PUTNEXT) { if (!(d.task_args[0] >= 2)) { delete h; return set_err(MWB_EINVAL, "PutNext: size >= 2"); } d.R_max = 1; d.S_max = 4; }
     else {
         int rows = (int)d.task_args[0], cols = (int)d.task_args[1];
@@ -261,7 +265,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N * d.n_boxes); A(d.box_z, N * d.n_boxes); A(d.box_y, N * d.n_boxes); A(d.box_dir, N * d.n_boxes); A(d.carrying, N);
     A(d.box_color, N * d.n_boxes * 3); A(d.box_size, N * d.n_boxes); A(d.goal_dist, N); A(d.episode_count, N); A(d.task_step_count, N); A(d.goal_idx, N); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
     A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.reset_set, N); A(d.reset_list, N); A(d.reset_count, (size_t)1);
-    A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * MWB_ROOM_WORDS); A(d.segs, N * d.S_max * 4); A(d.frame, N * d.frame_words);
+    A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * d.room_words); A(d.segs, N * d.S_max * 4); A(d.frame, N * d.frame_words);
     A(d.obs, N * d.W * d.H * 3);
     if (d.want_depth) { A(d.depth, N * d.W * d.H); }
     {   // the small per-step outputs share one allocation (one D2H copy for a host-side consumer); 16-byte aligned parts
@@ -605,6 +609,7 @@ static int fetch(T *dst, const T *src_dev, size_t first, size_t count, size_t st
 }
 
 extern "C" int mwb_num_boxes(mwb_handle *h) { return h ? h->dev.n_boxes : 0; }
+extern "C" int mwb_room_words(mwb_handle *h) { return h ? h->dev.room_words : 0; }
 
 // box arrays live as [B][N] planes on the device and as [count][B](x width) rows in mwb_state
 static int fetch_boxes(double *dst, const double *src_dev, size_t N, int B, size_t first, size_t count, size_t width) {
@@ -817,7 +822,7 @@ extern "C" int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_ro
     HIP_TRY(hipMemcpy(n_segs, d.n_segs + env, sizeof(int), hipMemcpyDeviceToHost));
     if (rooms) {
         int n = *n_rooms < max_rooms ? *n_rooms : max_rooms;
-        if (n > 0) HIP_TRY(hipMemcpy(rooms, d.rooms + (size_t)env * d.R_max * MWB_ROOM_WORDS, (size_t)n * MWB_ROOM_WORDS * 4, hipMemcpyDeviceToHost));
+        if (n > 0) HIP_TRY(hipMemcpy(rooms, d.rooms + (size_t)env * d.R_max * d.room_words, (size_t)n * d.room_words * 4, hipMemcpyDeviceToHost));
     }
     if (segs) {   // device layout is transposed: element (i, c) of env e at segs[(i*4 + c) * N + e]
         int n = *n_segs < max_segs ? *n_segs : max_segs;

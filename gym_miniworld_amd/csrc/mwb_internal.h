@@ -44,6 +44,17 @@
 #define RS_UORG 3
 #define RW_NO_NBR 0xFFFFu
 
+// polygon room table (MWB_TASK_YMAZE): MWB_POLY_ROOM_WORDS = 52 f32 words per room
+//   0 wall height   1 textures (as RW_TEX, no flip bits)   2 n_edges | culled << 8   3 pad
+//   4 + 12 k, edge k (a missing 4th edge has n = (0, 0): never an exit, never excludes the eye):
+//     p.x p.z dir.x dir.z | n.x n.z lo hi | max_y nbr 0 0   nbr: room behind the portal as int bits, -1 none; a portal into a
+//     "culled" connector (reversed winding, nothing of it is drawn) points on to the room behind the connector
+#define PW_HEIGHT 0
+#define PW_TEX 1
+#define PW_FLAGS 2
+#define PW_EDGE0 4
+#define PW_EDGE_WORDS 12
+
 // frame-constant word offsets
 #define FC_EYE 0
 #define FC_F 3
@@ -55,6 +66,9 @@
 #define FC_LIT_FLOOR 17
 #define FC_LIT_CEIL 20
 #define FC_LIT_WALL 23   // 4 x 3
+#define FC_LIGHT_DIR 23  // polygon rooms (d.poly): the light itself instead of the four axis-aligned wall colours -
+#define FC_LIGHT_AMB 26  //   a wall's colour is computed from its edge normal when it is shaded
+#define FC_LIGHT_DIF 29
 #define FC_BOX_IN_VIEW 35      // != 0 if some box's footprint-inflated sphere can meet the view cone
 // per-box block of FC_BOX_STRIDE words starting at FC_LIT_BOX; box b at + b * FC_BOX_STRIDE
 #define FC_BOX_STRIDE 34
@@ -88,6 +102,8 @@ struct MwbDev {
     int frame_words;   // MWB_FRAME_WORDS_FOR(n_boxes)
     int n_tex;         // leading texture slots the task can draw (7, or MWB_NUM_TEXTURES for the sim-to-real rinks)
     int split_envs;    // the last split_envs envs of a bulk render launch are rendered by two half-frame workgroups each
+    int poly;          // rooms are general convex polygons (YMaze): polygon room table, POLY render kernels
+    int room_words;    // f32 words per room of d.rooms: MWB_ROOM_WORDS or MWB_POLY_ROOM_WORDS
     int no_ceiling;    // the task's rooms have no ceiling (sim-to-real rinks): selects the NOCEIL render kernels
     double agent_radius;   // entity.py:451 (0.4), 0.11 in the sim-to-real rinks
     int debug_flags;   // MWB_DEBUG env var at mwb_create: bit0 = resolve every pixel with the full 8-sample path
@@ -111,7 +127,7 @@ struct MwbDev {
     int32_t *reset_list;    // [N] the same envs as a compact list (order arbitrary) ...
     int32_t *reset_count;   // [1] ... and its length; zeroed by clear_list_kernel at the end of every pass
     uint32_t *rng;          // [N][625]
-    float *rooms;           // [N][R_max][MWB_ROOM_WORDS]
+    float *rooms;           // [N][R_max][room_words]
     double *segs;           // [S_max][4][N]
     float *frame;           // [N][frame_words]
     const uint32_t *texels;

@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
             }
         } else {
             if (near[0]) { r += rw; done = 1; }
-            if (d.task == MWB_TASK_TMAZE) { d.goal_pos[e * 3] = bx[0]; d.goal_pos[e * 3 + 1] = 0.0; d.goal_pos[e * 3 + 2] = bz[0]; }
+            if (d.task == MWB_TASK_TMAZE || d.task == MWB_TASK_YMAZE) { d.goal_pos[e * 3] = bx[0]; d.goal_pos[e * 3 + 1] = 0.0; d.goal_pos[e * 3 + 2] = bz[0]; }
         }
     }
     d.reward64[e] = r; d.reward[e] = (float)r; d.done[e] = (uint8_t)done; d.ep_steps[e] = sc;
@@ -404,6 +404,20 @@ __global__ void mark_reset_kernel(MwbDev d, const uint8_t *__restrict__ mask) {
     if (regen) d.reset_list[atomicAdd(d.reset_count, 1)] = e;
 }
 
+// gen_rot_matrix (math.py:9-23) and numpy's row-vector x matrix product as the reference's np.dot evaluates it
+__device__ __forceinline__ void rot_matrix(double axx, double axy, double axz, double angle, double *m) {
+    double n = sqrt(axx * axx + axy * axy + axz * axz);
+    axx /= n; axy /= n; axz /= n;
+    double a = ref_cos(angle / 2.0), s = ref_sin(angle / 2.0);
+    double b = -axx * s, c = -axy * s, dd = -axz * s;
+    m[0] = a * a + b * b - c * c - dd * dd; m[1] = 2 * (b * c - a * dd); m[2] = 2 * (b * dd + a * c);
+    m[3] = 2 * (b * c + a * dd); m[4] = a * a + c * c - b * b - dd * dd; m[5] = 2 * (c * dd - a * b);
+    m[6] = 2 * (b * dd - a * c); m[7] = 2 * (c * dd + a * b); m[8] = a * a + dd * dd - b * b - c * c;
+}
+__device__ __forceinline__ void vec_mat(const double *v, const double *m, double *o) {
+    for (int j = 0; j < 3; j++) o[j] = (v[0] * m[j] + v[1] * m[3 + j]) + v[2] * m[6 + j];
+}
+
 // ================================================================================= reset kernel
 // World generation.  One wave per environment; all 64 lanes run the same sequential logic on
 // identical values (the RNG stream is inherently serial) and split the wide parts: the MT19937
@@ -417,6 +431,7 @@ struct alignas(16) WRoom {
     double edx[4], edz[4], elen[4];   // edge direction (p1 - p0) / norm and length, computed once
     int n_port[4], nbr[4];
     int tex_fam[3], tex_id[3];      // wall, floor, ceil
+    int ne, pad_;                   // num_walls: 4, or 3 for YMaze's triangular hub
 };
 
 enum { TEXF_FLOOR_TILES_BW = 0, TEXF_CONCRETE, TEXF_CONCRETE_TILES, TEXF_BRICK_WALL,
@@ -436,19 +451,23 @@ struct WorldGen {
     bool fail;
 
     // Room.__init__, miniworld.py:75-138
-    __device__ int add_room(const double *ox, const double *oz, double height, int wall_fam, int floor_fam, int ceil_fam) {
+    __device__ int add_room(const double *ox, const double *oz, double height, int wall_fam, int floor_fam, int ceil_fam, int ne = 4) {
         WRoom &r = rooms[n_rooms];
         double mnx = ox[0], mxx = ox[0], mnz = oz[0], mxz = oz[0];
+        r.ne = ne;
         for (int i = 0; i < 4; i++) {
-            r.ox[i] = ox[i]; r.oz[i] = oz[i];
-            mnx = fmin(mnx, ox[i]); mxx = fmax(mxx, ox[i]); mnz = fmin(mnz, oz[i]); mxz = fmax(mxz, oz[i]);
+            const int q = i < ne ? i : 0;   // a triangle's unused 4th slot repeats corner 0 (never read as an edge)
+            r.ox[i] = ox[q]; r.oz[i] = oz[q];
+            mnx = fmin(mnx, ox[q]); mxx = fmax(mxx, ox[q]); mnz = fmin(mnz, oz[q]); mxz = fmax(mxz, oz[q]);
             r.n_port[i] = 0; r.nbr[i] = -1;
         }
         r.min_x = mnx; r.max_x = mxx; r.min_z = mnz; r.max_z = mxz;
         r.area = (mxx - mnx) * (mxz - mnz);
         for (int e = 0; e < 4; e++) {   // edge direction as Room.__init__ / add_portal compute it
-            double ex = ox[(e + 1) & 3] - ox[e], ez = oz[(e + 1) & 3] - oz[e];
+            const int e1 = e + 1 < ne ? e + 1 : 0;
+            double ex = r.ox[e1] - r.ox[e], ez = r.oz[e1] - r.oz[e];
             double len = sqrt((ex * ex + 0.0) + ez * ez);
+            if (e >= ne) { ex = 1; ez = 0; len = 1; }
             r.edx[e] = ex / len; r.edz[e] = ez / len; r.elen[e] = len;
         }
         r.height = height;
@@ -463,6 +482,13 @@ struct WorldGen {
     // edge direction as Room.__init__ / add_portal compute it: (p1 - p0) / norm
     __device__ __forceinline__ void edge(const WRoom &r, int e, double &dx, double &dz, double &len) const {
         dx = r.edx[e]; dz = r.edz[e]; len = r.elen[e];
+    }
+    // edge_norms = -cross(edge_dir, Y), normalised (miniworld.py:119-120): (dz, 0, -dx) / its norm - exactly (dz, -dx) for
+    // the axis-aligned edges of the rectangle tasks, one more rounding for YMaze's rotated arms
+    __device__ __forceinline__ void edge_normal(const WRoom &r, int e, double &nx, double &nz) const {
+        const double ex = r.edz[e], ez = -r.edx[e];
+        const double nn = sqrt((ex * ex + 0.0) + ez * ez);
+        nx = ex / nn; nz = ez / nn;
     }
     // Room.add_portal, miniworld.py:140-218; mode 0 start/end, 1 min_x/max_x, 2 min_z/max_z
     __device__ void add_portal(int ri, int e, int mode, double a, double b, bool has_max_y, double max_y_in,
@@ -492,13 +518,13 @@ struct WorldGen {
         int idx_a = -1, idx_b = -1;
         {
             const int ci = (lane >> 2) & 3, cj = lane & 3;
-            double adx = rooms[ia].edx[ci], adz = rooms[ia].edz[ci], bdx = rooms[ib].edx[cj], bdz = rooms[ib].edz[cj];
-            // edge_norms = -cross(edge_dir, Y) = (dz, 0, -dx) (unit for axis-aligned edges)
-            double nax = adz, naz = -adx, nbx = bdz, nbz = -bdx;
+            double nax, naz, nbx, nbz;
+            edge_normal(rooms[ia], ci, nax, naz);
+            edge_normal(rooms[ib], cj, nbx, nbz);
             double dotn = (nax * nbx + 0.0) + naz * nbz;
             double ddx = rooms[ib].ox[cj] - rooms[ia].ox[ci], ddz = rooms[ib].oz[cj] - rooms[ia].oz[ci];
             double dd = (nax * ddx + 0.0) + naz * ddz;
-            bool okc = lane < 16 && !(dotn > -0.9) && !(dd > 0.05);
+            bool okc = lane < 16 && ci < rooms[ia].ne && cj < rooms[ib].ne && !(dotn > -0.9) && !(dd > 0.05);
             unsigned long long m = __ballot(okc);
             if (m) { int first = __ffsll((long long)m) - 1; idx_a = first >> 2; idx_b = first & 3; }
         }
@@ -594,7 +620,7 @@ struct WorldGen {
         __syncthreads();
         for (int i = lane; i < n_rooms; i += WAVE) {   // segments per room, lane-parallel
             int c = 0;
-            for (int e = 0; e < 4; e++) c += edge_segs(rooms[i], e, nullptr);
+            for (int e = 0; e < rooms[i].ne; e++) c += edge_segs(rooms[i], e, nullptr);
             seg_off[i] = c;
         }
         __syncthreads();
@@ -611,7 +637,7 @@ struct WorldGen {
         __syncthreads();
         for (int i = lane; i < n_rooms && !fail; i += WAVE) {
             int o = seg_off[i];
-            for (int e = 0; e < 4; e++) o += edge_segs(rooms[i], e, segs + o * 4);
+            for (int e = 0; e < rooms[i].ne; e++) o += edge_segs(rooms[i], e, segs + o * 4);
         }
         __syncthreads();
         double sum = pairwise_area_sum(0, n_rooms);
@@ -675,10 +701,9 @@ struct WorldGen {
             double pz = rng.uniform(lz + radius, hz - radius);
             // Room.point_inside, miniworld.py:220-232
             bool inside = true;
-            for (int e = 0; e < 4; e++) {
-                double dx, dz, len;
-                edge(r, e, dx, dz, len);
-                double nx = dz, nz = -dx;
+            for (int e = 0; e < r.ne; e++) {
+                double nx, nz;
+                edge_normal(r, e, nx, nz);
                 double dot = (nx * (px - r.ox[e]) + 0.0) + nz * (pz - r.oz[e]);
                 if (!(dot > 0)) inside = false;
             }
@@ -840,6 +865,42 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         }
         o.n_others = 6;
         w.place_entity_ex(arad, o, ag_x, ag_z, ag_dir);
+    } else if (d.task == MWB_TASK_YMAZE) {   // envs/ymaze.py:28-83
+        const double mox[4] = {-9.15, -9.15, -1.15, -1.15}, moz[4] = {-2, 2, 2, -2};
+        w.add_room(mox, moz, 2.74, TEXF_CONCRETE, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES);
+        const double hox[4] = {-1.15, -1.15, 2.31, 0}, hoz[4] = {-2, 2, 0, 0};   // the hub: a triangle
+        w.add_room(hox, hoz, 2.74, TEXF_CONCRETE, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES, 3);
+        for (int arm = 0; arm < 2; arm++) {   // np.dot(main_outline, gen_rot_matrix(Y_VEC, -+120 deg))
+            double m[9], ox[4], oz[4];
+            rot_matrix(0, 1, 0, (arm == 0 ? -120 : 120) * (3.141592653589793 / 180), m);
+            for (int i = 0; i < 4; i++) {
+                const double v[3] = {mox[i], 0, moz[i]};
+                double out[3];
+                vec_mat(v, m, out);
+                ox[i] = out[0]; oz[i] = out[2];
+            }
+            w.add_room(ox, oz, 2.74, TEXF_CONCRETE, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES);
+        }
+        w.connect_rooms(0, 1, 2, -2, 2, false, 0);
+        w.connect_rooms(2, 1, 2, -1.995, 0, false, 0);
+        w.connect_rooms(3, 1, 2, 0, 1.995, false, 0);
+        const double arm2_min_z = rooms[2].min_z, arm3_max_z = rooms[3].max_z;
+        // `if self.rand.bool():` (ymaze.py:69) comes before the first place_entity, i.e. before the texture draws
+        const bool random_arm = d.task_args[0] == 0;
+        const bool left_arm = random_arm && w.rng.randint(0, 2) == 0;
+        w.gen_static_data(dr, d.S_max);
+        WorldGen::PlaceOpt o;
+        if (!random_arm) {   // goal_pos given (YMazeLeft / YMazeRight, ymaze.py:97-103): min == max, room drawn at random
+            o.has_min_x = o.has_max_x = o.has_min_z = o.has_max_z = true;
+            o.min_x = o.max_x = d.task_args[1]; o.min_z = o.max_z = d.task_args[2];
+        } else if (left_arm) { o.room = 2; o.has_max_z = true; o.max_z = arm2_min_z + 2.5; }
+        else { o.room = 3; o.has_min_z = true; o.min_z = arm3_max_z - 2.5; }
+        w.place_entity_ex(brad, o, box_x, box_z, box_dir);
+        WorldGen::PlaceOpt a;
+        a.room = 0; a.has_dir = true;
+        a.dir = w.rng.uniform(-3.141592653589793 / 4, 3.141592653589793 / 4);
+        a.n_others = 1; a.other_radius = brad; a.other_x[0] = box_x; a.other_z[0] = box_z;
+        w.place_entity_ex(arad, a, ag_x, ag_z, ag_dir);
     } else if (d.task == MWB_TASK_HALLWAY) {   // envs/hallway.py:25-42
         double length = d.task_args[0];
         int r = w.add_rect_room(-1, -1 + length, -2, 2, TEXF_CONCRETE);
@@ -967,8 +1028,54 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         d.n_segs[e] = w.n_segs;
     }
     for (int i = lane; i < w.n_segs * 4; i += WAVE) d.segs[(size_t)i * d.N + e] = segs[i];   // transposed, see step_kernel
-    float *grooms = d.rooms + (size_t)e * d.R_max * MWB_ROOM_WORDS;
-    for (int ri = lane; ri < w.n_rooms; ri += WAVE) {
+    float *grooms = d.rooms + (size_t)e * d.R_max * d.room_words;
+    // A room whose outline runs the other way round (the connectors connect_rooms builds between YMaze's hub and arms:
+    // miniworld.py:826 lists their corners clockwise there) has every polygon facing away from its inside - with back-face
+    // culling on (miniworld.py:498-499) nothing of it is drawn.  Test: the "inward" normals point away from the centroid.
+    auto culled = [&](const WRoom &r) {
+        double cx = 0, cz = 0, inward = 0;
+        for (int k = 0; k < r.ne; k++) { cx += r.ox[k] / r.ne; cz += r.oz[k] / r.ne; }
+        for (int k = 0; k < r.ne; k++) {
+            double nx, nz;
+            w.edge_normal(r, k, nx, nz);
+            inward += nx * (cx - r.ox[k]) + nz * (cz - r.oz[k]);
+        }
+        return inward < 0;
+    };
+    for (int ri = lane; d.poly && ri < w.n_rooms; ri += WAVE) {   // polygon room table (mwb_internal.h)
+        const WRoom &r = rooms[ri];
+        float *o = grooms + (size_t)ri * MWB_POLY_ROOM_WORDS;
+        const bool cull_r = culled(r);
+        o[PW_HEIGHT] = d.no_ceiling ? -(float)r.height : (float)r.height;
+        o[PW_TEX] = __int_as_float(r.tex_id[0] | (r.tex_id[1] << 8) | (r.tex_id[2] << 16));
+        o[PW_FLAGS] = __int_as_float(r.ne | (cull_r ? 256 : 0));
+        o[3] = 0.0f;
+        for (int k = 0; k < 4; k++) {
+            float *ed = o + PW_EDGE0 + PW_EDGE_WORDS * k;
+            for (int q = 0; q < PW_EDGE_WORDS; q++) ed[q] = 0.0f;
+            ed[9] = __int_as_float(-1);
+            if (k >= r.ne) continue;
+            double nx, nz;
+            w.edge_normal(r, k, nx, nz);
+            ed[0] = (float)r.ox[k]; ed[1] = (float)r.oz[k]; ed[2] = (float)r.edx[k]; ed[3] = (float)r.edz[k];
+            ed[4] = (float)nx; ed[5] = (float)nz;
+            if (r.n_port[k]) {
+                ed[6] = (float)r.p_start[k]; ed[7] = (float)r.p_end[k]; ed[8] = (float)r.p_maxy[k];
+                int nb = r.nbr[k];
+                if (nb >= 0 && !cull_r && culled(rooms[nb])) {   // by-pass a culled connector: on to the room behind its other portal
+                    const WRoom &c = rooms[nb];
+                    int onward = -1;
+                    for (int q = 0; q < c.ne; q++)
+                        if (c.n_port[q] == 1 && c.nbr[q] != ri) onward = c.nbr[q];
+                    if (onward < 0 || culled(rooms[onward])) atomicExch(d.error_flag, e + 1);
+                    nb = onward;
+                }
+                if (nb < 0) atomicExch(d.error_flag, e + 1);
+                ed[9] = __int_as_float(nb);
+            }
+        }
+    }
+    for (int ri = lane; !d.poly && ri < w.n_rooms; ri += WAVE) {
         const WRoom &r = rooms[ri];
         float *o = grooms + (size_t)ri * MWB_ROOM_WORDS;
         o[RW_MINX] = (float)r.min_x; o[RW_MAXX] = (float)r.max_x; o[RW_MINZ] = (float)r.min_z; o[RW_MAXZ] = (float)r.max_z;
@@ -1007,18 +1114,6 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
 // Camera basis (Agent.cam_pos / cam_dir, entity.py:457-484 via gen_rot_matrix math.py:9-23), the
 // gluPerspective / gluLookAt set-up of render_obs (miniworld.py:1183-1200), fixed-function lighting
 // per flat face (miniworld.py:1026-1045) and the box frame (entity.py:385-408), once per env-step.
-__device__ __forceinline__ void rot_matrix(double axx, double axy, double axz, double angle, double *m) {
-    double n = sqrt(axx * axx + axy * axy + axz * axz);
-    axx /= n; axy /= n; axz /= n;
-    double a = ref_cos(angle / 2.0), s = ref_sin(angle / 2.0);
-    double b = -axx * s, c = -axy * s, dd = -axz * s;
-    m[0] = a * a + b * b - c * c - dd * dd; m[1] = 2 * (b * c - a * dd); m[2] = 2 * (b * dd + a * c);
-    m[3] = 2 * (b * c + a * dd); m[4] = a * a + c * c - b * b - dd * dd; m[5] = 2 * (c * dd - a * b);
-    m[6] = 2 * (b * dd - a * c); m[7] = 2 * (c * dd + a * b); m[8] = a * a + dd * dd - b * b - c * c;
-}
-__device__ __forceinline__ void vec_mat(const double *v, const double *m, double *o) {
-    for (int j = 0; j < 3; j++) o[j] = (v[0] * m[j] + v[1] * m[3 + j]) + v[2] * m[6 + j];
-}
 __device__ __forceinline__ void lit_color(const float *L, const float *amb, const float *dif, float nx, float ny, float nz,
                                           const float *C, float *out) {
     float ndl = nx * L[0] + ny * L[1] + nz * L[2];
@@ -1070,6 +1165,8 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     lit_color(L, amb, dif, 0, 0, 1, white, fc + FC_LIT_WALL + 3);
     lit_color(L, amb, dif, 1, 0, 0, white, fc + FC_LIT_WALL + 6);
     lit_color(L, amb, dif, 0, 0, -1, white, fc + FC_LIT_WALL + 9);
+    if (d.poly)   // walls of any orientation: the light itself, the colour is computed per edge in the render kernel
+        for (int k = 0; k < 3; k++) { fc[FC_LIGHT_DIR + k] = L[k]; fc[FC_LIGHT_AMB + k] = amb[k]; fc[FC_LIGHT_DIF + k] = dif[k]; }
     // Frame-level gate for every box test of the render kernel: can any box's (pixel-footprint-inflated) bounding sphere
     // meet the cone around the view direction that contains the whole image (half angle atan |(TW, TH)|)?  Conservative
     // (2 % + 0.01 rad slack); in a maze the box is out of view in most frames and the tests are skipped wholesale.
@@ -1263,6 +1360,62 @@ __device__ __forceinline__ uint32_t trace_rooms(const float *__restrict__ rooms,
 }
 
 
+// The same traversal for rooms that are convex polygons with up to 4 arbitrary edges (YMaze; polygon room table,
+// mwb_internal.h).  Spec (polygon rooms): edge k with start p and inward unit normal n is an exit
+// candidate if den = fmaf(n.z, d.z, n.x d.x) < 0, at t = fmaf(n.z, p.z - o.z, n.x (p.x - o.x)) / den; the exit edge is the first
+// one, in edge order, with the smallest t; the crossing point's distance along it is hc = fmaf(dir.z, hz - p.z, dir.x (hx - p.x))
+// with (hx, hz) = fmaf(t, d, o).  Keys and paths carry the edge index where the rectangle version carries the side.
+template <bool PATH>
+__device__ __forceinline__ uint32_t trace_rooms_poly(const float *__restrict__ rooms, int n_rooms, int room, const float *o,
+                                                     const float *dv, float &t_hit, uint32_t &path) {
+    t_hit = INFINITY;
+    path = 1;
+    if (room < 0) return MAKE_KEY(KIND_SKY, 0, 0);
+    const bool ypos = dv[1] > 0, yneg = dv[1] < 0;
+    const float iy = (ypos || yneg) ? (PATH ? __builtin_amdgcn_rcpf(dv[1]) : 1.0f / dv[1]) : 0.0f;
+    const float tfloor = yneg ? (0.0f - o[1]) * iy : INFINITY;
+    float ts = INFINITY, tc = INFINITY, hc = 0.0f, y = 0.0f, height_w = 0.0f, p_lo = 0.0f, p_hi = 0.0f, p_maxy = 0.0f;
+    int nbr = -1, s = 0, steps = 0;
+    for (int iter = 0; iter <= n_rooms; iter++) {
+        const float *r = rooms + __umul24((uint32_t)room, MWB_POLY_ROOM_WORDS);
+        height_w = r[PW_HEIGHT];
+        ts = INFINITY; s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float4 a = *(const float4 *)(r + PW_EDGE0 + PW_EDGE_WORDS * k);       // p.x p.z dir.x dir.z
+            const float2 n = *(const float2 *)(r + PW_EDGE0 + PW_EDGE_WORDS * k + 4);   // n.x n.z
+            const float den = fmaf(n.y, dv[2], n.x * dv[0]);
+            const float num = fmaf(n.y, a.y - o[2], n.x * (a.x - o[0]));
+            const float t = PATH ? num * __builtin_amdgcn_rcpf(den) : num / den;
+            const bool take = den < 0.0f && t < ts;
+            ts = take ? t : ts; s = take ? k : s;
+        }
+        const float *ed = r + PW_EDGE0 + __umul24((uint32_t)s, PW_EDGE_WORDS);
+        const float4 a = *(const float4 *)ed;
+        const float4 b = *(const float4 *)(ed + 4);   // n.x n.z lo hi
+        p_lo = b.z; p_hi = b.w; p_maxy = ed[8]; nbr = __float_as_int(ed[9]);
+        tc = ypos ? (fabsf(height_w) - o[1]) * iy : INFINITY;
+        const float hx = fmaf(ts, dv[0], o[0]), hz = fmaf(ts, dv[2], o[2]);
+        hc = fmaf(a.w, hz - a.y, a.z * (hx - a.x));
+        y = fmaf(ts, dv[1], o[1]);
+        const bool go_on = nbr >= 0 && p_lo < hc && hc < p_hi && 0.0f < y && y < p_maxy && !(tfloor <= ts) && !(tc <= ts) && ts < INFINITY;
+        if (!go_on) break;
+        if (PATH) { path = (path << 2) | (uint32_t)s; steps++; }
+        room = nbr;
+    }
+    const bool hit_floor = tfloor <= ts, hit_ceil = tc <= ts, escaped = !(ts < INFINITY);
+    const bool pass = nbr >= 0 && p_lo < hc && hc < p_hi && 0.0f < y && y < p_maxy;
+    const bool stopped = hit_floor || hit_ceil || escaped || !pass;
+    if (PATH && steps > 15) path = 0x80000000u | (uint32_t)steps;
+    const bool wall = stopped && !hit_floor && !hit_ceil && !escaped;
+    const bool ceil_drawn = stopped && !hit_floor && hit_ceil && !(height_w < 0.0f);
+    const bool floor_ = stopped && hit_floor;
+    uint32_t wall_key = MAKE_KEY(KIND_WALL, s, room);
+    if (PATH) wall_key |= (nbr >= 0 ? (hc <= p_lo ? 1u : hc >= p_hi ? 2u : y >= p_maxy ? 3u : 0u) : 0u) << 28;
+    t_hit = floor_ ? tfloor : ceil_drawn ? tc : wall ? ts : INFINITY;
+    return floor_ ? MAKE_KEY(KIND_FLOOR, 0, room) : ceil_drawn ? MAKE_KEY(KIND_CEIL, 0, room) : wall ? wall_key : MAKE_KEY(KIND_SKY, 0, 0);
+}
+
 // slab test in box-local axes; returns face 0..5 (-x,+x,-y,+y,-z,+z) or -1
 __device__ __forceinline__ int trace_box(const float *fc, const float *dv, float &t_out) {
     const float c = fc[FC_BOX_C], s = fc[FC_BOX_S];
@@ -1365,7 +1518,7 @@ __device__ __forceinline__ bool plane_texcoord(int axis, float plane, float u_or
     return od != 0.0f && tt > 0.0f;
 }
 
-template <int NBOX>
+template <int NBOX, bool POLY>
 struct RenderCtx {
     const float *rooms, *fc;
     const TexLds *tex;
@@ -1385,10 +1538,82 @@ struct RenderCtx {
         for (int k = 0; k < 3; k++) { dx[k] = fmaf(cam.S[k], sx, dc[k]); dy[k] = fmaf(cam.U[k], sy, dc[k]); }
     }
 
+    template <bool PATH>
+    __device__ __forceinline__ uint32_t trace(const float *dv, float &t_hit, uint32_t &path) const {
+        if constexpr (POLY) return trace_rooms_poly<PATH>(rooms, n_rooms, cam_room, cam.eye, dv, t_hit, path);
+        else return trace_rooms<PATH>(rooms, n_rooms, cam_room, cam.eye, dv, t_hit, path);
+    }
+
+    // shade() for the polygon room table: a wall's plane, texture origin and lit colour come from its edge record
+    template <bool INTERIOR>
+    __device__ __forceinline__ void shade_poly(uint32_t key, int first_k, float cx, float cy, float *col) const {
+        const uint32_t kind = key & 7u, side = (key >> 3) & 3u;
+        if (!INTERIOR) {
+            if (kind == KIND_SKY) { col[0] = fc[FC_SKY]; col[1] = fc[FC_SKY + 1]; col[2] = fc[FC_SKY + 2]; return; }
+            if (kind == KIND_BOX) {
+                const float *lb = fc + FC_LIT_BOX + 3 * ((key >> 3) & 7u) + (NBOX > 1 ? (key >> 6) * FC_BOX_STRIDE : 0u);
+                col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2];
+                return;
+            }
+        }
+        const float *r = rooms + __umul24(key >> 6, MWB_POLY_ROOM_WORDS);
+        const float height = fabsf(r[PW_HEIGHT]);
+        const uint32_t texw = (uint32_t)__float_as_int(r[PW_TEX]);
+        const float *ed = r + PW_EDGE0 + __umul24(side, PW_EDGE_WORDS);
+        const float4 a = *(const float4 *)ed;          // p.x p.z dir.x dir.z
+        const float2 n = *(const float2 *)(ed + 4);    // n.x n.z
+        const bool wall = kind == KIND_WALL, floor_ = kind == KIND_FLOOR;
+        const uint32_t tex_id = (wall ? texw : floor_ ? (texw >> 8) : (texw >> 16)) & 255u;
+        const TexLds &T = tex[tex_id];
+        const float sc_s = T.sc_s, sc_t = T.sc_t;
+        float lit[3];
+        {   // flat face with the edge's inward normal (fixed-function lighting, miniworld.py:1026-1045)
+            const float *Ld = fc + FC_LIGHT_DIR, *amb = fc + FC_LIGHT_AMB, *dif = fc + FC_LIGHT_DIF;
+            float ndl = n.x * Ld[0] + 0.0f * Ld[1] + n.y * Ld[2];
+            ndl = ndl < 0.0f ? 0.0f : ndl;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const float v = (0.2f + amb[q]) + ndl * dif[q];
+                const float wv = v > 1.0f ? 1.0f : v;
+                lit[q] = wall ? wv : (floor_ ? fc[FC_LIT_FLOOR + q] : fc[FC_LIT_CEIL + q]);
+            }
+        }
+        const float plane = floor_ ? 0.0f : height;
+        auto texcoord = [&](const float *dv, float &s, float &t) {
+            if (wall) {
+                const float den = fmaf(n.y, dv[2], n.x * dv[0]);
+                const float tt = fmaf(n.y, a.y - cam.eye[2], n.x * (a.x - cam.eye[0])) * __builtin_amdgcn_rcpf(den);
+                const float hx = fmaf(tt, dv[0], cam.eye[0]), hz = fmaf(tt, dv[2], cam.eye[2]), yy = fmaf(tt, dv[1], cam.eye[1]);
+                s = fmaf(a.w, hz - a.y, a.z * (hx - a.x)) * sc_s; t = yy * sc_t;
+                return den != 0.0f && tt > 0.0f;
+            }
+            return plane_texcoord(1, plane, 0.0f, sc_s, sc_t, cam.eye, dv, s, t);
+        };
+        float dc[3], dx[3], dy[3];
+        make_ray(cam, cx, cy, dc);
+        neighbour_rays(dc, dx, dy);
+        float s0, t0, s1, t1, s2, t2;
+        const bool hit0 = texcoord(dc, s0, t0);
+        const bool v1 = texcoord(dx, s1, t1);
+        const bool v2 = texcoord(dy, s2, t2);
+        bool valid = v1 && v2;
+        if (!INTERIOR && !hit0) {
+            float dv[3];
+            make_ray(cam, cx + c_sample_x[first_k], cy + c_sample_y[first_k], dv);
+            texcoord(dv, s0, t0);
+            valid = false; s1 = s2 = s0; t1 = t2 = t0;
+        }
+        float texel[3];
+        sample_texture(texels, T, s0, t0, s1, t1, s2, t2, valid, texel);
+#pragma unroll
+        for (int q = 0; q < 3; q++) col[q] = lit[q] * (texel[q] * (1.0f / 255.0f));
+    }
+
     // INTERIOR: the caller guarantees a room surface (floor / ceiling / wall) whose plane the pixel's centre ray meets
     // in front of the eye (the four corner rays of the pixel do): no sky / box cases, no fallback to a sample's ray.
     template <bool INTERIOR>
     __device__ __forceinline__ void shade(uint32_t key, int first_k, float cx, float cy, float *col) const {
+        if constexpr (POLY) { shade_poly<INTERIOR>(key, first_k, cx, cy, col); return; }
         const uint32_t kind = key & 7u, side = (key >> 3) & 3u;
         if (!INTERIOR) {
             if (kind == KIND_SKY) { col[0] = fc[FC_SKY]; col[1] = fc[FC_SKY + 1]; col[2] = fc[FC_SKY + 2]; return; }
@@ -1490,7 +1715,7 @@ struct RenderCtx {
             float dv[3], th;
             uint32_t path;
             make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
-            uint32_t key = trace_rooms<false>(rooms, n_rooms, cam_room, cam.eye, dv, th, path);
+            uint32_t key = trace<false>(dv, th, path);
             // conservative bounding-sphere cull, then the exact slab test; boxes in entity order, a later
             // box wins only when strictly nearer
             const float dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
@@ -1557,6 +1782,16 @@ struct RenderCtx {
             float dv[3];
             make_ray(cam, cx + c_sample_x[0], cy + c_sample_y[0], dv);
             const uint32_t kind = key & 7u, side = (key >> 3) & 7u;
+            if constexpr (POLY) {
+                const float *r = rooms + __umul24(key >> 6, MWB_POLY_ROOM_WORDS);
+                const float *ed = r + PW_EDGE0 + __umul24(side & 3u, PW_EDGE_WORDS);
+                const float den = fmaf(ed[5], dv[2], ed[4] * dv[0]);
+                const float num = fmaf(ed[5], ed[1] - cam.eye[2], ed[4] * (ed[0] - cam.eye[0]));
+                const float plane = kind == KIND_CEIL ? fabsf(r[PW_HEIGHT]) : 0.0f;
+                t_s0 = kind == KIND_WALL ? num / den : (plane - cam.eye[1]) * (1.0f / dv[1]);
+                write_pixel<true>(px, py, col, true, t_s0);
+                return;
+            }
             const float *r = rooms + __umul24(key >> 6, MWB_ROOM_WORDS);
             const float4 rect = *(const float4 *)(r + RW_MINX);
             const bool wall = kind == KIND_WALL;
@@ -1595,7 +1830,7 @@ __device__ __forceinline__ void copy_frame_range(uint8_t *__restrict__ dst, cons
 // part < 0: the whole frame; part 0 / 1: one half of it (the last envs of a bulk launch are cut in two so that the
 // launch drains in units of half a workgroup time) - the upper / lower rows for HWC frames, the left / right
 // strips for CWH ones, so that a half's bytes are one (three) contiguous run(s).
-template <int THREADS, int NBOX, bool LOOPED>
+template <int THREADS, int NBOX, bool LOOPED, bool POLY>
 __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const int part, unsigned char *smem) {
     // LOOPED (the body sits in a loop over the regenerated-env list): make the lane id opaque to the optimiser so that
     // nothing derived from it is hoisted out of that loop and kept alive across whole frames (200 -> 76 B/lane of scratch)
@@ -1605,7 +1840,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     int n_rooms = d.n_rooms[e];
     if (n_rooms < 0) n_rooms = 0;
     float *rooms = (float *)smem;
-    size_t off = ((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15;
+    size_t off = ((size_t)d.R_max * d.room_words * 4 + 15) & ~(size_t)15;
     float *fc = (float *)(smem + off); off += (size_t)d.frame_words * 4;
     TexLds *tex = (TexLds *)(smem + off); off += sizeof(TexLds) * d.n_tex;
     int *cam_room_s = (int *)(smem + off); off += 16 + 2 * (THREADS / WAVE) * sizeof(int);   // + leftover counts
@@ -1615,9 +1850,10 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     uint8_t *fb = smem + off;   // the frame is assembled in LDS and leaves as 16-byte coalesced stores
 
     {   // stage the room table, the frame constants and the texture descriptors
-        const float4 *src = (const float4 *)(d.rooms + (size_t)e * d.R_max * MWB_ROOM_WORDS);
+        const int rw = POLY ? MWB_POLY_ROOM_WORDS : MWB_ROOM_WORDS;
+        const float4 *src = (const float4 *)(d.rooms + (size_t)e * d.R_max * rw);
         float4 *dst = (float4 *)rooms;
-        for (int i = tid; i < n_rooms * (MWB_ROOM_WORDS / 4); i += THREADS) dst[i] = src[i];
+        for (int i = tid; i < n_rooms * (rw / 4); i += THREADS) dst[i] = src[i];
         const float *fsrc = d.frame + (size_t)e * d.frame_words;
         for (int i = tid; i < d.frame_words; i += THREADS) fc[i] = fsrc[i];
         const uint32_t *tsrc = (const uint32_t *)d.tex_desc;
@@ -1626,7 +1862,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         if (tid == 0) { cam_room_s[0] = 0x7fffffff; cam_room_s[1] = 0; }   // eye room (atomicMin), work-item counter
     }
     __syncthreads();
-    RenderCtx<NBOX> ctx;
+    RenderCtx<NBOX, POLY> ctx;
     ctx.rooms = rooms; ctx.fc = fc; ctx.tex = tex; ctx.texels = d.texels; ctx.fb = fb;
     ctx.depth = d.want_depth ? d.depth + (size_t)e * W * H : nullptr;
     ctx.n_rooms = n_rooms; ctx.W = W; ctx.H = H; ctx.layout = d.layout;
@@ -1639,9 +1875,19 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     cam.Wf = (float)W; cam.Hf = (float)H; cam.invW = 1.0f / (float)W; cam.invH = 1.0f / (float)H;
     // room containing the eye: first (lowest index) rectangle that holds it, bounds inclusive
     for (int i = tid; i < n_rooms; i += THREADS) {
-        const float *r = rooms + i * MWB_ROOM_WORDS;
-        if (cam.eye[0] >= r[RW_MINX] && cam.eye[0] <= r[RW_MAXX] && cam.eye[2] >= r[RW_MINZ] && cam.eye[2] <= r[RW_MAXZ])
-            atomicMin(cam_room_s, i);
+        if constexpr (POLY) {   // first room, in creation order, with the eye on the inner side of every edge; never a culled one
+            const float *r = rooms + i * MWB_POLY_ROOM_WORDS;
+            bool in = !((__float_as_int(r[PW_FLAGS]) >> 8) & 1);
+            for (int k = 0; k < 4; k++) {
+                const float *ed = r + PW_EDGE0 + PW_EDGE_WORDS * k;
+                if (!(fmaf(ed[5], cam.eye[2] - ed[1], ed[4] * (cam.eye[0] - ed[0])) >= 0.0f)) in = false;
+            }
+            if (in) atomicMin(cam_room_s, i);
+        } else {
+            const float *r = rooms + i * MWB_ROOM_WORDS;
+            if (cam.eye[0] >= r[RW_MINX] && cam.eye[0] <= r[RW_MAXX] && cam.eye[2] >= r[RW_MINZ] && cam.eye[2] <= r[RW_MAXZ])
+                atomicMin(cam_room_s, i);
+        }
     }
     __syncthreads();
     ctx.cam_room = __builtin_amdgcn_readfirstlane(*cam_room_s);
@@ -1746,7 +1992,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             float dv[3], th;
             uint32_t path;
             make_ray(cam, (float)(x0 + ((q & 1) ? wi : 0)), (float)(H - crow), dv);
-            const uint32_t key = trace_rooms<true>(rooms, n_rooms, ctx.cam_room, cam.eye, dv, th, path);
+            const uint32_t key = ctx.template trace<true>(dv, th, path);
             const uint32_t kind = key & 7u;
             const bool ok = (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
             const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)key, 0), tp = (uint32_t)__builtin_amdgcn_readlane((int)path, 0);
@@ -1777,7 +2023,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             float dv[3], th;
             uint32_t path;
             make_ray(cam, (float)(x0 + ci), (float)(H - crow), dv);
-            uint32_t key = trace_rooms<true>(rooms, n_rooms, ctx.cam_room, cam.eye, dv, th, path);
+            uint32_t key = ctx.template trace<true>(dv, th, path);
             const uint32_t kind = key & 7u;
             bool ok = (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
             // the pixel whose bottom-left corner this lane traced: corners (crow-1, ci), (crow-1, ci+1),
@@ -1850,13 +2096,13 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
 // MODE 0: every env; 1: only the envs regenerated this step (side stream, through the compact list);
 // 2: all the others (bulk).  A template parameter so that the three launches carry distinct kernel names
 // in profiles.
-template <int THREADS, int MODE, int NBOX>
+template <int THREADS, int MODE, int NBOX, bool POLY = false>
 __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (MODE == 1) {
         const int count = d.reset_count[0];
         for (int li = blockIdx.x; li < count; li += gridDim.x) {
-            render_env<THREADS, NBOX, true>(d, d.reset_list[li], -1, smem);
+            render_env<THREADS, NBOX, true, POLY>(d, d.reset_list[li], -1, smem);
             __syncthreads();   // LDS is reused by the next env of this block
         }
     } else {
@@ -1871,7 +2117,7 @@ __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
         const int e = __builtin_amdgcn_readfirstlane(d.order_bufs[d.order_state[0] & 1][slot]);
         if (MODE == 2 && d.reset_set[e]) return;   // block-uniform
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // read by every wave: stays in scalar registers
-        render_env<THREADS, NBOX, false>(d, e, part, smem);
+        render_env<THREADS, NBOX, false, POLY>(d, e, part, smem);
         if (threadIdx.x == 0) {
             const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
             if (d.wg_ts) { d.wg_ts[2 * b] = t0; d.wg_ts[2 * b + 1] = t1; }
@@ -1953,7 +2199,7 @@ size_t mwb_reset_lds_bytes(const MwbDev &d) {
     return (b + 15) & ~(size_t)15;
 }
 size_t mwb_render_lds_bytes(const MwbDev &d) {
-    size_t b = (((size_t)d.R_max * MWB_ROOM_WORDS * 4 + 15) & ~(size_t)15) + (size_t)d.frame_words * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
+    size_t b = (((size_t)d.R_max * d.room_words * 4 + 15) & ~(size_t)15) + (size_t)d.frame_words * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
                (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)d.W * d.H * 3;
     b += (size_t)(d.debug_flags >> 8) * 1024;   // MWB_DEBUG bits 8+: KiB of LDS padding (occupancy experiments)
     return (b + 15) & ~(size_t)15;
@@ -1985,8 +2231,9 @@ int mwb_prepare_kernels(const MwbDev &d) {
         const void *fns[3][3] = {{(const void *)render_kernel<RENDER_THREADS, 0, 1>, (const void *)render_kernel<RENDER_THREADS, 1, 1>, (const void *)render_kernel<RENDER_THREADS, 2, 1>},
                                  {(const void *)render_kernel<RENDER_THREADS, 0, 2>, (const void *)render_kernel<RENDER_THREADS, 1, 2>, (const void *)render_kernel<RENDER_THREADS, 2, 2>},
                                  {(const void *)render_kernel<RENDER_THREADS, 0, 6>, (const void *)render_kernel<RENDER_THREADS, 1, 6>, (const void *)render_kernel<RENDER_THREADS, 2, 6>}};
+        const void *pfns[3] = {(const void *)render_kernel<RENDER_THREADS, 0, 1, true>, (const void *)render_kernel<RENDER_THREADS, 1, 1, true>, (const void *)render_kernel<RENDER_THREADS, 2, 1, true>};
         for (int m = 0; m < 3; m++)
-            if (hipFuncSetAttribute(fns[d.n_boxes == 6 ? 2 : d.n_boxes == 2 ? 1 : 0][m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess) return -2;
+            if (hipFuncSetAttribute(d.poly ? pfns[m] : fns[d.n_boxes == 6 ? 2 : d.n_boxes == 2 ? 1 : 0][m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess) return -2;
     }
     return 0;
 }
@@ -2003,6 +2250,12 @@ void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
     const dim3 g(d.N + d.split_envs), b(RENDER_THREADS);
     const size_t lds = mwb_render_lds_bytes(d);
     const dim3 gl(d.N < LIST_GRID ? d.N : LIST_GRID);
+    if (d.poly) {   // YMaze: polygon rooms (one box)
+        if (mode == 1) render_kernel<RENDER_THREADS, 1, 1, true><<<gl, b, lds, s>>>(d);
+        else if (mode == 2) render_kernel<RENDER_THREADS, 2, 1, true><<<g, b, lds, s>>>(d);
+        else render_kernel<RENDER_THREADS, 0, 1, true><<<g, b, lds, s>>>(d);
+        return;
+    }
     if (d.n_boxes == 2) {   // the two-box T-maze: its own instantiation, so that the one-box kernels stay as they are
         if (mode == 1) render_kernel<RENDER_THREADS, 1, 2><<<gl, b, lds, s>>>(d);
         else if (mode == 2) render_kernel<RENDER_THREADS, 2, 2><<<g, b, lds, s>>>(d);

@@ -26,7 +26,16 @@ class _Ent:
 
 class _Room:
     def __init__(self, words):
-        self.min_x, self.max_x, self.min_z, self.max_z, self.wall_height = (float(w) for w in words[:5])
+        if len(words) == 24:
+            self.min_x, self.max_x, self.min_z, self.max_z, self.wall_height = (float(w) for w in words[:5])
+            self.outline = np.array([[self.max_x, 0, self.max_z], [self.max_x, 0, self.min_z], [self.min_x, 0, self.min_z], [self.min_x, 0, self.max_z]])
+        else:   # polygon room table (YMaze): height, tex, n_edges | culled << 8, pad, then 4 edges of 12 words starting p.x p.z
+            ne = int(np.asarray(words[2:3]).view(np.int32)[0]) & 255
+            self.wall_height = abs(float(words[0]))
+            self.outline = np.array([[float(words[4 + 12 * k]), 0.0, float(words[5 + 12 * k])] for k in range(ne)])
+            self.min_x, self.max_x = self.outline[:, 0].min(), self.outline[:, 0].max()
+            self.min_z, self.max_z = self.outline[:, 2].min(), self.outline[:, 2].max()
+        self.num_walls = len(self.outline)
 
 
 class MiniWorldEnv:

@@ -55,7 +55,11 @@ enum { MWB_TASK_HALLWAY = 0,   /* envs/hallway.py   task_args = {length}        
         * grey, purple, red, yellow - of sizes drawn per episode; the full MiniWorldEnv action set Discrete(8) incl. pickup (4)
         * and drop (5) with the carry physics of miniworld.py:594-606,622-631,645-654,682-702 (toggle 6 and done 7 do
         * nothing); reward + done once the red box is next to the yellow one and nothing is carried.  task_args = {size} */
-       MWB_TASK_PUTNEXT = 8 };
+       MWB_TASK_PUTNEXT = 8,
+       /* envs/ymaze.py:8-103 (YMaze, YMazeLeft, YMazeRight): a corridor, a triangular hub and two arms rotated by -+120
+        * degrees - rooms are convex polygons with 3 or 4 arbitrary edges (the polygon room table below); reward + done
+        * near the box, info['goal_pos'] = box position; Discrete(3).  task_args = {goal given (0 = random arm), goal x, goal z} */
+       MWB_TASK_YMAZE = 9 };
 
 /* observation layouts */
 enum { MWB_LAYOUT_HWC = 0,  /* [N,H,W,3]  MiniWorldEnv.observation_space, miniworld.py:473-478 */
@@ -213,8 +217,14 @@ int mwb_set_task_state(mwb_handle *h, int first_env, int count, const int64_t *e
  * to skip nobody.  result: 0 none, 1 wall (walls are tested first), 2 + k = the first entity k in list order within
  * radius + its radius. Synchronous. */
 int mwb_intersect(mwb_handle *h, int env, int ent, double x, double z, double radius, int *result);
-/* geometry of one env as the kernels see it: n_rooms x MWB_ROOM_WORDS f32 words and n_segs x 4 f64 */
+/* geometry of one env as the kernels see it: n_rooms x mwb_room_words(h) f32 words and n_segs x 4 f64.
+ * Rectangle tasks: MWB_ROOM_WORDS words per room (min_x max_x min_z max_z, height, textures, neighbours, 4 x side).
+ * MWB_TASK_YMAZE: MWB_POLY_ROOM_WORDS words per room - height, textures, n_edges | culled << 8, pad, then 4 edges of
+ * 12 words: p.x p.z dir.x dir.z | n.x n.z portal_lo portal_hi | portal_max_y neighbour(int bits, -1 none) 0 0
+ * (Room.outline / edge_dirs / edge_norms / portals, miniworld.py:75-218, as float32). */
 #define MWB_ROOM_WORDS 24
+#define MWB_POLY_ROOM_WORDS 52
+int mwb_room_words(mwb_handle *h);
 int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_rooms, double *segs, int max_segs,
                      int *n_rooms, int *n_segs);
 
