@@ -36,11 +36,14 @@ WORKLOADS = {
     # six boxes + the carry actions; 14 400 B obs + ~0.6 KB state (six box poses / sizes / colours)
     # + 96 B room + 960 B frame constants.  The shared action stream stays on {0, 1, 2} (nothing gets picked up).
     "putnext8192": ("MiniWorld-PutNext-v0", 8192, False, False, 16000),
+    # polygon rooms; 14 400 B obs + ~0.2 KB state + 6 rooms x 208 B + 288 B frame constants
+    "ymaze8192": ("MiniWorld-YMaze-v0", 8192, False, False, 16200),
 }
 ORACLE_TASK = {"MiniWorld-Maze-v0": ("Maze", None), "MiniWorld-OneRoom-v0": ("OneRoom", None),
                "MiniWorld-FourRooms-v0": ("FourRooms", None), "MiniWorld-Hallway-v0": ("Hallway", None),
                "MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0": ("TMazeTwoBox", [1, 0, 0, 100000]),
-               "MiniWorld-SimToRealPush-v0": ("SimToRealPush", None), "MiniWorld-PutNext-v0": ("PutNext", None)}
+               "MiniWorld-SimToRealPush-v0": ("SimToRealPush", None), "MiniWorld-PutNext-v0": ("PutNext", None),
+               "MiniWorld-YMaze-v0": ("YMaze", [0, 0, 0, 0])}
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ACTION_SEED = 12345
 
