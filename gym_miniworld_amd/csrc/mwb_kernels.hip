@@ -1809,6 +1809,7 @@ struct RenderCtx {
 #define TILE_CX 16   // corner grid of one wave pass: 16 x 4 corners; marching down a strip it classifies 15 x 4 pixels
 #define TILE_CY 4
 #define QUEUE_CAP 128
+#define ITEM_RES_BYTES(W) ((((W) + TILE_CX - 2) / (TILE_CX - 1)) * 4 * 8)   // n_strips x 4 quarters x uint2
 
 // LDS -> HBM copy of the byte range [begin, end) of the frame with the widest vectors its alignment allows
 template <int THREADS>
@@ -1847,6 +1848,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     uint16_t *queues = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
     uint32_t *ikeys = (uint32_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint32_t);
     uint16_t *ipix = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
+    uint2 *item_res = (uint2 *)(smem + off); off += (size_t)ITEM_RES_BYTES(W);   // per work item: uniform rows + their key
     uint8_t *fb = smem + off;   // the frame is assembled in LDS and leaves as 16-byte coalesced stores
 
     {   // stage the room table, the frame constants and the texture descriptors
@@ -1970,6 +1972,52 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         return touch;
     };
 
+    // Item pre-tests, all at once.  If the corner rays of a screen rectangle reach the same convex piece of a room surface
+    // through the same portals, so does every ray in between (the argument made for a pixel holds for any rectangle): all
+    // its pixels are interior pixels of that surface.  Tested for every 15 x 15 item and for its upper / lower 8 rows: the
+    // corner rays of all items form a lattice of 16 rows (4 per quarter: top, rows - 8, 8, bottom) x (strips + 1) columns,
+    // traced ONCE per frame by waves 0 and 1 (8 lattice columns = 7 strips per pass) - neighbouring items share corners,
+    // and a wave that pulls an item finds the verdict in LDS instead of spending a whole wave-trace on 8 rays.
+    // A uniform item skips its 4 corner passes, a uniform half leaves 2.
+    if (!(d.debug_flags & (1 | 32 | 128))) {
+        for (int chunk0 = 0; chunk0 < n_strips; chunk0 += 7) {
+            if (wave < 2) {
+                const int r = lane >> 3, k = lane & 7, q = wave * 2 + (r >> 2), rr = r & 3;
+                const int row0 = q * part_h;
+                const int rows = (H - row0) < part_h ? ((H - row0) > 0 ? (H - row0) : 0) : part_h;
+                const int ha = rows < 8 ? rows : 8, hb = rows > 8 ? rows - 8 : 0;   // rows [0, ha) and [hb, rows)
+                const int crow = row0 + (rr == 0 ? 0 : rr == 1 ? hb : rr == 2 ? ha : rows);
+                const int strip = chunk0 + k;
+                const int xcol = strip * (TILE_CX - 1) < W ? strip * (TILE_CX - 1) : W;
+                float dv[3], th;
+                uint32_t path;
+                make_ray(cam, (float)xcol, (float)(H - crow), dv);
+                uint32_t key = ctx.template trace<true>(dv, th, path);
+                const uint32_t kind = key & 7u;
+                const bool ok = (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
+                if (!ok) { key = 0xF0000000u | (uint32_t)lane; path = (uint32_t)lane; }   // equal to no other lane's
+                // lane (rr = 0, k) owns item (strip, q): its corners sit at lanes +0 +1 (top), +8 +9 (rows - 8), +16 +17 (8), +24 +25 (bottom)
+                uint32_t nk[8], np[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int src = (lane + (j >> 1) * 8 + (j & 1)) & (WAVE - 1);
+                    nk[j] = __shfl(key, src); np[j] = __shfl(path, src);
+                }
+                auto same = [&](int a, int b) { return nk[a] == nk[b] && np[a] == np[b]; };
+                const bool top_u = ok && same(0, 1) && same(0, 4) && same(0, 5);      // corner rows 0 and ha
+                const bool bot_u = same(2, 3) && same(2, 6) && same(2, 7);   // corner rows hb and rows (a lane that is not ok equals nobody)
+                const bool all_u = top_u && bot_u && same(0, 2);
+                int ur0 = 0, ur1 = 0;   // uniform rows [ur0, ur1) of the item
+                uint32_t ukey = 0;
+                if (all_u) { ur1 = rows; ukey = nk[0]; }
+                else if (top_u && ha < rows) { ur1 = ha; ukey = nk[0]; }
+                else if (bot_u && hb > 0) { ur0 = hb; ur1 = rows; ukey = nk[2]; }
+                if (rr == 0 && k < 7 && strip < n_strips) item_res[strip * 4 + q] = make_uint2(ukey, (uint32_t)(ur0 | (ur1 << 8)));
+            }
+        }
+        __syncthreads();
+    }
+
     for (;;) {
         int item = 0;
         if (lane == 0) item = atomicAdd(cam_room_s + 1, 1);
@@ -1980,32 +2028,18 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         const int rows = (H - row0) < part_h ? (H - row0) : part_h;   // pixel rows of this item
         if (rows <= 0) continue;
         int prow0 = row0, prows = rows;   // the rows left for the per-pixel corner passes
+        if (d.debug_flags & 128) continue;   // experiment: prologue + copy-out only
         if (!(d.debug_flags & (1 | 32))) {
-            // Item pre-test: corner rays of the whole item and of its upper / lower 8 rows (one trace, 8 lanes' worth).
-            // If the corner rays of a screen rectangle reach the same convex piece of a room surface through the same
-            // portals, so does every ray in between (the argument made for a pixel holds for any rectangle): all its
-            // pixels are interior pixels of that surface.  The whole item skips its 4 passes, a uniform half leaves 2.
             const int wi = (W - x0) < (TILE_CX - 1) ? (W - x0) : (TILE_CX - 1);   // pixel columns of this item
-            const int ha = rows < 8 ? rows : 8, hb = rows > 8 ? rows - 8 : 0;       // rows [0, ha) and [hb, rows)
-            const int q = lane & 7, qr = q >> 1;                                      // lanes 8..63 repeat lanes 0..7
-            const int crow = row0 + (qr == 0 ? 0 : qr == 1 ? hb : qr == 2 ? ha : rows);
-            float dv[3], th;
-            uint32_t path;
-            make_ray(cam, (float)(x0 + ((q & 1) ? wi : 0)), (float)(H - crow), dv);
-            const uint32_t key = ctx.template trace<true>(dv, th, path);
-            const uint32_t kind = key & 7u;
-            const bool ok = (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
-            const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)key, 0), tp = (uint32_t)__builtin_amdgcn_readlane((int)path, 0);
-            const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)key, 2), bp = (uint32_t)__builtin_amdgcn_readlane((int)path, 2);
-            const unsigned tm = (unsigned)__ballot(ok && key == tk && path == tp) & 0xFFu;   // corner rows 0 and ha: lanes 0 1 4 5
-            const unsigned bm = (unsigned)__ballot(ok && key == bk && path == bp) & 0xFFu;   // corner rows hb and rows: lanes 2 3 6 7
-            const bool top_u = (tm & 0x33u) == 0x33u, bot_u = (bm & 0xCCu) == 0xCCu;
-            const bool all_u = top_u && bot_u && tk == bk && tp == bp;
-            int ur0 = 0, ur1 = 0;   // uniform rows [ur0, ur1) of the item
-            uint32_t ukey = 0;
-            if (all_u) { ur1 = rows; ukey = tk; prows = 0; }
-            else if (top_u && ha < rows) { ur1 = ha; ukey = tk; prow0 = row0 + ha; prows = rows - ha; }
-            else if (bot_u && hb > 0) { ur0 = hb; ur1 = rows; ukey = bk; prows = hb; }
+            const uint2 res = item_res[item];   // the frame-level pre-test's verdict (workgroup-uniform address)
+            const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)res.x);
+            const int urw = __builtin_amdgcn_readfirstlane((int)res.y);
+            const int ur0 = urw & 255, ur1 = urw >> 8;   // uniform rows [ur0, ur1) of the item
+            if (ur1 > ur0) {
+                if (ur0 == 0 && ur1 == rows) prows = 0;
+                else if (ur0 == 0) { prow0 = row0 + ur1; prows = rows - ur1; }
+                else prows = ur0;
+            }
             const int col = lane & (TILE_CX - 1);
             for (int r0 = ur0; r0 < ur1; r0 += TILE_CY) {
                 const int px = x0 + col, py = row0 + r0 + lane / TILE_CX;
@@ -2016,6 +2050,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             }
             if (prows <= 0) continue;
         }
+        if (d.debug_flags & 64) continue;   // experiment: no per-pixel corner passes (prologue + pre-test + copy-out only)
         const int n_pass_i = (prows + 1 + TILE_CY - 1) / TILE_CY;   // corner rows of the remaining rows: prows + 1
         uint32_t prev_key = 0, prev_path = 0;
         for (int p = 0; p < n_pass_i; p++) {
@@ -2200,7 +2235,7 @@ size_t mwb_reset_lds_bytes(const MwbDev &d) {
 }
 size_t mwb_render_lds_bytes(const MwbDev &d) {
     size_t b = (((size_t)d.R_max * d.room_words * 4 + 15) & ~(size_t)15) + (size_t)d.frame_words * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
-               (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)d.W * d.H * 3;
+               (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)ITEM_RES_BYTES(d.W) + (size_t)d.W * d.H * 3;
     b += (size_t)(d.debug_flags >> 8) * 1024;   // MWB_DEBUG bits 8+: KiB of LDS padding (occupancy experiments)
     return (b + 15) & ~(size_t)15;
 }

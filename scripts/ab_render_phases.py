@@ -1,6 +1,7 @@
 """A/B timing of the render kernel's phases in one process via MWB_DEBUG (read at mwb_create):
 1 = every pixel through the 8-sample path, 2 = skip the 8-sample path, 4 = skip interior shading,
-6 = corner passes + prologue only; bits 8+ = KiB of LDS padding (occupancy experiments)."""
+6 = corner passes + prologue only; 70 = 6 without the per-pixel corner passes (prologue, item pre-tests, copy-out);
+134 = prologue + copy-out only; bits 8+ = KiB of LDS padding (occupancy experiments)."""
 import sys, os, time
 sys.path.insert(0, '.')
 import torch
@@ -8,7 +9,7 @@ from gym_miniworld_amd.batch import BatchedMiniWorld
 wl = sys.argv[1] if len(sys.argv) > 1 else "MiniWorld-Maze-v0"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 envs = {}
-for dbg in ("0", "1", "2", "4", "6"):
+for dbg in ("0", "2", "4", "6", "70", "134"):
     os.environ["MWB_DEBUG"] = dbg
     envs[dbg] = BatchedMiniWorld(wl, num_envs=n, seed=1)
     envs[dbg].reset()
