@@ -1416,6 +1416,54 @@ __device__ __forceinline__ uint32_t trace_rooms_poly(const float *__restrict__ r
     return floor_ ? MAKE_KEY(KIND_FLOOR, 0, room) : ceil_drawn ? MAKE_KEY(KIND_CEIL, 0, room) : wall ? wall_key : MAKE_KEY(KIND_SKY, 0, 0);
 }
 
+// The room a ray is in after its first n portal crossings (the caller knows that it makes them: rays inside a pixel
+// whose corner rays all make them do, see pixel_full).  Same side selection as trace_rooms; nothing is tested.
+// Returns -1 if a crossing finds no neighbour (cannot happen for such rays; the caller then starts from the eye's room).
+__device__ __forceinline__ int walk_rooms(const float *__restrict__ rooms, int room, const float *o, const float *dv, int n) {
+    const bool xpos = dv[0] > 0, xnz = dv[0] != 0, zpos = dv[2] > 0, znz = dv[2] != 0;
+    const float ix = xnz ? __builtin_amdgcn_rcpf(dv[0]) : 0.0f, iz = znz ? __builtin_amdgcn_rcpf(dv[2]) : 0.0f;
+    const float x_off = xnz ? 0.0f : INFINITY, z_off = znz ? 0.0f : INFINITY;
+    for (int i = 0; i < n && room >= 0; i++) {
+        const float *r = rooms + __umul24((uint32_t)room, MWB_ROOM_WORDS);
+        const float4 rect = *(const float4 *)(r + RW_MINX);
+        const uint32_t n01 = (uint32_t)__float_as_int(r[RW_NBR01]), n23 = (uint32_t)__float_as_int(r[RW_NBR23]);
+        const float tx = fmaf((xpos ? rect.y : rect.x) - o[0], ix, x_off);
+        const float tz = fmaf((zpos ? rect.w : rect.z) - o[2], iz, z_off);
+        const uint32_t nbrx = xpos ? (n01 & 0xFFFFu) : (n23 & 0xFFFFu), nbrz = zpos ? (n23 >> 16) : (n01 >> 16);
+        const uint32_t nbr = tx <= tz ? nbrx : nbrz;
+        room = nbr == RW_NO_NBR ? -1 : (int)nbr;
+    }
+    return room;
+}
+__device__ __forceinline__ int walk_rooms_poly(const float *__restrict__ rooms, int room, const float *o, const float *dv, int n) {
+    for (int i = 0; i < n && room >= 0; i++) {
+        const float *r = rooms + __umul24((uint32_t)room, MWB_POLY_ROOM_WORDS);
+        float ts = INFINITY;
+        int nbr = -1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float *ed = r + PW_EDGE0 + PW_EDGE_WORDS * k;
+            const float den = fmaf(ed[5], dv[2], ed[4] * dv[0]);
+            const float t = fmaf(ed[5], ed[1] - o[2], ed[4] * (ed[0] - o[0])) * __builtin_amdgcn_rcpf(den);
+            const bool take = den < 0.0f && t < ts;
+            ts = take ? t : ts; nbr = take ? __float_as_int(ed[9]) : nbr;
+        }
+        room = nbr;
+    }
+    return room;
+}
+
+// number of leading portal crossings two path words (trace_rooms<true>) have in common
+__device__ __forceinline__ int common_crossings(uint32_t a, uint32_t b) {
+    if (((a | b) & 0x80000000u) || a == 0 || b == 0) return 0;   // a path too long for the word / no path (lanes that are no pixel)
+    const int ca = __builtin_clz(a), cb = __builtin_clz(b);   // both have their sentinel bit
+    const uint32_t x = (a << ca) ^ (b << cb);
+    const int eq = x ? __builtin_clz(x) : 32;                  // equal leading bits incl. the sentinel
+    const int na = (31 - ca) >> 1, nb = (31 - cb) >> 1, ne = (eq - 1) >> 1;
+    const int m = na < nb ? na : nb;
+    return ne < m ? ne : m;
+}
+
 // slab test in box-local axes; returns face 0..5 (-x,+x,-y,+y,-z,+z) or -1
 __device__ __forceinline__ int trace_box(const float *fc, const float *dv, float &t_out) {
     const float c = fc[FC_BOX_C], s = fc[FC_BOX_S];
@@ -1539,9 +1587,13 @@ struct RenderCtx {
     }
 
     template <bool PATH>
+    __device__ __forceinline__ uint32_t trace_from(int room, const float *dv, float &t_hit, uint32_t &path) const {
+        if constexpr (POLY) return trace_rooms_poly<PATH>(rooms, n_rooms, room, cam.eye, dv, t_hit, path);
+        else return trace_rooms<PATH>(rooms, n_rooms, room, cam.eye, dv, t_hit, path);
+    }
+    template <bool PATH>
     __device__ __forceinline__ uint32_t trace(const float *dv, float &t_hit, uint32_t &path) const {
-        if constexpr (POLY) return trace_rooms_poly<PATH>(rooms, n_rooms, cam_room, cam.eye, dv, t_hit, path);
-        else return trace_rooms<PATH>(rooms, n_rooms, cam_room, cam.eye, dv, t_hit, path);
+        return trace_from<PATH>(cam_room, dv, t_hit, path);
     }
 
     // shade() for the polygon room table: a wall's plane, texture origin and lit colour come from its edge record
@@ -1700,9 +1752,21 @@ struct RenderCtx {
         }
     }
 
-    // the full 8-sample path for one pixel
-    __device__ __forceinline__ void pixel_full(int px, int py) const {
+    // the full 8-sample path for one pixel.  skip: the first `skip` portal crossings are common to the pixel's four corner
+    // rays, so every ray inside the pixel makes them too (each portal is convex: the rays through it form a convex cone
+    // that holds the corners, hence their hull) - the eight traversals start in the room behind them, found by walking
+    // the centre ray.  The traversal computes every distance from the eye, never from the previous room, so the
+    // results are bit-identical to a start in the eye's room (guarded by test_fast_path_equals_full_sample_path's
+    // MWB_DEBUG=8 leg).
+    __device__ __forceinline__ void pixel_full(int px, int py, int skip) const {
         const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
+        int start_room = cam_room;
+        if (skip > 0) {
+            float dc[3];
+            make_ray(cam, cx, cy, dc);
+            const int r = POLY ? walk_rooms_poly(rooms, cam_room, cam.eye, dc, skip) : walk_rooms(rooms, cam_room, cam.eye, dc, skip);
+            start_room = r >= 0 ? r : cam_room;
+        }
         // distinct surfaces among the 8 coverage samples, in order of first appearance:
         // up to 4 slots (key, count, first sample); a 5th distinct surface is shaded on the spot
         uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
@@ -1715,7 +1779,7 @@ struct RenderCtx {
             float dv[3], th;
             uint32_t path;
             make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
-            uint32_t key = trace<false>(dv, th, path);
+            uint32_t key = trace_from<false>(start_room, dv, th, path);
             // conservative bounding-sphere cull, then the exact slab test; boxes in entity order, a later
             // box wins only when strictly nearer
             const float dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
@@ -1919,6 +1983,11 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     // queued pixels are packed as (py << wshift) | px (host checks that it fits 16 bits): no integer division
     const int wshift = 32 - __builtin_clz((unsigned)(W > 1 ? W - 1 : 1));
     const int wmask = (1 << wshift) - 1;
+    // an 8-sample pixel's entry also carries, above the coordinates, how many leading portal crossings its corner rays share
+    // (as many bits as 16 - the coordinate bits leave, at most 3; MWB_DEBUG bit 3: none)
+    const int hshift = 32 - __builtin_clz((unsigned)(H > 1 ? H - 1 : 1));
+    const int qshift = wshift + hshift, hmask = (1 << hshift) - 1;
+    const int skip_max = (d.debug_flags & 8) || qshift >= 16 ? 0 : (1 << (16 - qshift > 3 ? 3 : 16 - qshift)) - 1;
     uint16_t *queue = queues + wave * QUEUE_CAP;
     uint32_t *iq_key = ikeys + wave * QUEUE_CAP;
     uint16_t *iq_pix = ipix + wave * QUEUE_CAP;
@@ -1936,10 +2005,10 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     (void)n_waves;
 
     // a classified pixel goes to its per-wave queue; a queue that reaches 64 entries is processed at once (dense lanes)
-    auto emit = [&](int px, int py, bool is_pixel, bool interior, uint32_t key) {
+    auto emit = [&](int px, int py, bool is_pixel, bool interior, uint32_t key, int skip) {
         const bool edge = is_pixel && !interior;
         const unsigned long long em = __ballot(edge);
-        if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)((py << wshift) | px);
+        if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)((skip << qshift) | (py << wshift) | px);
         q_count += __popcll(em);
         const unsigned long long im = __ballot(interior);
         if (interior) {
@@ -1955,7 +2024,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         if (q_count >= WAVE) {
             q_count -= WAVE;
             const int q = queue[q_count + lane];
-            if (!(d.debug_flags & 2)) ctx.pixel_full(q & wmask, q >> wshift);
+            if (!(d.debug_flags & 2)) ctx.pixel_full(q & wmask, (q >> wshift) & hmask, q >> qshift);
         }
     };
     // may a box intrude into an otherwise uniform pixel?  centre ray against the footprint-inflated bounding spheres
@@ -2046,7 +2115,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
                 const bool is_pixel = col < wi && py < row0 + ur1;
                 bool interior = is_pixel;
                 if (interior && ctx.boxes_in_view && box_may_touch(px, py)) interior = false;
-                emit(px, py, is_pixel, interior, ukey);
+                emit(px, py, is_pixel, interior, ukey, 0);
             }
             if (prows <= 0) continue;
         }
@@ -2077,7 +2146,10 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             bool interior = !(d.debug_flags & 1) && is_pixel && ok && key == k_br && key == k_tl && key == k_tr &&
                             path == p_br && path == p_tl && path == p_tr;
             if (interior && ctx.boxes_in_view && box_may_touch(px, py)) interior = false;
-            emit(px, py, is_pixel, interior, key);
+            int skip = common_crossings(path, p_br);
+            const int s_tl = common_crossings(path, p_tl), s_tr = common_crossings(path, p_tr);
+            skip = skip < s_tl ? skip : s_tl; skip = skip < s_tr ? skip : s_tr; skip = skip < skip_max ? skip : skip_max;
+            emit(px, py, is_pixel, interior, key, skip);
         }
     }
     // Leftovers (< 64 per wave and queue): pooled over the workgroup and dealt out again in full batches - interior
@@ -2107,7 +2179,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         }
         if (owner >= 0) {
             const int q = queues[owner * QUEUE_CAP + g];
-            ctx.pixel_full(q & wmask, q >> wshift);
+            ctx.pixel_full(q & wmask, (q >> wshift) & hmask, q >> qshift);
         }
     }
     __syncthreads();

@@ -300,25 +300,31 @@ def test_random_view_sweep_matches_oracle(oracle_mod, env_id, task, args, mes, d
 def test_fast_path_equals_full_sample_path(env_id, n, steps, dr, monkeypatch):
     """The corner-ray interior classification must never change a result: tens of thousands of frames
     rendered with it are bit-identical (obs and depth) to the same frames rendered with every pixel
-    resolved by the full 8-sample path (MWB_DEBUG=1 disables the classification at mwb_create)."""
+    resolved by the full 8-sample path (MWB_DEBUG=1 disables the classification at mwb_create), each of its eight
+    traversals started in the eye's room (bit 3, MWB_DEBUG=9: no skipping of the portal crossings the corner rays share)."""
     import torch
     from gym_miniworld_amd.batch import BatchedMiniWorld
     fast = BatchedMiniWorld(env_id, num_envs=n, seed=31, domain_rand=dr, want_depth=True)
-    monkeypatch.setenv("MWB_DEBUG", "1")
+    monkeypatch.setenv("MWB_DEBUG", "9")
     full = BatchedMiniWorld(env_id, num_envs=n, seed=31, domain_rand=dr, want_depth=True)
+    monkeypatch.setenv("MWB_DEBUG", "1")
+    full_skip = BatchedMiniWorld(env_id, num_envs=n, seed=31, domain_rand=dr, want_depth=True)
     monkeypatch.delenv("MWB_DEBUG")
     assert torch.equal(fast.reset(), full.reset()) and torch.equal(fast.depth, full.depth)
+    assert torch.equal(full_skip.reset(), full.obs) and torch.equal(full_skip.depth, full.depth)
     g = torch.Generator().manual_seed(3)
     for t in range(steps):
         a = torch.randint(0, 3, (n,), generator=g, dtype=torch.int32)
         fast.step(a)
         full.step(a)
+        full_skip.step(a)
+        assert torch.equal(full_skip.obs, full.obs) and torch.equal(full_skip.depth, full.depth), (env_id, t, "prefix skipping changed a frame")
         same = torch.equal(fast.obs, full.obs) and torch.equal(fast.depth, full.depth)
         if not same:
             bad = (fast.obs != full.obs).flatten(1).any(1).nonzero().flatten().tolist()
             raise AssertionError((env_id, t, "envs with differing pixels", bad[:8], len(bad)))
         assert torch.equal(fast.reward64, full.reward64)
-    fast.close(); full.close()
+    fast.close(); full.close(); full_skip.close()
 
 
 @pytest.mark.parametrize("env_id,kwargs,task,args,mes", [

@@ -138,7 +138,7 @@ def test_putnext_views_with_a_carried_box_and_fast_path(oracle_mod, monkeypatch)
     O = oracle_mod
     n = 24
     fast, envs = make_pair(O, n, seed=77, dr=1, depth=True)
-    monkeypatch.setenv("MWB_DEBUG", "1")
+    monkeypatch.setenv("MWB_DEBUG", "9")
     full, _ = make_pair(O, n, seed=77, dr=1, depth=True)
     monkeypatch.delenv("MWB_DEBUG")
     fast.reset(); full.reset()

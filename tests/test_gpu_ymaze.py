@@ -162,7 +162,7 @@ def test_ymaze_random_views_and_fast_path(oracle_mod, monkeypatch, dr):
     O = oracle_mod
     n = 48
     fast, envs = make_pair(O, "MiniWorld-YMaze-v0", [0, 0, 0, 0], n, seed=31, dr=dr, depth=True)
-    monkeypatch.setenv("MWB_DEBUG", "1")
+    monkeypatch.setenv("MWB_DEBUG", "9")
     full, _ = make_pair(O, "MiniWorld-YMaze-v0", [0, 0, 0, 0], n, seed=31, dr=dr, depth=True)
     monkeypatch.delenv("MWB_DEBUG")
     fast.reset(); full.reset()
