@@ -1873,7 +1873,7 @@ struct RenderCtx {
 #define TILE_CX 16   // corner grid of one wave pass: 16 x 4 corners; marching down a strip it classifies 15 x 4 pixels
 #define TILE_CY 4
 #define QUEUE_CAP 128
-#define ITEM_RES_BYTES(W) ((((W) + TILE_CX - 2) / (TILE_CX - 1)) * 4 * 8)   // n_strips x 4 quarters x uint2
+#define ITEM_RES_BYTES(W) ((((W) + TILE_CX - 2) / (TILE_CX - 1)) * 4 * 16)   // n_strips x 4 quarters x uint4
 
 // LDS -> HBM copy of the byte range [begin, end) of the frame with the widest vectors its alignment allows
 template <int THREADS>
@@ -1912,7 +1912,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     uint16_t *queues = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
     uint32_t *ikeys = (uint32_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint32_t);
     uint16_t *ipix = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
-    uint2 *item_res = (uint2 *)(smem + off); off += (size_t)ITEM_RES_BYTES(W);   // per work item: uniform rows + their key
+    uint4 *item_res = (uint4 *)(smem + off); off += (size_t)ITEM_RES_BYTES(W);   // per work item: uniform rows + their key
     uint8_t *fb = smem + off;   // the frame is assembled in LDS and leaves as 16-byte coalesced stores
 
     {   // stage the room table, the frame constants and the texture descriptors
@@ -2064,6 +2064,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
                 uint32_t key = ctx.template trace<true>(dv, th, path);
                 const uint32_t kind = key & 7u;
                 const bool ok = (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
+                const uint32_t path_raw = path;   // the crossings made, whatever was met in the end
                 if (!ok) { key = 0xF0000000u | (uint32_t)lane; path = (uint32_t)lane; }   // equal to no other lane's
                 // lane (rr = 0, k) owns item (strip, q): its corners sit at lanes +0 +1 (top), +8 +9 (rows - 8), +16 +17 (8), +24 +25 (bottom)
                 uint32_t nk[8], np[8];
@@ -2081,7 +2082,21 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
                 if (all_u) { ur1 = rows; ukey = nk[0]; }
                 else if (top_u && ha < rows) { ur1 = ha; ukey = nk[0]; }
                 else if (bot_u && hb > 0) { ur0 = hb; ur1 = rows; ukey = nk[2]; }
-                if (rr == 0 && k < 7 && strip < n_strips) item_res[strip * 4 + q] = make_uint2(ukey, (uint32_t)(ur0 | (ur1 << 8)));
+                // The leading portal crossings the item's four outer corner rays share are made by every ray of the item
+                // (same convexity argument): its corner passes start in the room behind them (found by walking this
+                // lane's own ray, the top-left corner) and the 8-sample pixels add the count to their own.
+                int common = common_crossings(path_raw, __shfl(path_raw, (lane + 1) & (WAVE - 1)));
+                const int c1 = common_crossings(path_raw, __shfl(path_raw, (lane + 24) & (WAVE - 1)));
+                const int c2 = common_crossings(path_raw, __shfl(path_raw, (lane + 25) & (WAVE - 1)));
+                common = common < c1 ? common : c1; common = common < c2 ? common : c2;
+                if ((d.debug_flags & 8) || ctx.cam_room < 0) common = 0;
+                int item_room = ctx.cam_room;
+                if (common > 0) {
+                    const int r = POLY ? walk_rooms_poly(rooms, ctx.cam_room, cam.eye, dv, common) : walk_rooms(rooms, ctx.cam_room, cam.eye, dv, common);
+                    if (r >= 0) item_room = r; else common = 0;
+                }
+                if (rr == 0 && k < 7 && strip < n_strips)
+                    item_res[strip * 4 + q] = make_uint4(ukey, (uint32_t)(ur0 | (ur1 << 16)), (uint32_t)common, (uint32_t)item_room);
             }
         }
         __syncthreads();
@@ -2097,13 +2112,16 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         const int rows = (H - row0) < part_h ? (H - row0) : part_h;   // pixel rows of this item
         if (rows <= 0) continue;
         int prow0 = row0, prows = rows;   // the rows left for the per-pixel corner passes
+        int item_skip = 0, item_room = ctx.cam_room;
         if (d.debug_flags & 128) continue;   // experiment: prologue + copy-out only
         if (!(d.debug_flags & (1 | 32))) {
             const int wi = (W - x0) < (TILE_CX - 1) ? (W - x0) : (TILE_CX - 1);   // pixel columns of this item
-            const uint2 res = item_res[item];   // the frame-level pre-test's verdict (workgroup-uniform address)
+            const uint4 res = item_res[item];   // the frame-level pre-test's verdict (workgroup-uniform address)
             const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)res.x);
             const int urw = __builtin_amdgcn_readfirstlane((int)res.y);
-            const int ur0 = urw & 255, ur1 = urw >> 8;   // uniform rows [ur0, ur1) of the item
+            const int ur0 = urw & 0xFFFF, ur1 = urw >> 16;   // uniform rows [ur0, ur1) of the item
+            item_skip = __builtin_amdgcn_readfirstlane((int)res.z);   // crossings every ray of the item makes, and the room behind them
+            item_room = __builtin_amdgcn_readfirstlane((int)res.w);
             if (ur1 > ur0) {
                 if (ur0 == 0 && ur1 == rows) prows = 0;
                 else if (ur0 == 0) { prow0 = row0 + ur1; prows = rows - ur1; }
@@ -2127,7 +2145,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             float dv[3], th;
             uint32_t path;
             make_ray(cam, (float)(x0 + ci), (float)(H - crow), dv);
-            uint32_t key = ctx.template trace<true>(dv, th, path);
+            uint32_t key = ctx.template trace_from<true>(item_room, dv, th, path);
             const uint32_t kind = key & 7u;
             bool ok = (kind == KIND_FLOOR || kind == KIND_CEIL || kind == KIND_WALL) && !(path & 0x80000000u);
             // the pixel whose bottom-left corner this lane traced: corners (crow-1, ci), (crow-1, ci+1),
@@ -2148,7 +2166,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             if (interior && ctx.boxes_in_view && box_may_touch(px, py)) interior = false;
             int skip = common_crossings(path, p_br);
             const int s_tl = common_crossings(path, p_tl), s_tr = common_crossings(path, p_tr);
-            skip = skip < s_tl ? skip : s_tl; skip = skip < s_tr ? skip : s_tr; skip = skip < skip_max ? skip : skip_max;
+            skip = skip < s_tl ? skip : s_tl; skip = skip < s_tr ? skip : s_tr; skip += item_skip; skip = skip < skip_max ? skip : skip_max;
             emit(px, py, is_pixel, interior, key, skip);
         }
     }
