@@ -11,7 +11,7 @@ rows = []
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*_kernel_trace.csv"), recursive=True):
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0], int(r["Queue_Id"])))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Queue_Id"])))
 rows.sort()
 # steps = from one step_kernel start to the next
 starts = [i for i, r in enumerate(rows) if r[2].startswith("step_kernel")]
