@@ -1464,6 +1464,18 @@ __device__ __forceinline__ int common_crossings(uint32_t a, uint32_t b) {
     return ne < m ? ne : m;
 }
 
+// the same for four paths at once (a pixel's corner rays): one xor-or-clz over the left-aligned words
+__device__ __forceinline__ int common_crossings4(uint32_t a, uint32_t b, uint32_t c, uint32_t e) {
+    if (((a | b | c | e) & 0x80000000u) || a == 0 || b == 0 || c == 0 || e == 0) return 0;
+    const int ca = __builtin_clz(a), cb = __builtin_clz(b), cc = __builtin_clz(c), ce = __builtin_clz(e);
+    const uint32_t A = a << ca;
+    const uint32_t x = (A ^ (b << cb)) | (A ^ (c << cc)) | (A ^ (e << ce));
+    const int eq = x ? __builtin_clz(x) : 32;
+    int cmax = ca > cb ? ca : cb; cmax = cmax > cc ? cmax : cc; cmax = cmax > ce ? cmax : ce;   // the shortest path has the most leading zeros
+    const int m = (31 - cmax) >> 1, ne = (eq - 1) >> 1;
+    return ne < m ? ne : m;
+}
+
 // slab test in box-local axes; returns face 0..5 (-x,+x,-y,+y,-z,+z) or -1
 __device__ __forceinline__ int trace_box(const float *fc, const float *dv, float &t_out) {
     const float c = fc[FC_BOX_C], s = fc[FC_BOX_S];
@@ -2164,9 +2176,8 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             bool interior = !(d.debug_flags & 1) && is_pixel && ok && key == k_br && key == k_tl && key == k_tr &&
                             path == p_br && path == p_tl && path == p_tr;
             if (interior && ctx.boxes_in_view && box_may_touch(px, py)) interior = false;
-            int skip = common_crossings(path, p_br);
-            const int s_tl = common_crossings(path, p_tl), s_tr = common_crossings(path, p_tr);
-            skip = skip < s_tl ? skip : s_tl; skip = skip < s_tr ? skip : s_tr; skip += item_skip; skip = skip < skip_max ? skip : skip_max;
+            int skip = common_crossings4(path, p_br, p_tl, p_tr) + item_skip;
+            skip = skip < skip_max ? skip : skip_max;
             emit(px, py, is_pixel, interior, key, skip);
         }
     }
