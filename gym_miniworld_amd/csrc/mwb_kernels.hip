@@ -2337,7 +2337,7 @@ size_t mwb_reset_lds_bytes(const MwbDev &d) {
 size_t mwb_render_lds_bytes(const MwbDev &d) {
     size_t b = (((size_t)d.R_max * d.room_words * 4 + 15) & ~(size_t)15) + (size_t)d.frame_words * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
                (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)ITEM_RES_BYTES(d.W) + (size_t)d.W * d.H * 3;
-    b += (size_t)(d.debug_flags >> 8) * 1024;   // MWB_DEBUG bits 8+: KiB of LDS padding (occupancy experiments)
+    b += (size_t)(d.debug_flags >> 8) * 128;   // MWB_DEBUG bits 8+: units of 128 B of LDS padding (occupancy experiments)
     return (b + 15) & ~(size_t)15;
 }
 

@@ -1,7 +1,7 @@
 """A/B timing of the render kernel's phases in one process via MWB_DEBUG (read at mwb_create):
 1 = every pixel through the 8-sample path, 2 = skip the 8-sample path, 4 = skip interior shading,
 6 = corner passes + prologue only; 70 = 6 without the per-pixel corner passes (prologue, item pre-tests, copy-out);
-134 = prologue + copy-out only; bits 8+ = KiB of LDS padding (occupancy experiments)."""
+134 = prologue + copy-out only; bits 8+ = units of 128 B of LDS padding (occupancy experiments)."""
 import sys, os, time
 sys.path.insert(0, '.')
 import torch
