@@ -18,7 +18,7 @@ from oracle import oracle as O  # noqa: E402
 TASKS = [("MiniWorld-Hallway-v0", "Hallway"), ("MiniWorld-OneRoom-v0", "OneRoom"), ("MiniWorld-FourRooms-v0", "FourRooms"),
          ("MiniWorld-Maze-v0", "Maze"), ("MiniWorld-MazeS3-v0", "Maze"), ("MiniWorld-TMaze-v0", "TMaze"),
          ("MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0", "TMazeTwoBox"), ("MiniWorld-SimToRealGoTo-v0", "SimToRealGoTo"),
-         ("MiniWorld-SimToRealPush-v0", "SimToRealPush")]
+         ("MiniWorld-SimToRealPush-v0", "SimToRealPush"), ("MiniWorld-PutNext-v0", "PutNext"), ("MiniWorld-YMaze-v0", "YMaze")]
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1536
 n = 64
 for env_id, task in TASKS:
