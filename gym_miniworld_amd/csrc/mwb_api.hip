@@ -842,6 +842,10 @@ extern "C" int mwb_timing_enable(mwb_handle *h, int enable) {
     h->timing_period = enable > 1 ? enable : 1;
     h->timing_tick = 0;
     h->ev_used = 0;
+    if (h->timing && h->ev_pool.empty()) {   // the first block of events is created here, not inside somebody's timed region
+        h->ev_pool.resize((size_t)EVN * 256);
+        for (size_t i = 0; i < h->ev_pool.size(); i++) HIP_TRY(hipEventCreate(&h->ev_pool[i]));
+    }
     return MWB_OK;
 }
 
