@@ -229,6 +229,14 @@ class BatchedMiniWorld:
         _lib.check(self.L.mwb_render(self.h, self._stream()))
         return self.obs
 
+    def render_top_view(self, width=None, height=None):
+        """MiniWorldEnv.render_top_view(frame_buffer) for every env (miniworld.py:1087-1158): uint8 [N, height, width, 3] on
+        the device, default the observation size (the reference's default frame buffer is obs_fb)."""
+        W, H = int(width or self.W), int(height or self.H)
+        out = self.torch.empty((self.num_envs, H, W, 3), dtype=self.torch.uint8, device=self.device)
+        _lib.check(self.L.mwb_render_top_view(self.h, out.data_ptr(), W, H, self._stream()))
+        return out
+
     # ---------------------------------------------------------------------------- introspection
     def check(self):
         """Synchronous: raises if world generation ever flagged a failure (see mwb_check)."""

@@ -265,7 +265,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N * d.n_boxes); A(d.box_z, N * d.n_boxes); A(d.box_y, N * d.n_boxes); A(d.box_dir, N * d.n_boxes); A(d.carrying, N);
     A(d.box_color, N * d.n_boxes * 3); A(d.box_size, N * d.n_boxes); A(d.goal_dist, N); A(d.episode_count, N); A(d.task_step_count, N); A(d.goal_idx, N); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
     A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.reset_set, N); A(d.reset_list, N); A(d.reset_count, (size_t)1);
-    A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * d.room_words); A(d.segs, N * d.S_max * 4); A(d.frame, N * d.frame_words);
+    A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * d.room_words); A(d.segs, N * d.S_max * 4); A(d.frame, N * d.frame_words); A(d.world_ext, N * 4);
     A(d.obs, N * d.W * d.H * 3);
     if (d.want_depth) { A(d.depth, N * d.W * d.H); }
     {   // the small per-step outputs share one allocation (one D2H copy for a host-side consumer); 16-byte aligned parts
@@ -551,6 +551,18 @@ extern "C" int mwb_render(mwb_handle *h, void *stream) {
     rc = timing_begin(h, s); if (rc) return rc;
     TMARK(1); TMARK(5); TMARK(6); TMARK(2);
     return render_tail(h, 0, s);
+}
+
+extern "C" int mwb_render_top_view(mwb_handle *h, uint8_t *out_dev, int width, int height, void *stream) {
+    if (!h || !out_dev) return set_err(MWB_EINVAL, "mwb_render_top_view: null argument");
+    if (width < 1 || height < 1 || width > 4096 || height > 4096) return set_err(MWB_EINVAL, "mwb_render_top_view: bad frame size");
+    USE_DEVICE(h->cfg.device);
+    int rc = ensure_ready(h); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    mwb_launch_prep(h->dev, 0, s);   // the state may have been set from outside since the last render
+    rc = check_launch("prep_kernel"); if (rc) return rc;
+    mwb_launch_top_view(h->dev, out_dev, width, height, s);
+    return check_launch("top_view_kernel");
 }
 
 extern "C" int mwb_get_outputs(mwb_handle *h, mwb_outputs *out) {

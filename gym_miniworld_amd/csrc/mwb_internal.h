@@ -130,6 +130,7 @@ struct MwbDev {
     float *rooms;           // [N][R_max][room_words]
     double *segs;           // [S_max][4][N]
     float *frame;           // [N][frame_words]
+    double *world_ext;      // [N][4] min_x max_x min_z max_z of the floorplan (miniworld.py:576-579), written by reset_kernel
     const uint32_t *texels;
     const MwbTexDesc *tex_desc;   // [MWB_MAX_TEX] in device memory
     // outputs
@@ -161,6 +162,7 @@ void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s);
 void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s);
 void mwb_launch_stack(const MwbDev &d, void *stack, int nstack, int dtype, int after_reset, hipStream_t s);
 void mwb_launch_intersect(const MwbDev &d, int env, int ent, double x, double z, double radius, int *result_dev, hipStream_t s);
+void mwb_launch_top_view(const MwbDev &d, uint8_t *out, int W, int H, hipStream_t s);   // render_top_view for every env, [N][H][W][3]
 int mwb_prepare_kernels(const MwbDev &d);   // 0 ok, -1 world too large for LDS, -2 HIP error, -3 frame too large for the pixel queue
 size_t mwb_reset_lds_bytes(const MwbDev &d);
 size_t mwb_render_lds_bytes(const MwbDev &d);

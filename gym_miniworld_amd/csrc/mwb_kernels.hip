@@ -1024,6 +1024,14 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         for (int k = 0; k < 4; k++) d.cam[e * 4 + k] = cam[k];
         d.step_count[e] = 0;
         d.n_rooms[e] = w.fail ? -1 : w.n_rooms;
+        {   // extents of the floorplan (miniworld.py:576-579), float64: the top view's frame
+            double mnx = rooms[0].min_x, mxx = rooms[0].max_x, mnz = rooms[0].min_z, mxz = rooms[0].max_z;
+            for (int i = 1; i < w.n_rooms; i++) {
+                mnx = fmin(mnx, rooms[i].min_x); mxx = fmax(mxx, rooms[i].max_x);
+                mnz = fmin(mnz, rooms[i].min_z); mxz = fmax(mxz, rooms[i].max_z);
+            }
+            d.world_ext[e * 4 + 0] = mnx; d.world_ext[e * 4 + 1] = mxx; d.world_ext[e * 4 + 2] = mnz; d.world_ext[e * 4 + 3] = mxz;
+        }
         if (w.fail) atomicExch(d.error_flag, e + 1);
         d.n_segs[e] = w.n_segs;
     }
@@ -2408,6 +2416,145 @@ void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
     else if (mode == 2) render_kernel<RENDER_THREADS, 2, 1><<<g, b, lds, s>>>(d);
     else render_kernel<RENDER_THREADS, 0, 1><<<g, b, lds, s>>>(d);
 }
+// ================================================================================== top view
+// MiniWorldEnv.render_top_view (miniworld.py:1087-1158) for the whole batch: the floorplan from straight above (glOrtho over its
+// extents + 1 m, widened to the frame's aspect), agent drawn.  Not on the training path - a display / debugging view, so
+// simple: one workgroup per env, pixels strided over the threads, room tables read through L2.  Walls and box sides are
+// edge-on and cover nothing; ceilings are back-face culled except those of rooms whose outline runs the other way round
+// (they face up).  A sample sees the highest of: such a ceiling, the agent's triangle at agent.height (entity.py:494-514;
+// lit with the normal the last box face left current, (0, -1, 0)), a box's top face, the floor of the first room holding the
+// point, else the clear colour; equal heights go to what is drawn first (rooms, boxes in list order, agent).  Frozen float32
+// choices as DESIGN.md 5.7: x = fmaf(wx, XS, X0), z = fmaf(-wy, ZS, Z1); inclusive containment tests; 8 coverage samples,
+// one shade per (pixel, surface) at the pixel centre, LOD from the +1 pixel neighbours.
+template <bool POLY>
+__global__ void __launch_bounds__(256) top_view_kernel(MwbDev d, uint8_t *__restrict__ out, int W, int H) {
+    __shared__ TexLds tex[MWB_MAX_TEX];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < (int)(sizeof(TexLds) / 4) * d.n_tex; i += 256) ((uint32_t *)tex)[i] = ((const uint32_t *)d.tex_desc)[i];
+    __syncthreads();
+    int n_rooms = d.n_rooms[e];
+    if (n_rooms < 0) n_rooms = 0;
+    const float *rooms = d.rooms + (size_t)e * d.R_max * d.room_words;
+    const float *fc = d.frame + (size_t)e * d.frame_words;
+    double min_x = d.world_ext[e * 4 + 0] - 1, max_x = d.world_ext[e * 4 + 1] + 1, min_z = d.world_ext[e * 4 + 2] - 1, max_z = d.world_ext[e * 4 + 3] + 1;
+    {
+        const double width = max_x - min_x, height = max_z - min_z, aspect = width / height, fb_aspect = (double)W / (double)H;
+        if (aspect > fb_aspect) { const double new_h = width / fb_aspect, h_diff = new_h - height; min_z -= h_diff / 2; max_z += h_diff / 2; }
+        else if (aspect < fb_aspect) { const double new_w = height * fb_aspect, w_diff = new_w - width; min_x -= w_diff / 2; max_x += w_diff / 2; }
+    }
+    const float X0 = (float)min_x, XS = (float)((max_x - min_x) / (double)W), Z1 = (float)max_z, ZS = (float)((max_z - min_z) / (double)H);
+    // the agent's triangle (float64 as the reference, then float32) and its height
+    float tri[3][2];
+    {
+        const double adir = d.agent_dir[e], ar = d.agent_radius, ax = d.agent_x[e], az = d.agent_z[e];
+        const double c = ref_cos(adir), s_ = ref_sin(adir);
+        const double dvx = c * ar, dvz = -s_ * ar, rvx = s_ * ar, rvz = c * ar;
+        tri[0][0] = (float)(ax + dvx); tri[0][1] = (float)(az + dvz);
+        tri[1][0] = (float)(ax + 0.75 * (rvx - dvx)); tri[1][1] = (float)(az + 0.75 * (rvz - dvz));
+        tri[2][0] = (float)(ax + 0.75 * (-rvx - dvx)); tri[2][1] = (float)(az + 0.75 * (-rvz - dvz));
+    }
+    const float agent_y = (float)(0.0 + 1.6);   // pos.y + Agent.height (entity.py:449)
+    float lit_agent[3];
+    {
+        const float amb = (float)d.light_ambient[e * 3];
+        const float v = (0.2f * 1.0f + amb * 1.0f) + 0.0f * (float)d.light_color[e * 3] * 1.0f;
+        lit_agent[0] = v > 1.0f ? 1.0f : v; lit_agent[1] = 0.0f; lit_agent[2] = 0.0f;
+    }
+    enum { T_SKY = 0, T_FLOOR = 1, T_CEIL = 2, T_BOX = 4, T_AGENT = 5 };
+    auto classify = [&](float x, float z, float &y_out) -> uint32_t {
+        uint32_t key = T_SKY;
+        float ybest = -INFINITY;
+        for (int i = 0; i < n_rooms; i++) {
+            bool in, culled = false;
+            float height;
+            if (!POLY) {
+                const float4 rect = *(const float4 *)(rooms + i * MWB_ROOM_WORDS + RW_MINX);
+                in = x >= rect.x && x <= rect.y && z >= rect.z && z <= rect.w;
+                height = rooms[i * MWB_ROOM_WORDS + RW_HEIGHT];
+            } else {
+                const float *r = rooms + i * MWB_POLY_ROOM_WORDS;
+                culled = ((__float_as_int(r[PW_FLAGS]) >> 8) & 1) != 0;
+                const int ne = __float_as_int(r[PW_FLAGS]) & 255;
+                height = r[PW_HEIGHT];
+                in = true;
+                for (int q = 0; q < ne; q++) {
+                    const float *ed = r + PW_EDGE0 + PW_EDGE_WORDS * q;
+                    const float side = fmaf(ed[5], z - ed[1], ed[4] * (x - ed[0]));
+                    if (culled ? !(side <= 0.0f) : !(side >= 0.0f)) in = false;   // a reversed outline's normals point outwards
+                }
+            }
+            if (!in) continue;
+            if (!culled && 0.0f > ybest) { key = T_FLOOR | ((uint32_t)i << 3); ybest = 0.0f; }
+            if (culled && !(height < 0.0f) && height > ybest) { key = T_CEIL | ((uint32_t)i << 3); ybest = height; }
+        }
+        for (int b = 0; b < d.n_boxes; b++) {
+            const float *fb = fc + b * FC_BOX_STRIDE;
+            const float rx = x - fb[FC_BOX_POS], rz = z - fb[FC_BOX_POS + 2];
+            const float lx = rx * fb[FC_BOX_C] - rz * fb[FC_BOX_S], lz = rx * fb[FC_BOX_S] + rz * fb[FC_BOX_C];
+            const float top = fb[FC_BOX_POS + 1] + fb[FC_BOX_SY];
+            if (fabsf(lx) <= fb[FC_BOX_HX] && fabsf(lz) <= fb[FC_BOX_HZ] && top > ybest) { key = T_BOX | ((uint32_t)b << 3); ybest = top; }
+        }
+        {
+            float sgn[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const float *a = tri[q], *b = tri[(q + 1) % 3];
+                sgn[q] = fmaf(b[0] - a[0], z - a[1], -((b[1] - a[1]) * (x - a[0])));
+            }
+            const bool in = (sgn[0] >= 0 && sgn[1] >= 0 && sgn[2] >= 0) || (sgn[0] <= 0 && sgn[1] <= 0 && sgn[2] <= 0);
+            if (in && agent_y > ybest) { key = T_AGENT; ybest = agent_y; }
+        }
+        y_out = ybest;
+        return key;
+    };
+    for (int p = tid; p < W * H; p += 256) {
+        const int py = p / W, px = p - py * W;
+        const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
+        uint32_t keys[8];
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) {
+            const float wx = cx + c_sample_x[k], wy = cy + c_sample_y[k];
+            float yy;
+            keys[k] = classify(fmaf(wx, XS, X0), fmaf(-wy, ZS, Z1), yy);
+        }
+        const float xc = fmaf(cx, XS, X0), zc = fmaf(-cy, ZS, Z1);
+        float acc[3] = {0, 0, 0};
+        uint32_t done_mask = 0;
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) {
+            if (done_mask & (1u << k)) continue;
+            int cnt = 0;
+            for (int j = k; j < 8; j++)
+                if (!(done_mask & (1u << j)) && keys[j] == keys[k]) { cnt++; done_mask |= 1u << j; }
+            const uint32_t kind = keys[k] & 7u, idx = keys[k] >> 3;
+            float col[3];
+            if (kind == T_SKY) { col[0] = fc[FC_SKY]; col[1] = fc[FC_SKY + 1]; col[2] = fc[FC_SKY + 2]; }
+            else if (kind == T_BOX) { const float *lb = fc + idx * FC_BOX_STRIDE + FC_LIT_BOX + 3 * 3; col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2]; }   // face 3 = +y
+            else if (kind == T_AGENT) { col[0] = lit_agent[0]; col[1] = lit_agent[1]; col[2] = lit_agent[2]; }
+            else {
+                const uint32_t texw = (uint32_t)__float_as_int(rooms[idx * (POLY ? MWB_POLY_ROOM_WORDS : MWB_ROOM_WORDS) + (POLY ? PW_TEX : RW_TEX)]);
+                const uint32_t tex_id = (kind == T_FLOOR ? (texw >> 8) : (texw >> 16)) & 255u;
+                const TexLds &T = tex[tex_id];
+                const float *lit = fc + (kind == T_FLOOR ? FC_LIT_FLOOR : FC_LIT_CEIL);
+                float texel[3];
+                sample_texture(d.texels, T, xc * T.sc_s, zc * T.sc_t, (xc + XS) * T.sc_s, zc * T.sc_t, xc * T.sc_s, (zc - ZS) * T.sc_t, true, texel);
+                for (int q = 0; q < 3; q++) col[q] = lit[q] * (texel[q] * (1.0f / 255.0f));
+            }
+            for (int q = 0; q < 3; q++) acc[q] += (float)cnt * col[q];
+        }
+        uint8_t *o = out + ((size_t)e * W * H + p) * 3;
+        for (int q = 0; q < 3; q++) {
+            float v = acc[q] * 0.125f;
+            v = __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f);
+            o[q] = (uint8_t)(unsigned)(v * 255.0f + 0.5f);
+        }
+    }
+}
+void mwb_launch_top_view(const MwbDev &d, uint8_t *out, int W, int H, hipStream_t s) {
+    if (d.poly) top_view_kernel<true><<<dim3(d.N), dim3(256), 0, s>>>(d, out, W, H);
+    else top_view_kernel<false><<<dim3(d.N), dim3(256), 0, s>>>(d, out, W, H);
+}
+
 void mwb_launch_intersect(const MwbDev &d, int env, int ent, double x, double z, double radius, int *result_dev, hipStream_t s) {
     hipLaunchKernelGGL(intersect_kernel, dim3(1), dim3(64), 0, s, d, env, ent, x, z, radius, result_dev);
 }

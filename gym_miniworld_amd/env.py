@@ -153,6 +153,19 @@ class MiniWorldEnv:
         self._b.render()
         return self._b.depth.cpu().numpy()[0]
 
+    def render_top_view(self, width=None, height=None):
+        """miniworld.py:1087-1158 (frame size: the reference passes a frame buffer; default the observation's)"""
+        return self._b.render_top_view(width, height).cpu().numpy()[0]
+
+    def render(self, mode="rgb_array", close=False, view="agent"):
+        """miniworld.py:1317-1335, mode 'rgb_array' only (there is no window here): the 800 x 600 human-view frame"""
+        if close:
+            return None
+        assert view in ("agent", "top") and mode == "rgb_array", "only mode='rgb_array' exists without a window"
+        if view == "top":
+            return self.render_top_view(800, 600)
+        raise NotImplementedError("view='agent' at 800 x 600 needs a second observation size: construct the env with obs_width=800, obs_height=600")
+
     def intersect(self, ent, pos, radius):
         """miniworld.py:933-959: True for a wall, the other entity for an entity hit, else None."""
         idx = next((i for i, e2 in enumerate(self.entities) if e2 is ent), -1)

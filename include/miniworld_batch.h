@@ -228,6 +228,12 @@ int mwb_room_words(mwb_handle *h);
 int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_rooms, double *segs, int max_segs,
                      int *n_rooms, int *n_segs);
 
+/* replaces: MiniWorldEnv.render_top_view(frame_buffer) (miniworld.py:1087-1158; `render(view='top')` 1317-1335) for the whole
+ * batch: the floorplan from straight above, extents + 1 m widened to the frame's aspect, floors, box tops and the agent's
+ * triangle.  out_dev: uint8 [N][height][width][3] in device memory, any frame size; enqueued on `stream`.  A display /
+ * debugging view, not part of the step pipeline. */
+int mwb_render_top_view(mwb_handle *h, uint8_t *out_dev, int width, int height, void *stream);
+
 /* ---- timing hooks used by bench.py -------------------------------------------------------- */
 /* average device time (ms) of each kernel of the step pipeline since the last call (HIP events
  * recorded on the stream the kernels were launched on); names: "step","reset","prep","render".

@@ -1567,6 +1567,140 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
     free(pr);
 }
 
+/* ---- render_top_view (miniworld.py:1087-1158): glOrtho over the floorplan's extents + 1 m (widened to the frame's aspect),
+ * looking straight down (modelview x -> x, z -> -y, y -> z), _render_world(render_agent=True).  Walls and box sides are
+ * vertical: edge-on, they cover nothing.  Ceilings face away from the viewer (back-face culled) - except those of rooms whose
+ * outline runs the other way round (YMaze's connector slivers), which face UP.  What a sample sees is the highest of: such a
+ * ceiling, the agent's triangle at agent.height (entity.py:494-514; it is lit with the normal the last box face left current,
+ * (0, -1, 0): ambient terms only), a box's top face, the floor of the first room (creation order) that holds the point, else the
+ * clear colour; equal heights go to the surface drawn first (GL_LESS): rooms, boxes in list order, agent.
+ * Frozen choices (float32): x = fmaf(wx, XS, X0), z = fmaf(-wy, ZS, Z1) for window coordinates (wx, wy up), XS = width / W,
+ * ZS = height / H from the float64 extents; containment tests inclusive; 8 coverage samples and one shade per (pixel, surface)
+ * at the pixel centre as in mwo_render; LOD from the +1 pixel neighbours (x + XS, z) and (x, z - ZS). */
+typedef struct { int kind, idx; float y; } TopHit;   /* kind: 0 clear colour, 1 floor, 2 up-facing ceiling, 4 box top, 5 agent */
+
+void mwo_render_top(MwoEnv *e, int W, int H, uint8_t *rgb) {
+    const int poly = e->task == MWO_YMAZE;
+    RRoom *rr = (RRoom *)malloc(sizeof(RRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));
+    PRoom *pr = (PRoom *)malloc(sizeof(PRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));
+    int n_rooms = poly ? build_prooms(e, pr) : build_rrooms(e, rr);
+    /* extents, miniworld.py:576-579 and 1108-1131 */
+    double min_x = e->rooms[0].min_x, max_x = e->rooms[0].max_x, min_z = e->rooms[0].min_z, max_z = e->rooms[0].max_z;
+    for (int i = 1; i < e->n_rooms; i++) {
+        if (e->rooms[i].min_x < min_x) min_x = e->rooms[i].min_x;
+        if (e->rooms[i].max_x > max_x) max_x = e->rooms[i].max_x;
+        if (e->rooms[i].min_z < min_z) min_z = e->rooms[i].min_z;
+        if (e->rooms[i].max_z > max_z) max_z = e->rooms[i].max_z;
+    }
+    min_x -= 1; max_x += 1; min_z -= 1; max_z += 1;
+    {
+        double width = max_x - min_x, height = max_z - min_z, aspect = width / height, fb_aspect = (double)W / (double)H;
+        if (aspect > fb_aspect) { double new_h = width / fb_aspect, h_diff = new_h - height; min_z -= h_diff / 2; max_z += h_diff / 2; }
+        else if (aspect < fb_aspect) { double new_w = height * fb_aspect, w_diff = new_w - width; min_x -= w_diff / 2; max_x += w_diff / 2; }
+    }
+    const float X0 = (float)min_x, XS = (float)((max_x - min_x) / (double)W), Z1 = (float)max_z, ZS = (float)((max_z - min_z) / (double)H);
+    Light L;
+    double lp[3] = {e->light_pos[0] + 1, e->light_pos[1] + 1, e->light_pos[2] + 1};
+    double ll = sqrt(lp[0] * lp[0] + lp[1] * lp[1] + lp[2] * lp[2]);
+    for (int k = 0; k < 3; k++) {
+        L.light_dir[k] = (float)(lp[k] / ll); L.amb[k] = (float)e->light_ambient[k]; L.diff[k] = (float)e->light_color[k];
+        L.sky[k] = (float)e->sky_color[k];
+    }
+    const float white[3] = {1, 1, 1}, red[3] = {1, 0, 0}, up[3] = {0, 1, 0}, down[3] = {0, -1, 0};
+    float lit_floor[3], lit_ceil[3], lit_agent[3], lit_top[MWO_MAX_BOXES][3];
+    lit_color(&L, up, white, lit_floor); lit_color(&L, down, white, lit_ceil); lit_color(&L, down, red, lit_agent);
+    float bx[MWO_MAX_BOXES], bz[MWO_MAX_BOXES], bc[MWO_MAX_BOXES], bs[MWO_MAX_BOXES], bh[MWO_MAX_BOXES], btop[MWO_MAX_BOXES];
+    for (int b = 0; b < e->n_boxes; b++) {
+        const Ent *be = &e->boxes[b];
+        float col[3];
+        for (int k = 0; k < 3; k++) col[k] = (float)e->box_colors[b][k];
+        lit_color(&L, up, col, lit_top[b]);
+        bx[b] = (float)be->pos[0]; bz[b] = (float)be->pos[2]; bc[b] = (float)cos(be->dir); bs[b] = (float)sin(be->dir);
+        bh[b] = (float)(e->box_s[b] / 2); btop[b] = (float)be->pos[1] + (float)e->box_s[b];
+    }
+    /* the agent's triangle, entity.py:502-510 */
+    float tri[3][2];
+    {
+        const Ent *a = &e->agent;
+        double dvx = cos(a->dir) * a->radius, dvz = -sin(a->dir) * a->radius, rvx = sin(a->dir) * a->radius, rvz = cos(a->dir) * a->radius;
+        tri[0][0] = (float)(a->pos[0] + dvx); tri[0][1] = (float)(a->pos[2] + dvz);
+        tri[1][0] = (float)(a->pos[0] + 0.75 * (rvx - dvx)); tri[1][1] = (float)(a->pos[2] + 0.75 * (rvz - dvz));
+        tri[2][0] = (float)(a->pos[0] + 0.75 * (-rvx - dvx)); tri[2][1] = (float)(a->pos[2] + 0.75 * (-rvz - dvz));
+    }
+    const float agent_y = (float)(e->agent.pos[1] + e->agent.height);
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
+            TopHit hits[8];
+            for (int k = 0; k < 8; k++) {
+                const float wx = cx + SAMPLE_X[k] * 0.0625f, wy = cy + SAMPLE_Y[k] * 0.0625f;
+                const float x = fmaf(wx, XS, X0), z = fmaf(-wy, ZS, Z1);
+                TopHit h = {0, 0, -INFINITY};
+                for (int i = 0; i < n_rooms; i++) {   /* rooms first (drawn first): floor at 0, an up-facing ceiling at its height */
+                    int in, culled = 0; float height;
+                    if (!poly) { in = x >= rr[i].min_x && x <= rr[i].max_x && z >= rr[i].min_z && z <= rr[i].max_z; height = rr[i].height; }
+                    else {
+                        culled = pr[i].culled; height = pr[i].height; in = 1;
+                        for (int q = 0; q < pr[i].ne; q++) {
+                            const PEdge *pe = &pr[i].e[q];
+                            float side = fmaf(pe->nz, z - pe->pz, pe->nx * (x - pe->px));
+                            if (culled ? !(side <= 0.0f) : !(side >= 0.0f)) in = 0;   /* a reversed outline's normals point outwards */
+                        }
+                    }
+                    if (!in) continue;
+                    if (!culled && 0.0f > h.y) { h.kind = 1; h.idx = i; h.y = 0.0f; }
+                    if (culled && !pr[i].no_ceiling && height > h.y) { h.kind = 2; h.idx = i; h.y = height; }
+                }
+                for (int b = 0; b < e->n_boxes; b++) {
+                    const float rx = x - bx[b], rz = z - bz[b];
+                    const float lx = rx * bc[b] - rz * bs[b], lz = rx * bs[b] + rz * bc[b];
+                    if (fabsf(lx) <= bh[b] && fabsf(lz) <= bh[b] && btop[b] > h.y) { h.kind = 4; h.idx = b; h.y = btop[b]; }
+                }
+                {
+                    float s0 = 0, s1 = 0, s2 = 0;
+                    for (int q = 0; q < 3; q++) {
+                        const float *a = tri[q], *b = tri[(q + 1) % 3];
+                        float ef = fmaf(b[0] - a[0], z - a[1], -((b[1] - a[1]) * (x - a[0])));
+                        if (q == 0) s0 = ef; else if (q == 1) s1 = ef; else s2 = ef;
+                    }
+                    int in = (s0 >= 0 && s1 >= 0 && s2 >= 0) || (s0 <= 0 && s1 <= 0 && s2 <= 0);
+                    if (in && agent_y > h.y) { h.kind = 5; h.idx = 0; h.y = agent_y; }
+                }
+                hits[k] = h;
+            }
+            const float xc = fmaf(cx, XS, X0), zc = fmaf(-cy, ZS, Z1);
+            float acc[3] = {0, 0, 0};
+            int done_mask = 0;
+            for (int k = 0; k < 8; k++) {
+                if (done_mask & (1 << k)) continue;
+                int cnt = 0;
+                for (int j = k; j < 8; j++)
+                    if (!(done_mask & (1 << j)) && hits[j].kind == hits[k].kind && hits[j].idx == hits[k].idx) { cnt++; done_mask |= 1 << j; }
+                float col[3];
+                const TopHit *h = &hits[k];
+                if (h->kind == 0) { col[0] = L.sky[0]; col[1] = L.sky[1]; col[2] = L.sky[2]; }
+                else if (h->kind == 4) { col[0] = lit_top[h->idx][0]; col[1] = lit_top[h->idx][1]; col[2] = lit_top[h->idx][2]; }
+                else if (h->kind == 5) { col[0] = lit_agent[0]; col[1] = lit_agent[1]; col[2] = lit_agent[2]; }
+                else {
+                    int tex = h->kind == 1 ? (poly ? pr[h->idx].floor_tex : rr[h->idx].floor_tex) : pr[h->idx].ceil_tex;
+                    const float *lit = h->kind == 1 ? lit_floor : lit_ceil;
+                    float sc_s = (float)(512.0 / tex_width(tex)), sc_t = (float)(512.0 / tex_height(tex));
+                    float texel[3];
+                    sample_texture(tex, xc * sc_s, zc * sc_t, (xc + XS) * sc_s, zc * sc_t, xc * sc_s, (zc - ZS) * sc_t, 1, texel);
+                    for (int q = 0; q < 3; q++) col[q] = lit[q] * (texel[q] * (1.0f / 255.0f));
+                }
+                for (int q = 0; q < 3; q++) acc[q] += (float)cnt * col[q];
+            }
+            for (int q = 0; q < 3; q++) {
+                float v = acc[q] * 0.125f;
+                v = v < 0 ? 0 : (v > 1 ? 1 : v);
+                rgb[(py * W + px) * 3 + q] = (uint8_t)(int)floorf(v * 255.0f + 0.5f);
+            }
+        }
+    free(rr);
+    free(pr);
+}
+
 /* ====================================================================== bench helper */
 static uint64_t splitmix(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;

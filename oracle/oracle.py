@@ -86,6 +86,7 @@ def lib():
         L.mwo_get_geometry.argtypes = [vp] + [vp] * 13
         L.mwo_intersect.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         L.mwo_render.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp]
+        L.mwo_render_top.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
         L.mwo_set_texture.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
         L.mwo_intersect_circle_segs.argtypes = [dp, ctypes.c_double, dp, ctypes.c_int]
         L.mwo_gen_rot_matrix.argtypes = [dp, ctypes.c_double, dp]
@@ -247,6 +248,13 @@ class OracleEnv:
         self.L.mwo_render(self.h, self.W, self.H, rgb.ctypes.data_as(ctypes.c_void_p),
                           dep.ctypes.data_as(ctypes.c_void_p) if depth else None)
         return (rgb, dep) if depth else rgb
+
+    def render_top(self, width=None, height=None):
+        """render_top_view(frame_buffer) (miniworld.py:1087-1158) at width x height (default: the observation size)"""
+        W, H = int(width or self.W), int(height or self.H)
+        rgb = np.zeros((H, W, 3), np.uint8)
+        self.L.mwo_render_top(self.h, W, H, rgb.ctypes.data_as(ctypes.c_void_p))
+        return rgb
 
     def geometry(self):
         s = self.state()

@@ -432,8 +432,10 @@ def parse_gl_log(log):
         elif name == "glEnd":
             polys.append(poly)
             poly = None
-        elif name in ("gluPerspective", "gluLookAt", "glClearColor", "glClearDepth"):
+        elif name in ("gluPerspective", "gluLookAt", "glClearColor", "glClearDepth", "glOrtho"):
             misc[name] = [float(x) for x in args]
+        elif name == "glLoadMatrixf":
+            misc[name] = [float(x) for x in args[0]]
     return polys, lights, misc
 
 
@@ -515,6 +517,39 @@ def capture_gl(cls, kwargs, seed, dr, pose=None):
     }
 
 
+def capture_gl_top(cls, kwargs, seed, dr, pose=None):
+    """render_top_view() (miniworld.py:1087-1158) under the call recorder: the room polygons of the display list (recorded
+    when reset() compiled it), then this frame's glOrtho / glLoadMatrixf, the non-static entities and the agent's triangle -
+    drawn with whatever normal the last box face left current (entity.py:494-514)."""
+    env = construct(cls, kwargs, dr)
+    env.seed(seed)
+    deps.GL_LOG.clear()
+    deps.GL_LOG_ENABLED[0] = True
+    env.reset()
+    deps.GL_LOG_ENABLED[0] = False
+    reset_polys, lights, misc = parse_gl_log(list(deps.GL_LOG))
+    deps.GL_LOG.clear()
+    if pose is not None:
+        env.agent.pos = np.array([pose[0], 0.0, pose[1]])
+        env.agent.dir = pose[2]
+    deps.GL_LOG_ENABLED[0] = True
+    env.render_top_view()
+    deps.GL_LOG_ENABLED[0] = False
+    top_polys, _, top_misc = parse_gl_log(list(deps.GL_LOG))
+    deps.GL_LOG.clear()
+    ents = snapshot_entities(env)
+    boxes = [e for e in env.entities if e is not env.agent]
+    return {
+        "task": cls.__name__, "kwargs": kwargs, "seed": seed, "domain_rand": int(dr),
+        "lights": lights, "misc": {**misc, **top_misc},
+        "polys": [p for p in reset_polys if p["tex_on"]] + top_polys,   # rooms (textured), then this frame's entities + agent
+        "room_tex": [[tex_basename(r.wall_tex), tex_basename(r.floor_tex), tex_basename(r.ceil_tex)] for r in env.rooms],
+        "extents": [float(env.min_x), float(env.max_x), float(env.min_z), float(env.max_z)],
+        "agent_pos": ents["agent_pos"].tolist(), "agent_dir": float(ents["agent_dir"]),
+        "boxes_pos": [np.array(b.pos, dtype=float).tolist() for b in boxes], "boxes_dir": [float(b.dir) for b in boxes],
+    }
+
+
 def math_kat():
     """Known-answer vectors for the two importable numpy-only reference modules (math.py)."""
     rng = np.random.default_rng(7)
@@ -528,6 +563,11 @@ def math_kat():
     axes = np.array([ref_math.Y_VEC, ref_math.Z_VEC, ref_math.X_VEC])
     rots = np.stack([[ref_math.gen_rot_matrix(ax, a) for ax in axes] for a in ang])
     return {"segs": segs, "pts": pts, "rad": rad, "hit": hit, "ang": ang, "rots": rots}
+
+
+# render_top_view() streams: polygon rooms with the culled connectors, rectangles with portals + domain randomisation,
+# six boxes; the agent moved off its spawn pose in two of them
+TOP_VIEWS = [("YMaze", 0, None), ("FourRooms", 1, (2.5, -3.0, 0.7)), ("PutNext", 1, (6.0, 6.0, -2.0))]
 
 
 def main():
@@ -586,6 +626,12 @@ def main():
             g = capture_gl_carry(cls, kwargs, 1, dr)
             with open(os.path.join(HERE, "glstream_%s_dr%d.json" % (task, dr)), "w") as fh:
                 json.dump(g, fh, separators=(",", ":"))
+    for task, dr, pose in TOP_VIEWS:
+        if only and not any(task.startswith(o) for o in only):
+            continue
+        cls, kwargs = {**TASKS, **CARRY_TASKS}[task]
+        with open(os.path.join(HERE, "gltop_%s_dr%d.json" % (task, dr)), "w") as fh:
+            json.dump(capture_gl_top(cls, kwargs, 1, dr, pose), fh, separators=(",", ":"))
     if only:
         return
     np.savez_compressed(os.path.join(HERE, "math_kat.npz"), **math_kat())

@@ -117,7 +117,9 @@ def main():
             out, task=task, hud_pos=np.array([hx, hz]), hud_angle=hang, fit_pose=np.array(pose), fit_cost=cost,
             main160=np.rint(main160).astype(np.uint8), main80=np.rint(main80).astype(np.uint8), inset_only=name in INSET_ONLY,
             inset80=np.rint(inset).astype(np.uint8), mask160=non_box_mask(main160, 3), mask80=non_box_mask(main80, 2),
-            mask_inset=non_box_mask(inset, 2), box_faces=faces)
+            mask_inset=non_box_mask(inset, 2), box_faces=faces,
+            # ymaze_0.jpg's main area is a TOP VIEW (manual_control.py --top_view): kept box-filtered to 400 x 300
+            **({"top400": np.rint(box_down(main_view, 2)).astype(np.uint8)} if name in INSET_ONLY else {}))
         print("%-8s pose %.4f %.4f %.3f deg  cost %.2f  box faces %s -> %s" %
               (name, pose[0], pose[1], math.degrees(pose[2]), cost, np.round(faces).tolist(), os.path.basename(out)))
     # depth_map.jpg: grey level of the human view = displayed depth.  Kept: the 160x120 box-filtered luminance.

@@ -49,7 +49,7 @@ def polygons_from_stream(g):
                 tex = g["room_tex"][room_i][1 if p["norms"][0][1] > 0 else 2]
         else:
             tex = None
-        n_per = {"GL_QUADS": 4, "GL_POLYGON": len(verts)}[p["mode"]]
+        n_per = {"GL_QUADS": 4, "GL_POLYGON": len(verts), "GL_TRIANGLES": 3}[p["mode"]]
         for k in range(0, len(verts), n_per):
             out.append({"verts": verts[k:k + n_per], "texcs": texcs[k:k + n_per] if tex else None,
                         "normal": norms[k], "color": np.array(p["color"], float), "tex": tex})
@@ -82,17 +82,25 @@ def _trilinear(levels, s, t, rho2):
     return out
 
 
-def render_stream(g, textures, W=80, H=60):
-    """textures: name -> list of mip levels (H,W,4) uint8 with row 0 = bottom.  Returns (H,W,3) uint8."""
+def render_stream(g, textures, W=80, H=60, ortho=False):
+    """textures: name -> list of mip levels (H,W,4) uint8 with row 0 = bottom.  Returns (H,W,3) uint8.
+    ortho: the frame of render_top_view (glOrtho + the fixed modelview of miniworld.py:1133-1151) instead of the camera's."""
     polys = polygons_from_stream(g)
-    fovy, aspect, _, _ = g["misc"]["gluPerspective"]
-    la = g["misc"]["gluLookAt"]
-    eye, center, up = np.array(la[0:3]), np.array(la[3:6]), np.array(la[6:9])
-    f = _norm(center - eye)
-    s_ = _norm(np.cross(f, up))
-    u_ = np.cross(s_, f)
-    th = np.tan(np.radians(fovy) / 2)
-    tw = th * aspect
+    if ortho:
+        o_l, o_r, o_b, o_t, _, o_far = g["misc"]["glOrtho"]
+        m = np.array(g["misc"]["glLoadMatrixf"]).reshape(4, 4).T   # column-major upload: eye = m @ world
+        assert np.array_equal(m[:3, :3], [[1, 0, 0], [0, 0, -1], [0, 1, 0]]) and not m[:3, 3].any()
+        minv = m[:3, :3].T
+        fdir = minv @ np.array([0.0, 0.0, -1.0])   # straight down
+    else:
+        fovy, aspect, _, _ = g["misc"]["gluPerspective"]
+        la = g["misc"]["gluLookAt"]
+        eye, center, up = np.array(la[0:3]), np.array(la[3:6]), np.array(la[6:9])
+        f = _norm(center - eye)
+        s_ = _norm(np.cross(f, up))
+        u_ = np.cross(s_, f)
+        th = np.tan(np.radians(fovy) / 2)
+        tw = th * aspect
     sky = np.array(g["misc"]["glClearColor"][:3])
     Lp = np.array(g["lights"]["GL_POSITION"])
     assert Lp[3] == 0.0  # directional (miniworld.py:1026)
@@ -100,8 +108,16 @@ def render_stream(g, textures, W=80, H=60):
     amb, dif = np.array(g["lights"]["GL_AMBIENT"][:3]), np.array(g["lights"]["GL_DIFFUSE"][:3])
 
     def rays(wx, wy):
+        if ortho:
+            return np.broadcast_to(fdir, (len(wx), 3))
         nx, ny = 2 * wx / W - 1, 2 * wy / H - 1
         return f[None] + s_[None] * (nx * tw)[:, None] + u_[None] * (ny * th)[:, None]
+
+    def origins(wx, wy):
+        if not ortho:
+            return np.broadcast_to(eye, (len(wx), 3))
+        e = np.stack([o_l + wx / W * (o_r - o_l), o_b + wy / H * (o_t - o_b), np.full(len(wx), o_far)], axis=1)
+        return e @ minv.T
 
     py, px = np.mgrid[0:H, 0:W]
     cx, cy = (px + 0.5).ravel(), (H - 1 - py + 0.5).ravel()
@@ -115,11 +131,12 @@ def render_stream(g, textures, W=80, H=60):
         planes.append(ng)
         for k in range(8):
             d = rays(cx + SAMPLE_X[k], cy + SAMPLE_Y[k])
+            o = origins(cx + SAMPLE_X[k], cy + SAMPLE_Y[k])
             den = d @ ng
             with np.errstate(divide="ignore", invalid="ignore"):
-                t = ((v[0] - eye) @ ng) / den
+                t = ((v[0][None] - o) @ ng) / den
             ok = (den < 0) & (t > 0) & (t < best_t[k])
-            P = eye[None] + t[:, None] * d
+            P = o + t[:, None] * d
             for e in range(len(v)):
                 a, b = v[e], v[(e + 1) % len(v)]
                 ok &= (np.cross(b - a, P - a) @ ng) >= -1e-9
@@ -127,6 +144,7 @@ def render_stream(g, textures, W=80, H=60):
             best_p[k] = np.where(ok, pi, best_p[k])
     acc = np.zeros((npx, 3))
     dc, dx, dy = rays(cx, cy), rays(cx + 1, cy), rays(cx, cy + 1)
+    oc, ox, oy = origins(cx, cy), origins(cx + 1, cy), origins(cx, cy + 1)
     acc += (best_p == -1).sum(axis=0)[:, None] * sky[None]
     for pi in np.unique(best_p[best_p >= 0]):
         p = polys[pi]
@@ -142,18 +160,18 @@ def render_stream(g, textures, W=80, H=60):
             e1, e2 = v[1] - v[0], v[-1] - v[0]
             M = np.array([[e1 @ e1, e1 @ e2], [e1 @ e2, e2 @ e2]])
 
-            def texc(d):
+            def texc(d, o):
                 with np.errstate(divide="ignore", invalid="ignore"):
-                    t = ((v[0] - eye) @ ng) / (d @ ng)
-                P = eye[None] + t[:, None] * d - v[0][None]
+                    t = ((v[0][None] - o) @ ng) / (d @ ng)
+                P = o + t[:, None] * d - v[0][None]
                 ab = np.linalg.solve(M, np.stack([P @ e1, P @ e2]))
                 st = tc[0][None] + ab[0][:, None] * (tc[1] - tc[0])[None] + ab[1][:, None] * (tc[-1] - tc[0])[None]
                 return st, t > 0
             levels = textures[p["tex"]]
             h0, w0 = levels[0].shape[:2]
-            st0, ok0 = texc(dc[idx])
-            stx, okx = texc(dx[idx])
-            sty, oky = texc(dy[idx])
+            st0, ok0 = texc(dc[idx], oc[idx])
+            stx, okx = texc(dx[idx], ox[idx])
+            sty, oky = texc(dy[idx], oy[idx])
             r1 = ((stx[:, 0] - st0[:, 0]) * w0) ** 2 + ((stx[:, 1] - st0[:, 1]) * h0) ** 2
             r2 = ((sty[:, 0] - st0[:, 0]) * w0) ** 2 + ((sty[:, 1] - st0[:, 1]) * h0) ** 2
             rho2 = np.where(ok0 & okx & oky, np.maximum(r1, r2), np.inf)

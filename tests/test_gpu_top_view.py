@@ -1,0 +1,86 @@
+"""render_top_view (miniworld.py:1087-1158), GPU legs: mwb_render_top_view through the C ABI against the CPU
+oracle (itself equal to the brute-force rendition of the reference's own top-view GL stream and pinned to the reference's
+ymaze_0.jpg screenshot, tests/test_oracle_top_view.py) - within +-1/255 at every pixel - and against that screenshot."""
+import os
+
+import numpy as np
+import pytest
+
+import test_oracle_top_view as TV
+from test_gpu_parity import obs_diff
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("MiniWorld-Hallway-v0", "Hallway", None), ("MiniWorld-FourRooms-v0", "FourRooms", None), ("MiniWorld-Maze-v0", "Maze", None),
+         ("MiniWorld-TMazeTwoBoxDynamic-v0", "TMazeTwoBox", [0, 0, 0, 100]), ("MiniWorld-SimToRealPush-v0", "SimToRealPush", None),
+         ("MiniWorld-PutNext-v0", "PutNext", None), ("MiniWorld-YMaze-v0", "YMaze", [0, 0, 0, 0])]
+
+
+@pytest.mark.parametrize("env_id,task,args", CASES)
+@pytest.mark.parametrize("dr", [0, 1])
+def test_top_view_matches_oracle(oracle_mod, env_id, task, args, dr):
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld, ENV_SPECS
+    O = oracle_mod
+    n = 6
+    spec = ENV_SPECS[env_id]
+    params = spec[3]().to_table() if spec[3] else None
+    if task.startswith("SimToReal"):
+        dr = 1
+    b = BatchedMiniWorld(env_id, num_envs=n, seed=70, domain_rand=dr)
+    envs = [O.OracleEnv(task, seed=70 + i, domain_rand=dr, task_args=args, params=params) for i in range(n)]
+    b.reset()
+    for e in envs:
+        e.reset(render=False)
+    n_act = b.n_actions
+    rng = np.random.default_rng(2)
+    for rnd, (W, H) in enumerate(((80, 60), (200, 150), (97, 41))):
+        for t in range(15 * rnd):   # walk (and, in PutNext, pick boxes up) between the looks
+            a = rng.integers(0, n_act, n).astype(np.int32)
+            b.step(torch.from_numpy(a))
+            for i, e in enumerate(envs):
+                _, _, d, _ = e.step(int(a[i]))
+                if d:
+                    e.reset(render=False)
+        top = b.render_top_view(W, H).cpu().numpy()
+        assert top.shape == (n, H, W, 3)
+        for i, e in enumerate(envs):
+            ref = e.render_top(W, H)
+            d = obs_diff(top[i], ref)
+            assert d.max() <= 1, (env_id, dr, (W, H), i, int(d.max()), int((d > 1).sum()))
+        assert len(np.unique(top[0].reshape(-1, 3), axis=0)) > 3   # sky, floor texels, box, agent
+    b.close()
+
+
+def test_top_view_after_set_state_and_single_env_view(oracle_mod):
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    from gym_miniworld_amd.env import MiniWorldEnv
+    O = oracle_mod
+    b = BatchedMiniWorld("MiniWorld-OneRoom-v0", num_envs=2, seed=5)
+    b.reset()
+    b.set_state(0, agent_pos=[[2.0, 0.0, 3.0]] * 2, agent_dir=[1.0, -2.0], boxes_pos=[[[7.0, 0.0, 7.0]]] * 2, boxes_dir=[[0.5]] * 2)
+    top = b.render_top_view().cpu().numpy()   # no render() in between: the call prepares the frame constants itself
+    for i, dirv in enumerate((1.0, -2.0)):
+        e = O.OracleEnv("OneRoom", seed=5 + i)
+        e.reset(render=False)
+        e.set_agent(2.0, 3.0, dirv)
+        e.set_box(0, 7.0, 7.0, 0.5)
+        assert obs_diff(top[i], e.render_top()).max() <= 1
+    b.close()
+    env = MiniWorldEnv("MiniWorld-Hallway-v0", seed=3)
+    env.reset()
+    img = env.render(mode="rgb_array", view="top")
+    assert img.shape == (600, 800, 3) and env.render_top_view().shape == (60, 80, 3)
+    env.close()
+
+
+def test_hip_top_view_matches_the_reference_screenshot():
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    fx = np.load(os.path.join(TV.GOLD, "refimg_ymaze.npz"))
+    x, z, d = fx["fit_pose"]
+    b = BatchedMiniWorld("MiniWorld-YMaze-v0", num_envs=1, seed=1)
+    b.reset()
+    b.set_state(0, agent_pos=[[x, 0.0, z]], agent_dir=[d], boxes_pos=[[[-8.0, 0.0, 0.0]]], boxes_dir=[[0.0]])
+    img = b.render_top_view(400, 300).cpu().numpy()[0]
+    b.close()
+    TV.check_top_view_pin(TV.top_view_pin_stats(img, fx["top400"]))
