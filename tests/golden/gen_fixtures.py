@@ -8,7 +8,7 @@ and the exact *inputs* it hands to OpenGL (vertex / texcoord / normal / colour /
 streams).  They do NOT contain reference pixels - none can be produced here.
 
 Run:  python tests/golden/gen_fixtures.py          (only in the container that has /root/reference)
-Outputs: state_<task>.npz, glstream_<task>.json, math_kat.npz  (data only, no reference text).
+Outputs: state_<task>.npz, glstream_<task>.json, gltop_<task>.json (render_top_view streams), math_kat.npz  (data only, no reference text).
 """
 import json
 import math

@@ -18,7 +18,7 @@ def test_state_and_glstream_fixtures_round_trip(tmp_path):
     out = str(tmp_path)
     subprocess.check_call([sys.executable, os.path.join(GOLDEN, "gen_fixtures.py"), "--out", out], stdout=subprocess.DEVNULL)
     names = sorted(f for f in os.listdir(out) if f.endswith((".npz", ".json")))
-    committed = sorted(f for f in os.listdir(GOLDEN) if f.startswith(("state_", "glstream_", "math_kat", "seed_keys")))
+    committed = sorted(f for f in os.listdir(GOLDEN) if f.startswith(("state_", "glstream_", "gltop_", "math_kat", "seed_keys")))
     assert names == committed
     n_arrays = 0
     for f in names:
