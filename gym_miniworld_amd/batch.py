@@ -229,6 +229,13 @@ class BatchedMiniWorld:
         _lib.check(self.L.mwb_render(self.h, self._stream()))
         return self.obs
 
+    def visible_ents(self):
+        """MiniWorldEnv.get_visible_ents() for every env (miniworld.py:1222-1315): int32 [N] on the device, bit b = box b
+        (entity-list order) passes its occlusion query"""
+        out = self.torch.empty((self.num_envs,), dtype=self.torch.int32, device=self.device)
+        _lib.check(self.L.mwb_visible_ents(self.h, out.data_ptr(), self._stream()))
+        return out
+
     def render_top_view(self, width=None, height=None):
         """MiniWorldEnv.render_top_view(frame_buffer) for every env (miniworld.py:1087-1158): uint8 [N, height, width, 3] on
         the device, default the observation size (the reference's default frame buffer is obs_fb)."""

@@ -565,6 +565,17 @@ extern "C" int mwb_render_top_view(mwb_handle *h, uint8_t *out_dev, int width, i
     return check_launch("top_view_kernel");
 }
 
+extern "C" int mwb_visible_ents(mwb_handle *h, uint32_t *mask_dev, void *stream) {
+    if (!h || !mask_dev) return set_err(MWB_EINVAL, "mwb_visible_ents: null argument");
+    USE_DEVICE(h->cfg.device);
+    int rc = ensure_ready(h); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    mwb_launch_prep(h->dev, 0, s);   // the state may have been set from outside since the last render
+    rc = check_launch("prep_kernel"); if (rc) return rc;
+    mwb_launch_visible(h->dev, mask_dev, s);
+    return check_launch("visible_kernel");
+}
+
 extern "C" int mwb_get_outputs(mwb_handle *h, mwb_outputs *out) {
     if (!h || !out) return set_err(MWB_EINVAL, "mwb_get_outputs: null argument");
     const MwbDev &d = h->dev;

@@ -2555,6 +2555,97 @@ void mwb_launch_top_view(const MwbDev &d, uint8_t *out, int W, int H, hipStream_
     else top_view_kernel<false><<<dim3(d.N), dim3(256), 0, s>>>(d, out, W, H);
 }
 
+// =========================================================================== get_visible_ents
+// MiniWorldEnv.get_visible_ents (miniworld.py:1222-1315) for the whole batch: rooms into the observation frame (8 samples, the
+// camera of render_obs), then per entity but the agent, in list order, an axis-aligned 0.2 m cube at its position inside a
+// GL_ANY_SAMPLES_PASSED query; GL_LESS with depth writes on, so a cube is visible iff at some sample its front face is nearer
+// than the room surface and than every cube drawn before it (ray parameters of the same ray compared; depth-buffer
+// quantisation and the near plane are not modelled).  One workgroup per env, pixels strided over the threads; a sample that
+// meets no cube - nearly all of them - costs the slab tests only.  Not on the training path; the reference never calls it.
+template <bool POLY>
+__global__ void __launch_bounds__(256) visible_kernel(MwbDev d, uint32_t *__restrict__ mask_out) {
+    __shared__ int cam_room_s;
+    __shared__ uint32_t mask_s;
+    const int e = blockIdx.x, tid = threadIdx.x, W = d.W, H = d.H;
+    int n_rooms = d.n_rooms[e];
+    if (n_rooms < 0) n_rooms = 0;
+    const float *rooms = d.rooms + (size_t)e * d.R_max * d.room_words;
+    const float *fc = d.frame + (size_t)e * d.frame_words;
+    if (tid == 0) { cam_room_s = 0x7fffffff; mask_s = 0; }
+    __syncthreads();
+    Cam cam;
+    for (int k = 0; k < 3; k++) { cam.eye[k] = fc[FC_EYE + k]; cam.F[k] = fc[FC_F + k]; cam.S[k] = fc[FC_S + k]; cam.U[k] = fc[FC_U + k]; }
+    cam.TW = fc[FC_TW]; cam.TH = fc[FC_TH];
+    cam.Wf = (float)W; cam.Hf = (float)H; cam.invW = 1.0f / (float)W; cam.invH = 1.0f / (float)H;
+    for (int i = tid; i < n_rooms; i += 256) {
+        bool in;
+        if (POLY) {
+            const float *r = rooms + i * MWB_POLY_ROOM_WORDS;
+            in = !((__float_as_int(r[PW_FLAGS]) >> 8) & 1);
+            for (int k = 0; k < 4; k++) {
+                const float *ed = r + PW_EDGE0 + PW_EDGE_WORDS * k;
+                if (!(fmaf(ed[5], cam.eye[2] - ed[1], ed[4] * (cam.eye[0] - ed[0])) >= 0.0f)) in = false;
+            }
+        } else {
+            const float *r = rooms + i * MWB_ROOM_WORDS;
+            in = cam.eye[0] >= r[RW_MINX] && cam.eye[0] <= r[RW_MAXX] && cam.eye[2] >= r[RW_MINZ] && cam.eye[2] <= r[RW_MAXZ];
+        }
+        if (in) atomicMin(&cam_room_s, i);
+    }
+    __syncthreads();
+    const int cam_room = cam_room_s == 0x7fffffff ? -1 : cam_room_s;
+    float lo[MWB_MAX_BOXES][3], hi[MWB_MAX_BOXES][3];
+    for (int b = 0; b < d.n_boxes; b++) {   // glVertex3f arguments: float32 of the float64 sums
+        const size_t be = (size_t)b * d.N + e;
+        const double px = d.box_x[be], py = d.box_y[be], pz = d.box_z[be];
+        lo[b][0] = (float)(px - 0.1); hi[b][0] = (float)(px + 0.1);
+        lo[b][1] = (float)py;         hi[b][1] = (float)(py + 0.2);
+        lo[b][2] = (float)(pz - 0.1); hi[b][2] = (float)(pz + 0.1);
+    }
+    uint32_t mask = 0;
+    for (int p = tid; p < W * H; p += 256) {
+        const int py = p / W, px = p - py * W;
+        const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) {
+            float dv[3], tb[MWB_MAX_BOXES];
+            make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
+            bool any = false;
+            for (int b = 0; b < d.n_boxes; b++) {
+                float tn = -INFINITY, tf = INFINITY;
+                bool miss = false;
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    if (dv[a] == 0) { miss = miss || cam.eye[a] < lo[b][a] || cam.eye[a] > hi[b][a]; continue; }
+                    const float inv = 1.0f / dv[a];
+                    const float t1 = (lo[b][a] - cam.eye[a]) * inv, t2 = (hi[b][a] - cam.eye[a]) * inv;
+                    const float tmin = t1 < t2 ? t1 : t2, tmax = t1 < t2 ? t2 : t1;
+                    if (tmin > tn) tn = tmin;
+                    if (tmax < tf) tf = tmax;
+                }
+                const bool hit = !miss && tn <= tf && tn > 0;   // eye inside the cube: only back faces, culled
+                tb[b] = hit ? tn : INFINITY;
+                any = any || hit;
+            }
+            if (!any) continue;
+            float th;
+            uint32_t path;
+            const uint32_t key = POLY ? trace_rooms_poly<false>(rooms, n_rooms, cam_room, cam.eye, dv, th, path)
+                                      : trace_rooms<false>(rooms, n_rooms, cam_room, cam.eye, dv, th, path);
+            float depth = (key & 7u) != KIND_SKY ? th : INFINITY;   // the depth buffer at this sample so far
+            for (int b = 0; b < d.n_boxes; b++)
+                if (tb[b] < depth) { mask |= 1u << b; depth = tb[b]; }
+        }
+    }
+    if (mask) atomicOr(&mask_s, mask);
+    __syncthreads();
+    if (tid == 0) mask_out[e] = mask_s;
+}
+void mwb_launch_visible(const MwbDev &d, uint32_t *mask_out, hipStream_t s) {
+    if (d.poly) visible_kernel<true><<<dim3(d.N), dim3(256), 0, s>>>(d, mask_out);
+    else visible_kernel<false><<<dim3(d.N), dim3(256), 0, s>>>(d, mask_out);
+}
+
 void mwb_launch_intersect(const MwbDev &d, int env, int ent, double x, double z, double radius, int *result_dev, hipStream_t s) {
     hipLaunchKernelGGL(intersect_kernel, dim3(1), dim3(64), 0, s, d, env, ent, x, z, radius, result_dev);
 }

@@ -153,6 +153,11 @@ class MiniWorldEnv:
         self._b.render()
         return self._b.depth.cpu().numpy()[0]
 
+    def get_visible_ents(self):
+        """miniworld.py:1222-1315: the set of entities (never the agent) whose query cube is visible"""
+        mask = int(self._b.visible_ents().cpu().numpy()[0])
+        return {ent for i, ent in enumerate(self.entities[:-1]) if (mask >> i) & 1}
+
     def render_top_view(self, width=None, height=None):
         """miniworld.py:1087-1158 (frame size: the reference passes a frame buffer; default the observation's)"""
         return self._b.render_top_view(width, height).cpu().numpy()[0]

@@ -234,6 +234,12 @@ int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_rooms, double
  * debugging view, not part of the step pipeline. */
 int mwb_render_top_view(mwb_handle *h, uint8_t *out_dev, int width, int height, void *stream);
 
+/* replaces: MiniWorldEnv.get_visible_ents() (miniworld.py:1222-1315) for the whole batch: per env a bit mask over the boxes in
+ * entity-list order, bit b set iff box b's 0.2 m query cube passes its occlusion query (any of the 8 x W x H samples of the
+ * observation frame nearer than the rooms and than the cubes of the boxes before it).  mask_dev: uint32 [N] in device memory;
+ * enqueued on `stream`.  The reference never calls the function and holds no output of it (parity unpinned). */
+int mwb_visible_ents(mwb_handle *h, uint32_t *mask_dev, void *stream);
+
 /* ---- timing hooks used by bench.py -------------------------------------------------------- */
 /* average device time (ms) of each kernel of the step pipeline since the last call (HIP events
  * recorded on the stream the kernels were launched on); names: "step","reset","prep","render".

@@ -1512,7 +1512,7 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
                 if (h->kind == 0) { col[0] = L.sky[0]; col[1] = L.sky[1]; col[2] = L.sky[2]; }
                 else if (h->kind == 4) { const float *lb = lit_boxes[h->room][h->side]; col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2]; }
                 else {
-                    float s0, t0, s1, t1, s2, t2;
+                    float s0 = 0, t0 = 0, s1 = 0, t1 = 0, s2 = 0, t2 = 0;
                     int tex;
                     const float *lit;
                     float lit_edge[3];
@@ -1565,6 +1565,85 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
         }
     free(rr);
     free(pr);
+}
+
+/* ---- get_visible_ents (miniworld.py:1222-1315): the rooms are drawn into the observation frame buffer (8 samples, the
+ * camera of render_obs), then for every entity but the agent, in list order, an axis-aligned 0.2 m cube at its position
+ * (x, z +- 0.1, y .. y + 0.2; drawBox: no rotation) inside a GL_ANY_SAMPLES_PASSED query.  Depth test GL_LESS with depth
+ * writes on: a cube is visible iff at some sample its front face is nearer than the room surface and than every cube drawn
+ * before it.  Depths are compared as ray parameters of the same ray (monotonic in the depth-buffer value; the 24-bit
+ * quantisation and the near plane are not modelled).  The reference never calls this function and no output of it exists
+ * anywhere: PARITY UNPINNED - this restatement is the spec the HIP kernel is tested against. */
+static int cube_entry(const float *lo, const float *hi, const float *o, const float *d, float *t_out) {
+    float tn = -INFINITY, tf = INFINITY;
+    for (int a = 0; a < 3; a++) {
+        if (d[a] == 0) { if (o[a] < lo[a] || o[a] > hi[a]) return 0; continue; }
+        float inv = 1.0f / d[a];
+        float t1 = (lo[a] - o[a]) * inv, t2 = (hi[a] - o[a]) * inv;
+        float tmin = t1 < t2 ? t1 : t2, tmax = t1 < t2 ? t2 : t1;
+        if (tmin > tn) tn = tmin;
+        if (tmax < tf) tf = tmax;
+    }
+    if (!(tn <= tf) || !(tn > 0)) return 0;   /* eye inside the cube: only back faces, culled */
+    *t_out = tn;
+    return 1;
+}
+
+uint32_t mwo_visible_ents(MwoEnv *e, int W, int H) {
+    const int poly = e->task == MWO_YMAZE;
+    RRoom *rr = (RRoom *)malloc(sizeof(RRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));
+    PRoom *pr = (PRoom *)malloc(sizeof(PRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));
+    int n_rooms = poly ? build_prooms(e, pr) : build_rrooms(e, rr);
+    double cp[3], cd[3];
+    camera(e, cp, cd);
+    double fl = sqrt(cd[0] * cd[0] + cd[1] * cd[1] + cd[2] * cd[2]);
+    double f[3] = {cd[0] / fl, cd[1] / fl, cd[2] / fl};
+    double sl = sqrt(f[2] * f[2] + f[0] * f[0]);
+    double s[3] = {-f[2] / sl, 0, f[0] / sl};
+    double u[3] = {s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0]};
+    double th = tan(e->cam_fov_y * M_PI / 180 / 2);
+    Cam c;
+    for (int k = 0; k < 3; k++) { c.eye[k] = (float)cp[k]; c.F[k] = (float)f[k]; c.S[k] = (float)s[k]; c.U[k] = (float)u[k]; }
+    c.TH = (float)th; c.TW = (float)(th * ((double)W / (double)H));
+    c.W = W; c.H = H; c.invW = 1.0f / (float)W; c.invH = 1.0f / (float)H;
+    int cam_room = -1;
+    for (int i = 0; i < n_rooms && cam_room < 0; i++) {
+        if (!poly) { if (c.eye[0] >= rr[i].min_x && c.eye[0] <= rr[i].max_x && c.eye[2] >= rr[i].min_z && c.eye[2] <= rr[i].max_z) cam_room = i; }
+        else {
+            int in = !pr[i].culled;
+            for (int k = 0; k < pr[i].ne; k++) {
+                const PEdge *pe = &pr[i].e[k];
+                if (!(fmaf(pe->nz, c.eye[2] - pe->pz, pe->nx * (c.eye[0] - pe->px)) >= 0.0f)) in = 0;
+            }
+            if (in) cam_room = i;
+        }
+    }
+    float lo[MWO_MAX_BOXES][3], hi[MWO_MAX_BOXES][3];
+    for (int b = 0; b < e->n_boxes; b++) {   /* glVertex3f arguments: float32 of the float64 sums */
+        const double *p = e->boxes[b].pos;
+        lo[b][0] = (float)(p[0] - 0.1); hi[b][0] = (float)(p[0] + 0.1);
+        lo[b][1] = (float)p[1];         hi[b][1] = (float)(p[1] + 0.2);
+        lo[b][2] = (float)(p[2] - 0.1); hi[b][2] = (float)(p[2] + 0.1);
+    }
+    uint32_t mask = 0;
+    for (int py = 0; py < H; py++)
+        for (int px = 0; px < W; px++) {
+            const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
+            for (int k = 0; k < 8; k++) {
+                float d[3], tb[MWO_MAX_BOXES];
+                int any = 0;
+                make_ray(&c, cx + SAMPLE_X[k] * 0.0625f, cy + SAMPLE_Y[k] * 0.0625f, d);
+                for (int b = 0; b < e->n_boxes; b++) { tb[b] = INFINITY; if (cube_entry(lo[b], hi[b], c.eye, d, &tb[b])) any = 1; else tb[b] = INFINITY; }
+                if (!any) continue;
+                Hit h = poly ? trace_rooms_poly(pr, n_rooms, cam_room, c.eye, d) : trace_rooms(rr, n_rooms, cam_room, c.eye, d);
+                float depth = h.kind != 0 ? h.t : INFINITY;   /* the depth buffer at this sample so far */
+                for (int b = 0; b < e->n_boxes; b++)
+                    if (tb[b] < depth) { mask |= 1u << b; depth = tb[b]; }
+            }
+        }
+    free(rr);
+    free(pr);
+    return mask;
 }
 
 /* ---- render_top_view (miniworld.py:1087-1158): glOrtho over the floorplan's extents + 1 m (widened to the frame's aspect),

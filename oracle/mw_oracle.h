@@ -104,6 +104,8 @@ int mwo_intersect(MwoEnv *e, int ent /*0=box,1=agent,2=box2*/, double x, double 
 void mwo_render(MwoEnv *e, int width, int height, uint8_t *rgb, float *depth);
 /* render_top_view(frame_buffer) (miniworld.py:1087-1158): the map from above, agent drawn, at any frame size */
 void mwo_render_top(MwoEnv *e, int width, int height, uint8_t *rgb);
+/* get_visible_ents() (miniworld.py:1222-1315): bit b = box b passes its occlusion query at the observation size */
+uint32_t mwo_visible_ents(MwoEnv *e, int width, int height);
 
 /* stand-alone pieces with reference known-answer vectors */
 int mwo_intersect_circle_segs(const double *pt3, double radius, const double *segs /*n*2*3*/, int n);

@@ -87,6 +87,8 @@ def lib():
         L.mwo_intersect.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         L.mwo_render.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp]
         L.mwo_render_top.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
+        L.mwo_visible_ents.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+        L.mwo_visible_ents.restype = ctypes.c_uint32
         L.mwo_set_texture.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
         L.mwo_intersect_circle_segs.argtypes = [dp, ctypes.c_double, dp, ctypes.c_int]
         L.mwo_gen_rot_matrix.argtypes = [dp, ctypes.c_double, dp]
@@ -248,6 +250,10 @@ class OracleEnv:
         self.L.mwo_render(self.h, self.W, self.H, rgb.ctypes.data_as(ctypes.c_void_p),
                           dep.ctypes.data_as(ctypes.c_void_p) if depth else None)
         return (rgb, dep) if depth else rgb
+
+    def visible_ents(self):
+        """get_visible_ents() (miniworld.py:1222-1315) as a bit mask over the boxes in entity-list order"""
+        return int(self.L.mwo_visible_ents(self.h, self.W, self.H))
 
     def render_top(self, width=None, height=None):
         """render_top_view(frame_buffer) (miniworld.py:1087-1158) at width x height (default: the observation size)"""

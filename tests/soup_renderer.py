@@ -82,6 +82,49 @@ def _trilinear(levels, s, t, rho2):
     return out
 
 
+def visible_cubes(g, positions, W=80, H=60):
+    """get_visible_ents (miniworld.py:1222-1315) on the polygon soup: the stream's ROOM polygons, then per entity position an
+    axis-aligned 0.2 m cube (drawBox's six quads, same winding), depth test GL_LESS in drawing order, back faces culled.
+    Returns the set of entity indices with at least one of the 8 x W x H samples passing."""
+    rooms = [p for p in polygons_from_stream(g) if p["tex"] is not None]
+    fovy, aspect, _, _ = g["misc"]["gluPerspective"]
+    la = g["misc"]["gluLookAt"]
+    eye, center, up = np.array(la[0:3]), np.array(la[3:6]), np.array(la[6:9])
+    f = _norm(center - eye)
+    s_ = _norm(np.cross(f, up))
+    u_ = np.cross(s_, f)
+    th = np.tan(np.radians(fovy) / 2)
+    tw = th * aspect
+    quads = [(p["verts"], -1) for p in rooms]
+    for bi, pos in enumerate(positions):
+        x0, x1, y0, y1, z0, z1 = pos[0] - 0.1, pos[0] + 0.1, pos[1], pos[1] + 0.2, pos[2] - 0.1, pos[2] + 0.1
+        for v in ([(x1, y1, z1), (x0, y1, z1), (x0, y0, z1), (x1, y0, z1)], [(x0, y1, z0), (x1, y1, z0), (x1, y0, z0), (x0, y0, z0)],
+                  [(x0, y1, z1), (x0, y1, z0), (x0, y0, z0), (x0, y0, z1)], [(x1, y1, z0), (x1, y1, z1), (x1, y0, z1), (x1, y0, z0)],
+                  [(x1, y1, z1), (x1, y1, z0), (x0, y1, z0), (x0, y1, z1)], [(x1, y0, z0), (x1, y0, z1), (x0, y0, z1), (x0, y0, z0)]):
+            quads.append((np.array(v, float), bi))   # opengl.py:394-444
+    py, px = np.mgrid[0:H, 0:W]
+    cx, cy = (px + 0.5).ravel(), (H - 1 - py + 0.5).ravel()
+    seen = set()
+    for k in range(8):
+        wx, wy = cx + SAMPLE_X[k], cy + SAMPLE_Y[k]
+        d = f[None] + s_[None] * ((2 * wx / W - 1) * tw)[:, None] + u_[None] * ((2 * wy / H - 1) * th)[:, None]
+        best_t = np.full(len(cx), np.inf)
+        for v, owner in quads:
+            ng = _norm(np.cross(v[1] - v[0], v[2] - v[0]))
+            den = d @ ng
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = ((v[0] - eye) @ ng) / den
+                ok = (den < 0) & (t > 0) & (t < best_t)
+                P = eye[None] + t[:, None] * d
+                for e in range(len(v)):
+                    a, b = v[e], v[(e + 1) % len(v)]
+                    ok &= (np.cross(b - a, P - a) @ ng) >= -1e-9
+            best_t = np.where(ok, t, best_t)
+            if owner >= 0 and ok.any():
+                seen.add(owner)
+    return seen
+
+
 def render_stream(g, textures, W=80, H=60, ortho=False):
     """textures: name -> list of mip levels (H,W,4) uint8 with row 0 = bottom.  Returns (H,W,3) uint8.
     ortho: the frame of render_top_view (glOrtho + the fixed modelview of miniworld.py:1133-1151) instead of the camera's."""

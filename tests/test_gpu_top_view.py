@@ -84,3 +84,56 @@ def test_hip_top_view_matches_the_reference_screenshot():
     img = b.render_top_view(400, 300).cpu().numpy()[0]
     b.close()
     TV.check_top_view_pin(TV.top_view_pin_stats(img, fx["top400"]))
+
+
+@pytest.mark.parametrize("env_id,task,args", CASES)
+def test_visible_ents_matches_oracle(oracle_mod, env_id, task, args):
+    """get_visible_ents (miniworld.py:1222-1315) through mwb_visible_ents against the oracle's restatement (itself equal to the
+    queries evaluated on the reference's room polygons, tests/test_oracle_top_view.py): the masks of 32 envs at reset, after
+    walks, and with the agents turned towards / away from a box"""
+    import math
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld, ENV_SPECS
+    O = oracle_mod
+    n = 32
+    spec = ENV_SPECS[env_id]
+    params = spec[3]().to_table() if spec[3] else None
+    dr = 1 if task.startswith("SimToReal") else 0
+    b = BatchedMiniWorld(env_id, num_envs=n, seed=11, domain_rand=dr)
+    envs = [O.OracleEnv(task, seed=11 + i, domain_rand=dr, task_args=args, params=params) for i in range(n)]
+    b.reset()
+    for e in envs:
+        e.reset(render=False)
+    rng = np.random.default_rng(4)
+    seen = 0
+    for rnd in range(5):
+        got = b.visible_ents().cpu().numpy()
+        want = np.array([e.visible_ents() for e in envs], dtype=np.int64)
+        assert np.array_equal(got.astype(np.int64), want), (env_id, rnd, got.tolist(), want.tolist())
+        seen += int((want != 0).sum())
+        st = b.get_state()
+        if rnd % 2 == 0:   # turn every agent towards its first box (odd rounds: a random walk)
+            pos, bp = st["agent_pos"], st["boxes_pos"][:, 0]
+            ang = np.arctan2(-(bp[:, 2] - pos[:, 2]), bp[:, 0] - pos[:, 0]) + rng.uniform(-0.3, 0.3, n)
+            b.set_state(0, agent_dir=ang)
+            for i, e in enumerate(envs):
+                e.set_agent(pos[i, 0], pos[i, 2], ang[i])
+        else:
+            for t in range(12):
+                a = rng.integers(0, 3, n).astype(np.int32)
+                b.step(torch.from_numpy(a))
+                for i, e in enumerate(envs):
+                    _, _, dn, _ = e.step(int(a[i]))
+                    if dn:
+                        e.reset(render=False)
+    assert seen > 0
+    b.close()
+
+
+def test_get_visible_ents_gym_view():
+    from gym_miniworld_amd.env import MiniWorldEnv
+    env = MiniWorldEnv("MiniWorld-PutNext-v0", seed=3)
+    env.reset()
+    vis = env.get_visible_ents()
+    assert isinstance(vis, set) and env.agent not in vis and all(v in env.boxes for v in vis)
+    env.close()

@@ -120,3 +120,39 @@ def test_top_view_matches_the_reference_screenshot(oracle_mod):
     img = env.render_top(400, 300)
     st = top_view_pin_stats(img, fx["top400"])
     check_top_view_pin(st)
+
+
+# ------------------------------------------------------------------------------------------- get_visible_ents
+VIS_STREAMS = [("PutNext", 0, "PutNext", None), ("PutNext", 1, "PutNext", None), ("TMazeTwoBoxFeatures", 1, "TMazeTwoBox", [1, 0, 0, 100000]),
+               ("FourRooms", 0, "FourRooms", None), ("YMaze", 1, "YMaze", [0, 0, 0, 0]), ("Hallway", 1, "Hallway", None)]
+
+
+@pytest.mark.parametrize("name,dr,task,args", VIS_STREAMS)
+def test_visible_ents_equals_occlusion_queries_on_the_reference_polygons(oracle_mod, name, dr, task, args):
+    """get_visible_ents (miniworld.py:1222-1315; the reference never calls it and holds no output of it: parity unpinned):
+    the oracle's restatement (portal traversal + cube slabs) against the same queries evaluated on the reference's own room
+    polygons (glstream_*.json) by the brute-force soup - from the stream's camera and from a ring of turned poses."""
+    import math
+    import test_oracle_render as TR
+    import soup_renderer as SR
+    O = oracle_mod
+    g = TR.load_stream(name, dr)
+    env = TR.posed_env(O, g, task, args, dr)
+    s = env.state()
+    boxes = [list(s.boxes_pos[b]) for b in range(s.n_boxes)]
+    seen_any = 0
+    for turn in range(8):
+        ang = g["agent_dir"] + turn * math.pi / 4
+        env.set_agent(g["agent_pos"][0], g["agent_pos"][2], ang)
+        st = env.state()
+        g2 = dict(g)
+        g2["misc"] = dict(g["misc"])
+        cp, cdir = np.array(st.cam_pos), np.array(st.cam_dir)
+        g2["misc"]["gluLookAt"] = list(cp) + list(cp + cdir) + [0.0, 1.0, 0.0]
+        want = SR.visible_cubes(g2, boxes)
+        mask = env.visible_ents()
+        got = {b for b in range(s.n_boxes) if (mask >> b) & 1}
+        assert got == want, (name, dr, turn, got, want)
+        seen_any += len(got)
+    if name == "PutNext":
+        assert seen_any > 0
