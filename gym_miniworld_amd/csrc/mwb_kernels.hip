@@ -1597,6 +1597,14 @@ struct RenderCtx {
     int n_rooms, cam_room, W, H, layout;
     float cull_cc[NBOX], cull_oc[NBOX][3], zA, zB;
     bool boxes_in_view;   // workgroup-uniform (scalar): false = no ray of this frame can touch a box
+    // per work item (15 x 15 pixels), which boxes can touch any of its rays at all (frame-level pre-test pass; null = unknown)
+    const uint4 *item_res;
+    int part_h_inv;       // ceil(65536 / rows per item): row -> quarter without a division
+    __device__ __forceinline__ uint32_t item_boxes(int px, int py) const {
+        if (NBOX == 1 || !item_res) return 0xFFFFFFFFu;   // one box: the frame-level gate and the per-ray sphere test are enough
+        const int item = ((px * 4370) >> 16) * 4 + ((py * part_h_inv) >> 16);   // px / 15 (exact below 4755), py / part_h
+        return item_res[item].z;
+    }
 
     // rays through the +1 pixel neighbours (for the LOD differences): the ray is affine in the window
     // coordinates, so they are the centre ray plus a per-frame constant (shading-only, tolerance-bound)
@@ -1787,6 +1795,14 @@ struct RenderCtx {
             const int r = POLY ? walk_rooms_poly(rooms, cam_room, cam.eye, dc, skip) : walk_rooms(rooms, cam_room, cam.eye, dc, skip);
             start_room = r >= 0 ? r : cam_room;
         }
+        // boxes that can touch this pixel's item at all, and their union over the batch (scalar): most batches see none
+        const uint32_t my_boxes = boxes_in_view ? item_boxes(px, py) : 0u;
+        uint32_t any_boxes = boxes_in_view ? 1u : 0u;
+        if (NBOX > 1) {
+            any_boxes = 0;
+#pragma unroll
+            for (int bi = 0; bi < NBOX; bi++) any_boxes |= __ballot((my_boxes >> bi) & 1u) ? 1u << bi : 0u;
+        }
         // distinct surfaces among the 8 coverage samples, in order of first appearance:
         // up to 4 slots (key, count, first sample); a 5th distinct surface is shaded on the spot
         uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
@@ -1803,7 +1819,7 @@ struct RenderCtx {
             // conservative bounding-sphere cull, then the exact slab test; boxes in entity order, a later
             // box wins only when strictly nearer
             const float dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
-            if (!boxes_in_view) {
+            if (!any_boxes) {
             } else if (NBOX == 1) {   // cull constants pinned to scalar registers
 #pragma unroll
                 for (int bi = 0; bi < NBOX; bi++) {
@@ -1816,11 +1832,12 @@ struct RenderCtx {
                 }
             } else {
 #pragma unroll 1
-                for (int bi = 0; bi < NBOX; bi++) {   // a real loop: one copy of the slab test, constants from LDS
+                for (uint32_t bm = any_boxes; bm; bm &= bm - 1u) {   // a real loop: one copy of the slab test, constants from LDS
+                    const int bi = __builtin_ctz(bm);                 // (entity order kept: a later box wins only when strictly nearer)
                     const float *fb_ = fc + bi * FC_BOX_STRIDE;
                     const float cc = fb_[FC_CULL_CC];
                     const float b = dv[0] * fb_[FC_CULL_OC] + dv[1] * fb_[FC_CULL_OC + 1] + dv[2] * fb_[FC_CULL_OC + 2];
-                    if (cc <= 0.0f || (b > 0.0f && b * b >= dd * cc)) {
+                    if (((my_boxes >> bi) & 1u) && (cc <= 0.0f || (b > 0.0f && b * b >= dd * cc))) {
                         float tb;
                         int face = trace_box(fb_, dv, tb);
                         if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, bi); th = tb; }
@@ -1990,6 +2007,8 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     }
     (void)cull_cc_px;
     ctx.boxes_in_view = __builtin_amdgcn_readfirstlane(__float_as_int(fc[FC_BOX_IN_VIEW])) != 0;
+    ctx.item_res = (d.debug_flags & (1 | 32 | 128)) ? nullptr : item_res;   // filled by the lattice pass below
+    ctx.part_h_inv = 65536 / ((H + 3) / 4) + 1;
 
     // Pass structure per wave: a 16 x 4 grid of rays through PIXEL CORNERS per pass, marching down a
     // 15-pixel-wide strip; the last corner row of a pass is carried in registers, so a pass classifies
@@ -2048,7 +2067,8 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         }
     };
     // may a box intrude into an otherwise uniform pixel?  centre ray against the footprint-inflated bounding spheres
-    auto box_may_touch = [&](int px, int py) {
+    auto box_may_touch = [&](int px, int py, uint32_t boxes /* wave-uniform: the item's */) {
+        if (NBOX > 1 && !boxes) return false;
         float dc[3];
         make_ray(cam, (float)px + 0.5f, (float)(H - 1 - py) + 0.5f, dc);
         const float dd = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
@@ -2056,7 +2076,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
 #pragma unroll
         for (int bi = 0; bi < NBOX; bi++) {
             const float b = dc[0] * ctx.cull_oc[bi][0] + dc[1] * ctx.cull_oc[bi][1] + dc[2] * ctx.cull_oc[bi][2];
-            if (cull_cc_px[bi] <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc_px[bi])) touch = true;
+            if ((NBOX == 1 || ((boxes >> bi) & 1u)) && (cull_cc_px[bi] <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc_px[bi]))) touch = true;
         }
         return touch;
     };
@@ -2115,8 +2135,48 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
                     const int r = POLY ? walk_rooms_poly(rooms, ctx.cam_room, cam.eye, dv, common) : walk_rooms(rooms, ctx.cam_room, cam.eye, dv, common);
                     if (r >= 0) item_room = r; else common = 0;
                 }
+                // Which boxes can touch this item at all?  The item's rays lie in the cone around its centre ray that holds its
+                // corner rays (half angle a); box b's pixel-inflated bounding sphere (the one box_may_touch tests) subtends
+                // asin(R / dist) around the direction to its centre: no ray of the item meets it unless the two directions are
+                // within a + b of each other.  Conservative (2 % on R, 0.02 on the cosine); evaluated once per item.
+                uint32_t boxes = 0xFFFFFFFFu;
+                if (NBOX > 1 && ctx.boxes_in_view) {
+                    boxes = 0;
+                    const int ix0 = strip * (TILE_CX - 1), iwi = (W - ix0) < (TILE_CX - 1) ? (W - ix0) : (TILE_CX - 1);
+                    float c[3], cn;
+                    make_ray(cam, (float)ix0 + 0.5f * (float)iwi, (float)(H - row0) - 0.5f * (float)rows, c);
+                    cn = __builtin_amdgcn_rsqf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+                    float cos_a = 1.0f;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float e[3];
+                        make_ray(cam, (float)(ix0 + ((j & 1) ? iwi : 0)), (float)(H - row0 - ((j & 2) ? rows : 0)), e);
+                        const float en = __builtin_amdgcn_rsqf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+                        const float dt = (c[0] * e[0] + c[1] * e[1] + c[2] * e[2]) * cn * en;
+                        cos_a = dt < cos_a ? dt : cos_a;
+                    }
+                    cos_a = cos_a - 0.002f;   // the corner rays' cone, a little wider
+                    cos_a = cos_a < 0.0f ? 0.0f : cos_a;
+                    const float sin_a = __builtin_sqrtf(1.0f - cos_a * cos_a);
+#pragma unroll 1
+                    for (int bi = 0; bi < NBOX; bi++) {
+                        const float *fb_ = fc + bi * FC_BOX_STRIDE;
+                        const float ox = fb_[FC_CULL_OC], oy = fb_[FC_CULL_OC + 1], oz = fb_[FC_CULL_OC + 2], ccp = fb_[FC_CULL_CC_PIXEL];
+                        const float oc2 = ox * ox + oy * oy + oz * oz;
+                        bool touch = true;
+                        if (ccp > 0.0f) {   // the eye is outside the inflated sphere
+                            const float idist = __builtin_amdgcn_rsqf(oc2);
+                            float sin_b = 1.02f * __builtin_sqrtf(fmaxf(oc2 - ccp, 0.0f)) * idist;
+                            sin_b = sin_b > 1.0f ? 1.0f : sin_b;
+                            const float cos_b = __builtin_sqrtf(1.0f - sin_b * sin_b);
+                            const float cos_t = (c[0] * ox + c[1] * oy + c[2] * oz) * cn * idist;
+                            touch = cos_t >= cos_a * cos_b - sin_a * sin_b - 0.02f;
+                        }
+                        boxes |= touch ? 1u << bi : 0u;
+                    }
+                }
                 if (rr == 0 && k < 7 && strip < n_strips)
-                    item_res[strip * 4 + q] = make_uint4(ukey, (uint32_t)(ur0 | (ur1 << 16)), (uint32_t)common, (uint32_t)item_room);
+                    item_res[strip * 4 + q] = make_uint4(ukey, (uint32_t)(ur0 | (ur1 << 16)), boxes, (uint32_t)((item_room & 0xFFFF) | (common << 16)));
             }
         }
         __syncthreads();
@@ -2133,6 +2193,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         if (rows <= 0) continue;
         int prow0 = row0, prows = rows;   // the rows left for the per-pixel corner passes
         int item_skip = 0, item_room = ctx.cam_room;
+        uint32_t item_boxes = 0xFFFFFFFFu;   // the boxes whose pixel-inflated sphere can meet the item's rays
         if (d.debug_flags & 128) continue;   // experiment: prologue + copy-out only
         if (!(d.debug_flags & (1 | 32))) {
             const int wi = (W - x0) < (TILE_CX - 1) ? (W - x0) : (TILE_CX - 1);   // pixel columns of this item
@@ -2140,8 +2201,10 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             const uint32_t ukey = (uint32_t)__builtin_amdgcn_readfirstlane((int)res.x);
             const int urw = __builtin_amdgcn_readfirstlane((int)res.y);
             const int ur0 = urw & 0xFFFF, ur1 = urw >> 16;   // uniform rows [ur0, ur1) of the item
-            item_skip = __builtin_amdgcn_readfirstlane((int)res.z);   // crossings every ray of the item makes, and the room behind them
-            item_room = __builtin_amdgcn_readfirstlane((int)res.w);
+            if (NBOX > 1) item_boxes = (uint32_t)__builtin_amdgcn_readfirstlane((int)res.z);
+            const int rw = __builtin_amdgcn_readfirstlane((int)res.w);
+            item_skip = rw >> 16;                                        // crossings every ray of the item makes, and the room behind them
+            item_room = (rw & 0xFFFF) == 0xFFFF ? -1 : (rw & 0xFFFF);
             if (ur1 > ur0) {
                 if (ur0 == 0 && ur1 == rows) prows = 0;
                 else if (ur0 == 0) { prow0 = row0 + ur1; prows = rows - ur1; }
@@ -2152,7 +2215,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
                 const int px = x0 + col, py = row0 + r0 + lane / TILE_CX;
                 const bool is_pixel = col < wi && py < row0 + ur1;
                 bool interior = is_pixel;
-                if (interior && ctx.boxes_in_view && box_may_touch(px, py)) interior = false;
+                if (interior && ctx.boxes_in_view && box_may_touch(px, py, item_boxes)) interior = false;
                 emit(px, py, is_pixel, interior, ukey, 0);
             }
             if (prows <= 0) continue;
@@ -2183,7 +2246,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             const bool is_pixel = ci < TILE_CX - 1 && px < W && py >= prow0 && py < prow0 + prows && !(p == 0 && cj == 0);
             bool interior = !(d.debug_flags & 1) && is_pixel && ok && key == k_br && key == k_tl && key == k_tr &&
                             path == p_br && path == p_tl && path == p_tr;
-            if (interior && ctx.boxes_in_view && box_may_touch(px, py)) interior = false;
+            if (interior && ctx.boxes_in_view && box_may_touch(px, py, item_boxes)) interior = false;
             int skip = common_crossings4(path, p_br, p_tl, p_tr) + item_skip;
             skip = skip < skip_max ? skip : skip_max;
             emit(px, py, is_pixel, interior, key, skip);
