@@ -1976,25 +1976,28 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     for (int k = 0; k < 3; k++) { cam.eye[k] = uni(fc[FC_EYE + k]); cam.F[k] = uni(fc[FC_F + k]); cam.S[k] = uni(fc[FC_S + k]); cam.U[k] = uni(fc[FC_U + k]); }
     cam.TW = uni(fc[FC_TW]); cam.TH = uni(fc[FC_TH]);
     cam.Wf = (float)W; cam.Hf = (float)H; cam.invW = 1.0f / (float)W; cam.invH = 1.0f / (float)H;
-    // room containing the eye: first (lowest index) rectangle that holds it, bounds inclusive
-    for (int i = tid; i < n_rooms; i += THREADS) {
-        if constexpr (POLY) {   // first room, in creation order, with the eye on the inner side of every edge; never a culled one
-            const float *r = rooms + i * MWB_POLY_ROOM_WORDS;
-            bool in = !((__float_as_int(r[PW_FLAGS]) >> 8) & 1);
-            for (int k = 0; k < 4; k++) {
-                const float *ed = r + PW_EDGE0 + PW_EDGE_WORDS * k;
-                if (!(fmaf(ed[5], cam.eye[2] - ed[1], ed[4] * (cam.eye[0] - ed[0])) >= 0.0f)) in = false;
+    // room containing the eye: first (lowest index) rectangle that holds it, bounds inclusive.  Every wave finds it for
+    // itself (64 rooms per sweep, lowest set bit of the first non-empty ballot): no LDS atomic, no barrier
+    ctx.cam_room = -1;
+    for (int base = 0; base < n_rooms; base += WAVE) {
+        const int i = base + (tid & (WAVE - 1));
+        bool in = i < n_rooms;
+        if (in) {
+            if constexpr (POLY) {   // the eye on the inner side of every edge; never a culled room
+                const float *r = rooms + i * MWB_POLY_ROOM_WORDS;
+                in = !((__float_as_int(r[PW_FLAGS]) >> 8) & 1);
+                for (int k = 0; k < 4; k++) {
+                    const float *ed = r + PW_EDGE0 + PW_EDGE_WORDS * k;
+                    if (!(fmaf(ed[5], cam.eye[2] - ed[1], ed[4] * (cam.eye[0] - ed[0])) >= 0.0f)) in = false;
+                }
+            } else {
+                const float *r = rooms + i * MWB_ROOM_WORDS;
+                in = cam.eye[0] >= r[RW_MINX] && cam.eye[0] <= r[RW_MAXX] && cam.eye[2] >= r[RW_MINZ] && cam.eye[2] <= r[RW_MAXZ];
             }
-            if (in) atomicMin(cam_room_s, i);
-        } else {
-            const float *r = rooms + i * MWB_ROOM_WORDS;
-            if (cam.eye[0] >= r[RW_MINX] && cam.eye[0] <= r[RW_MAXX] && cam.eye[2] >= r[RW_MINZ] && cam.eye[2] <= r[RW_MAXZ])
-                atomicMin(cam_room_s, i);
         }
+        const unsigned long long m = __ballot(in);
+        if (m) { ctx.cam_room = base + (__ffsll((long long)m) - 1); break; }
     }
-    __syncthreads();
-    ctx.cam_room = __builtin_amdgcn_readfirstlane(*cam_room_s);
-    if (ctx.cam_room == 0x7fffffff) ctx.cam_room = -1;
     const float zn = 0.04f, zf = 100.0f;   // gluPerspective near / far, miniworld.py:1186-1187
     ctx.zA = (zf + zn) / (zf - zn); ctx.zB = (2.0f * zf * zn) / (zf - zn);
     float cull_cc_px[NBOX];   // sphere inflated by a pixel footprint (prep_kernel)
