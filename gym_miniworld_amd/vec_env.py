@@ -118,12 +118,13 @@ class MiniWorldVecEnv(VecEnv):
                        requires (pytorch-a2c-ppo-acktr/main.py:614-619)
     graph=True      -> after two eager steps the whole step (mwb_step's kernels on both streams, the frame-stack /
                        float pass, the copies into the pinned host mirrors) is captured into one HIP graph and
-                       replayed: the VecEnv contract forces a host round trip per step, so the ~10 launches a step
-                       consists of would otherwise sit on the critical path (steps with a `mask` run eagerly)
+                       replayed (steps with a `mask` run eagerly).  Off by default: on ROCm 7.2 / MI355X replay is no
+                       faster than the ~10 eager launches (0.718 vs 0.715 ms per step at 8192 Maze envs) and now and
+                       then a replayed graph runs 15-40 % slower for a whole run (scripts/ab_vecenv_graph.py)
     """
 
     def __init__(self, env_id, num_envs, seed=1, device=0, domain_rand=False, transpose=True, to_float=True,
-                 frame_stack=0, torch_api=True, feature_info=False, first_env_index=0, graph=True, **kwargs):
+                 frame_stack=0, torch_api=True, feature_info=False, first_env_index=0, graph=False, **kwargs):
         import torch
         from .batch import BatchedMiniWorld
         self.torch = torch

@@ -239,3 +239,21 @@ def test_vecenv_leg_of_the_bench_line():
     v = d["vecenv"]
     assert "error" not in v, v
     assert v["vecenv_u8"]["value"] > 0 and v["make_vec_envs_f32_stack4"]["value"] > 0 and v["vecenv_u8"]["infos"] == "LazyInfos"
+
+
+def test_vecenv_graph_replay_equals_eager_steps():
+    """MiniWorldVecEnv(graph=True) (optional: off by default) replays the captured step; results equal the eager path's"""
+    import torch
+    from gym_miniworld_amd.vec_env import MiniWorldVecEnv
+    n = 64
+    a = MiniWorldVecEnv("MiniWorld-FourRooms-v0", n, seed=9, to_float=False, graph=True)
+    b = MiniWorldVecEnv("MiniWorld-FourRooms-v0", n, seed=9, to_float=False, graph=False)
+    assert torch.equal(a.reset(), b.reset())
+    g = torch.Generator().manual_seed(1)
+    for t in range(12):
+        act = torch.randint(0, 3, (n, 1), generator=g)
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and np.array_equal(da, db), t
+    assert a._graph is not None and b._graph is None
+    a.close(); b.close()
