@@ -528,9 +528,7 @@ extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t
     mwb_launch_reset(h->dev, 128, h->side);   // a handful of envs end per step: few blocks, started ahead of the bulk render
     rc = check_launch("reset_kernel"); if (rc) return rc;
     if (h->timing_now) HIP_TRY(hipEventRecord(h->ev[6], h->side));
-    mwb_launch_prep(h->dev, 1, h->side);
-    rc = check_launch("prep_kernel"); if (rc) return rc;
-    mwb_launch_render(h->dev, 1, h->side);
+    mwb_launch_render(h->dev, 1, h->side);   // reset_kernel has prepared the frame constants of the envs it regenerated
     rc = check_launch("render_kernel"); if (rc) return rc;
     mwb_launch_clear_list(h->dev, h->side);   // the list is consumed; off the critical path
     // also off the critical path: the next step's dispatch order, from the frame costs measured so far

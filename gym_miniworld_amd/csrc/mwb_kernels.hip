@@ -419,6 +419,7 @@ __device__ __forceinline__ void vec_mat(const double *v, const double *m, double
 }
 
 // ================================================================================= reset kernel
+__device__ __forceinline__ void prep_env(const MwbDev &d, int e);   // the prep kernel's per-env body, below
 // World generation.  One wave per environment; all 64 lanes run the same sequential logic on
 // identical values (the RNG stream is inherently serial) and split the wide parts: the MT19937
 // twist, the circle-vs-segments tests of the placement loop and the emission of the room / segment
@@ -730,6 +731,9 @@ __device__ __forceinline__ void sample_param(MtWave &g, const MwbParam &p, int n
 }
 
 __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
+    // The regenerated envs' chain (this kernel, then their render) runs beside the bulk render, whose five waves per SIMD
+    // would otherwise leave a lone latency-bound wave one issue slot in six: raise the wave's priority at the arbiter
+    __builtin_amdgcn_s_setprio(3);
     const int count = d.reset_count[0];
     const int lane = threadIdx.x;
     for (int li = blockIdx.x; li < count; li += gridDim.x) {
@@ -1115,6 +1119,9 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         o[RW_NBR01] = __int_as_float((int)(nbrs[0] | (nbrs[1] << 16)));
         o[RW_NBR23] = __int_as_float((int)(nbrs[2] | (nbrs[3] << 16)));
     }
+    // the frame constants of the new episode's first view, right here (lane 0 wrote the state it reads): the side stream
+    // needs no prep launch of its own between this kernel and the render of the regenerated envs
+    if (lane == 0) prep_env(d, e);
     }   // env loop
 }
 
@@ -1261,7 +1268,8 @@ void mwb_launch_order(const MwbDev &d, hipStream_t s) {
 
 __global__ void __launch_bounds__(256) prep_kernel(MwbDev d, int mode) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (mode == 1) {   // the regenerated envs, through the compact list
+    if (mode == 1) {
+        __builtin_amdgcn_s_setprio(3);   // beside the bulk render (see reset_kernel)   // the regenerated envs, through the compact list
         const int count = d.reset_count[0];
         for (int li = e; li < count; li += gridDim.x * blockDim.x) prep_env(d, d.reset_list[li]);
         return;
@@ -2310,6 +2318,7 @@ template <int THREADS, int MODE, int NBOX, bool POLY = false>
 __global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (MODE == 1) {
+        __builtin_amdgcn_s_setprio(3);   // the few regenerated envs, beside the bulk render (see reset_kernel)
         const int count = d.reset_count[0];
         for (int li = blockIdx.x; li < count; li += gridDim.x) {
             render_env<THREADS, NBOX, true, POLY>(d, d.reset_list[li], -1, smem);
