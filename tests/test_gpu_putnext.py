@@ -212,3 +212,40 @@ def test_putnext_gym_view_and_vecenv(oracle_mod):
         obs, rew, done, infos = v.step(torch.randint(0, 8, (8, 1)))
     assert obs.shape == (8, 3, 80, 60) and len(infos) == 8
     v.close()
+
+
+@pytest.mark.parametrize("W,H", [(97, 41), (160, 120), (48, 100)])
+def test_putnext_and_ymaze_at_other_frame_sizes(oracle_mod, W, H):
+    """the per-item box masks, the lattice pre-test (more than 7 strips at 160 wide: two passes) and the polygon rooms are not
+    specialised for 80 x 60: six boxes / polygon rooms at odd sizes, RGB + depth against the oracle, fast path == 8-sample path"""
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    O = oracle_mod
+    n = 8
+    for env_id, task, args in ((ENV_ID, "PutNext", None), ("MiniWorld-YMaze-v0", "YMaze", [0, 0, 0, 0])):
+        b = BatchedMiniWorld(env_id, num_envs=n, seed=21, domain_rand=True, obs_width=W, obs_height=H, want_depth=True)
+        import os
+        os.environ["MWB_DEBUG"] = "9"
+        try:
+            full = BatchedMiniWorld(env_id, num_envs=n, seed=21, domain_rand=True, obs_width=W, obs_height=H, want_depth=True)
+        finally:
+            del os.environ["MWB_DEBUG"]
+        envs = [O.OracleEnv(task, seed=21 + i, domain_rand=True, task_args=args, obs_width=W, obs_height=H) for i in range(n)]
+        b.reset(); full.reset()
+        for e in envs:
+            e.reset(render=False)
+        rng = np.random.default_rng(1)
+        for rnd in range(3):
+            for t in range(10 * rnd):
+                a = rng.integers(0, 3, n).astype(np.int32)
+                b.step(torch.from_numpy(a)); full.step(torch.from_numpy(a))
+                for i, e in enumerate(envs):
+                    _, _, d, _ = e.step(int(a[i]))
+                    if d:
+                        e.reset(render=False)
+            assert torch.equal(b.obs, full.obs) and torch.equal(b.depth, full.depth), (env_id, W, H, rnd)
+            obs, dep = b.obs.cpu().numpy(), b.depth.cpu().numpy()[..., 0]
+            for i, e in enumerate(envs):
+                ref, refd = e.render_obs(depth=True)
+                assert obs_diff(obs[i], ref).max() <= 1 and np.abs(dep[i] - refd).max() <= 1e-4, (env_id, W, H, rnd, i)
+        b.close(); full.close()
