@@ -19,7 +19,7 @@ from oracle import oracle as O  # noqa: E402
 TASKS = [("MiniWorld-Hallway-v0", "Hallway"), ("MiniWorld-OneRoom-v0", "OneRoom"), ("MiniWorld-FourRooms-v0", "FourRooms"),
          ("MiniWorld-MazeS3-v0", "Maze"), ("MiniWorld-Maze-v0", "Maze"), ("MiniWorld-TMaze-v0", "TMaze"),
          ("MiniWorld-TMazeDynamic-v0", "TMaze"), ("MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0", "TMazeTwoBox"),
-         ("MiniWorld-SimToRealGoTo-v0", "SimToRealGoTo"), ("MiniWorld-SimToRealPush-v0", "SimToRealPush")]
+         ("MiniWorld-SimToRealGoTo-v0", "SimToRealGoTo"), ("MiniWorld-SimToRealPush-v0", "SimToRealPush"), ("MiniWorld-PutNext-v0", "PutNext"), ("MiniWorld-YMaze-v0", "YMaze"), ("MiniWorld-YMazeLeft-v0", "YMaze")]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 for env_id, task in TASKS:
@@ -38,7 +38,8 @@ for env_id, task in TASKS:
         episodes = rewards = mism = pose_mism = 0
         pose_ulp = 0.0
         for t in range(steps):
-            a = rng.choice(na, size=n, p=[0.2, 0.2, 0.6] if na == 3 else [0.2, 0.2, 0.5, 0.1]).astype(np.int32)
+            a = rng.choice(na, size=n, p=[0.2, 0.2, 0.6] if na == 3 else [0.2, 0.2, 0.5, 0.1] if na == 4 else
+                           [0.15, 0.15, 0.4, 0.05, 0.15, 0.06, 0.02, 0.02]).astype(np.int32)
             b.step(torch.from_numpy(a))
             rew, done, eps = b.reward64.cpu().numpy(), b.done.cpu().numpy(), b.ep_steps.cpu().numpy()
             for i, e in enumerate(envs):
@@ -64,6 +65,10 @@ for env_id, task in TASKS:
                     if not np.array_equal(st[k].astype(np.int64) if st[k].dtype.kind in "iu" else st[k], np.array([f(s) for s in os_])):
                         mism += 1
                 if not np.array_equal(st["box_pos"], np.array([list(s.box_pos) for s in os_])):
+                    mism += 1
+                nb = b.n_boxes   # every box incl. the carry height, and who carries what (PutNext)
+                if not np.array_equal(st["boxes_pos"], np.array([np.array(s.boxes_pos)[:nb] for s in os_])) or \
+                        not np.array_equal(st["carrying"], np.array([s.carrying for s in os_])):
                     mism += 1
         b.close()
         print("%-46s dr%d  %d envs x %d steps  episodes %6d  nonzero rewards %6d  MISMATCHES %d  POSE MISMATCHES %d (max %.1f ulp)  (%.0f s)"
