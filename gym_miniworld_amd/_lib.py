@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MWB_LIB") or os.path.join(HERE, "libmwbatch.so")   # MWB_LIB: kernel A/B experiments only
 
 NPARAM = 13
+STACK_SLIDING = 16   # MWB_STACK_SLIDING
 ROOM_WORDS = 24
 POLY_ROOM_WORDS = 52   # MWB_TASK_YMAZE (include/miniworld_batch.h)
 ABI_VERSION = 4
@@ -53,7 +54,7 @@ class MwbState(ctypes.Structure):
 EXPORTS = [
     "mwb_create", "mwb_destroy", "mwb_last_error", "mwb_abi_version", "mwb_set_texture", "mwb_seed", "mwb_reset",
     "mwb_step", "mwb_render", "mwb_get_outputs", "mwb_get_state", "mwb_set_agent", "mwb_intersect",
-    "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read", "mwb_stack_enable", "mwb_stack_update", "mwb_check", "mwb_seed_key",
+    "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read", "mwb_stack_enable", "mwb_stack_update", "mwb_stack_window", "mwb_check", "mwb_seed_key",
     "mwb_set_task_state", "mwb_set_domain_rand", "mwb_num_textures", "mwb_debug_wg_times", "mwb_set_state", "mwb_num_boxes", "mwb_room_words", "mwb_render_top_view", "mwb_visible_ents",
 ]
 
@@ -104,6 +105,7 @@ def load():
     L.mwb_check.argtypes = [vp]
     L.mwb_seed_key.argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint32)]
     L.mwb_stack_update.argtypes = [vp, i32, vp]
+    L.mwb_stack_window.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.mwb_timing_read.argtypes = [vp] + [ctypes.POINTER(ctypes.c_double)] * 4 + [ctypes.POINTER(i32)]
     if L.mwb_abi_version() != ABI_VERSION:
         raise MwbError("libmwbatch.so ABI version mismatch")

@@ -347,20 +347,31 @@ class BatchedMiniWorld:
         return rooms[:nr.value], segs[:ns.value]
 
     # ------------------------------------------------------------------------------ frame stack
-    def stack_enable(self, nstack=4, dtype="float32"):
+    def stack_enable(self, nstack=4, dtype="float32", sliding=True):
         """Library-owned [N, nstack*3, W, H] stack kept by one fused HIP pass per step
-        (VecPyTorchFrameStack + .float(), pytorch-a2c-ppo-acktr/envs.py:117-165). Needs layout='CWH'."""
+        (VecPyTorchFrameStack + .float(), pytorch-a2c-ppo-acktr/envs.py:117-165). Needs layout='CWH'.
+        sliding=True: the stack is a window that moves over a longer run of planes per env, so a step writes the new frame only
+        (1/4 of the shifting stack's HBM traffic); stack_update() then returns a strided view [N, nstack*3, W, H] of it (same
+        values; a different view object every step).  sliding=False: the shifting stack in one fixed contiguous tensor."""
         torch = self.torch
         is_f = {"float32": 1, "uint8": 0}[dtype]
-        _lib.check(self.L.mwb_stack_enable(self.h, int(nstack), is_f))
+        _lib.check(self.L.mwb_stack_enable(self.h, int(nstack), is_f | (_lib.STACK_SLIDING if sliding else 0)))
         out = _lib.MwbOutputs()
         _lib.check(self.L.mwb_get_outputs(self.h, ctypes.byref(out)))
-        shape = (self.num_envs, nstack * 3, self.W, self.H)
-        self.stack = torch.as_tensor(_DevView(out.stack, shape, "<f4" if is_f else "|u1", self), device=self.device)
+        first, planes = ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self.L.mwb_stack_window(self.h, ctypes.byref(first), ctypes.byref(planes)))
+        self._stack_c, self._stack_sliding = nstack * 3, bool(sliding)
+        shape = (self.num_envs, planes.value, self.W, self.H)
+        self._stack_base = torch.as_tensor(_DevView(out.stack, shape, "<f4" if is_f else "|u1", self), device=self.device)
+        self.stack = self._stack_base[:, first.value:first.value + self._stack_c]
         return self.stack
 
     def stack_update(self, after_reset=False):
         _lib.check(self.L.mwb_stack_update(self.h, int(bool(after_reset)), self._stream()))
+        if self._stack_sliding:
+            first = ctypes.c_int32()
+            _lib.check(self.L.mwb_stack_window(self.h, ctypes.byref(first), None))
+            self.stack = self._stack_base[:, first.value:first.value + self._stack_c]
         return self.stack
 
     def timing_enable(self, on=True):

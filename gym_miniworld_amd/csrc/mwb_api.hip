@@ -63,6 +63,7 @@ struct mwb_handle {
     size_t pack_bytes;
     void *stack;
     int stack_n, stack_dtype;
+    int stack_planes, stack_pos;   // sliding-window stack: planes per env (0 = the classic shifting stack), the window's first plane
     size_t stack_bytes;
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
@@ -313,7 +314,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     h->timing = false; h->timing_now = false; h->timing_period = 1; h->timing_tick = 0; h->ev_used = 0; h->ev = nullptr;
     { const char *no = getenv("MWB_NO_OVERLAP"); h->overlap_reset = !(no && atoi(no)); }
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
-    h->stack = nullptr; h->stack_n = 0; h->stack_dtype = 0; h->stack_bytes = 0;
+    h->stack = nullptr; h->stack_n = 0; h->stack_dtype = 0; h->stack_bytes = 0; h->stack_planes = 0; h->stack_pos = 0;
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // numerically lowest = highest priority
     if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
@@ -601,24 +602,44 @@ extern "C" int mwb_check(mwb_handle *h) {
 extern "C" int mwb_stack_enable(mwb_handle *h, int nstack, int dtype) {
     if (!h) return set_err(MWB_EINVAL, "mwb_stack_enable: null handle");
     const MwbDev &d = h->dev;
+    const int sliding = (dtype & MWB_STACK_SLIDING) != 0;
+    dtype &= ~MWB_STACK_SLIDING;
     if (nstack < 1 || nstack > 16 || (dtype != 0 && dtype != 1)) return set_err(MWB_EINVAL, "mwb_stack_enable: bad nstack / dtype");
     if (d.layout != MWB_LAYOUT_CWH) return set_err(MWB_EINVAL, "mwb_stack_enable: the frame stack is channel-first, create the handle with MWB_LAYOUT_CWH");
     if ((d.W * d.H) % 4) return set_err(MWB_EINVAL, "mwb_stack_enable: W*H must be a multiple of 4");
     if (h->stack) return set_err(MWB_ESTATE, "mwb_stack_enable: already enabled");
     USE_DEVICE(h->cfg.device);
-    size_t bytes = (size_t)d.N * nstack * 3 * d.W * d.H * (dtype == 1 ? 4 : 1);
+    const int planes = sliding ? nstack * 3 + 3 * MWB_STACK_SLACK_FRAMES : nstack * 3;
+    size_t bytes = (size_t)d.N * planes * d.W * d.H * (dtype == 1 ? 4 : 1);
     uint8_t *p = nullptr;
     int rc = dev_alloc(h, &p, bytes);
     if (rc) return rc;
     h->stack = p; h->stack_n = nstack; h->stack_dtype = dtype; h->stack_bytes = bytes;
+    h->stack_planes = sliding ? planes : 0; h->stack_pos = 0;
     return MWB_OK;
 }
 
 extern "C" int mwb_stack_update(mwb_handle *h, int after_reset, void *stream) {
     if (!h || !h->stack) return set_err(MWB_ESTATE, "mwb_stack_update: call mwb_stack_enable first");
     USE_DEVICE(h->cfg.device);
+    if (h->stack_planes) {   // sliding window: the host owns the window position (mwb_stack_window)
+        const int C = h->stack_n * 3, from = h->stack_pos;
+        int mode = 0, pos = from + 3;
+        if (after_reset) { mode = 2; pos = 0; }
+        else if (pos + C > h->stack_planes) { mode = 1; pos = 0; }
+        mwb_launch_stack_slide(h->dev, h->stack, h->stack_n, h->stack_planes, h->stack_dtype, pos, from, mode, (hipStream_t)stream);
+        h->stack_pos = pos;
+        return check_launch("stack_slide_kernel");
+    }
     mwb_launch_stack(h->dev, h->stack, h->stack_n, h->stack_dtype, after_reset, (hipStream_t)stream);
     return check_launch("stack_kernel");
+}
+
+extern "C" int mwb_stack_window(mwb_handle *h, int *first_plane, int *planes_per_env) {
+    if (!h || !h->stack) return set_err(MWB_ESTATE, "mwb_stack_window: call mwb_stack_enable first");
+    if (first_plane) *first_plane = h->stack_planes ? h->stack_pos : 0;
+    if (planes_per_env) *planes_per_env = h->stack_planes ? h->stack_planes : h->stack_n * 3;
+    return MWB_OK;
 }
 
 // -------------------------------------------------------------------------------- introspection

@@ -161,6 +161,7 @@ void mwb_launch_reset(const MwbDev &d, int max_blocks, hipStream_t s);   // grid
 void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s);
 void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s);
 void mwb_launch_stack(const MwbDev &d, void *stack, int nstack, int dtype, int after_reset, hipStream_t s);
+void mwb_launch_stack_slide(const MwbDev &d, void *stack, int nstack, int planes, int dtype, int pos, int from, int mode, hipStream_t s);
 void mwb_launch_intersect(const MwbDev &d, int env, int ent, double x, double z, double radius, int *result_dev, hipStream_t s);
 void mwb_launch_visible(const MwbDev &d, uint32_t *mask_out, hipStream_t s);   // get_visible_ents for every env
 void mwb_launch_top_view(const MwbDev &d, uint8_t *out, int W, int H, hipStream_t s);   // render_top_view for every env, [N][H][W][3]

@@ -2380,6 +2380,46 @@ __global__ void __launch_bounds__(256) stack_kernel(MwbDev d, V *__restrict__ st
     }
 }
 
+// The same stack as a SLIDING WINDOW over K > C channel planes per env: the view of step t is planes [pos, pos + C); a step
+// moves the window three planes on and writes only the new frame (3 planes) - the C - 3 planes of history stay where they
+// are - and zeroes the history of the envs whose episode ended; when the window reaches the end of the K planes the
+// history is copied back to the front (the classic pass, once every (K - C) / 3 + 1 steps).  mode: 0 slide to `pos` (the
+// window's new first plane), 1 wrap (history from `from`, window at 0), 2 after reset (window at 0, history zeroed).
+template <typename V, bool IS_FLOAT>
+__global__ void __launch_bounds__(256) stack_slide_kernel(MwbDev d, V *__restrict__ stack, int C, int K, int pos, int from, int mode) {
+    const int e = blockIdx.y;
+    const int plane4 = (d.W * d.H) / 4;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= plane4) return;
+    V *base = stack + (size_t)e * K * plane4;
+    const bool clear = mode == 2 || d.done[e];
+    V zero;
+    memset(&zero, 0, sizeof(V));
+    if (mode == 1 && !clear) {
+        for (int c = 0; c < C - 3; c++) base[(size_t)c * plane4 + j] = base[(size_t)(from + 3 + c) * plane4 + j];
+    } else if (clear) {
+        for (int c = 0; c < C - 3; c++) base[(size_t)(pos + c) * plane4 + j] = zero;
+    }
+    const uint32_t *obs = (const uint32_t *)(d.obs + (size_t)e * 3 * d.W * d.H);   // CWH: [3][W][H]
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint32_t p = obs[(size_t)k * plane4 + j];
+        V v;
+        if constexpr (IS_FLOAT) {
+            v.x = (float)(p & 255u); v.y = (float)((p >> 8) & 255u); v.z = (float)((p >> 16) & 255u); v.w = (float)(p >> 24);
+        } else {
+            v = p;
+        }
+        base[(size_t)(pos + C - 3 + k) * plane4 + j] = v;
+    }
+}
+void mwb_launch_stack_slide(const MwbDev &d, void *stack, int nstack, int planes, int dtype, int pos, int from, int mode, hipStream_t s) {
+    const int plane4 = (d.W * d.H) / 4;
+    dim3 grid((plane4 + 255) / 256, d.N);
+    if (dtype == 1) stack_slide_kernel<float4, true><<<grid, dim3(256), 0, s>>>(d, (float4 *)stack, nstack * 3, planes, pos, from, mode);
+    else stack_slide_kernel<uint32_t, false><<<grid, dim3(256), 0, s>>>(d, (uint32_t *)stack, nstack * 3, planes, pos, from, mode);
+}
+
 void mwb_launch_stack(const MwbDev &d, void *stack, int nstack, int dtype, int after_reset, hipStream_t s) {
     const int plane4 = (d.W * d.H) / 4;
     dim3 grid((plane4 + 255) / 256, d.N);

@@ -137,8 +137,9 @@ class MiniWorldVecEnv(VecEnv):
         if self.nstack:
             assert transpose, "frame stacking follows VecPyTorchFrameStack: channel-first observations"
             shape = (shape[0] * self.nstack,) + shape[1:]
-            # fused in the library: shift + zero-on-done + append + uint8->float in one HBM pass
-            self.stackedobs = b.stack_enable(self.nstack, "float32" if to_float else "uint8")
+            # fused in the library: zero-on-done + append + uint8->float in one HBM pass over a sliding window (the new
+            # frame is all a step writes; a replayed graph would freeze the window position: the shifting stack there)
+            self.stackedobs = b.stack_enable(self.nstack, "float32" if to_float else "uint8", sliding=not graph)
         VecEnv.__init__(self, num_envs, Box(0, 255, shape, np.float32 if to_float else np.uint8), Discrete(b.n_actions))
         self.device = b.device
         self.feature_info = feature_info

@@ -187,6 +187,15 @@ int mwb_get_outputs(mwb_handle *h, mwb_outputs *out);
  * channels (envs.py:158-162); after_reset == 0 implements step_wait(): shift by 3 channels, zero the envs
  * whose `done` is set, append the newest obs (envs.py:149-156) - one pass over the stack. */
 int mwb_stack_enable(mwb_handle *h, int nstack, int dtype);
+/* dtype | MWB_STACK_SLIDING: the stack as a sliding window over nstack*3 + 3*MWB_STACK_SLACK_FRAMES planes per env - a step
+ * writes the new frame only (the history planes stay in place) and the window moves three planes on; once every
+ * MWB_STACK_SLACK_FRAMES + 1 steps the history is copied back to the front.  The current view is planes
+ * [first_plane, first_plane + nstack*3) of each env's planes_per_env (mwb_stack_window, valid after each mwb_stack_update):
+ * same values as the shifting stack at ~1/4 of its HBM traffic.  The window position lives on the host, so a captured graph
+ * of mwb_stack_update must not be replayed with this flag. */
+#define MWB_STACK_SLIDING 16
+#define MWB_STACK_SLACK_FRAMES 8
+int mwb_stack_window(mwb_handle *h, int *first_plane, int *planes_per_env);
 int mwb_stack_update(mwb_handle *h, int after_reset, void *stream);
 
 /* World generation cannot fail for the four tasks with sane arguments; if it ever does (a portal outside
