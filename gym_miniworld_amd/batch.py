@@ -347,15 +347,18 @@ class BatchedMiniWorld:
         return rooms[:nr.value], segs[:ns.value]
 
     # ------------------------------------------------------------------------------ frame stack
-    def stack_enable(self, nstack=4, dtype="float32", sliding=True):
+    def stack_enable(self, nstack=4, dtype="float32", sliding=True, fused=False):
         """Library-owned [N, nstack*3, W, H] stack kept by one fused HIP pass per step
         (VecPyTorchFrameStack + .float(), pytorch-a2c-ppo-acktr/envs.py:117-165). Needs layout='CWH'.
         sliding=True: the stack is a window that moves over a longer run of planes per env, so a step writes the new frame only
         (1/4 of the shifting stack's HBM traffic); stack_update() then returns a strided view [N, nstack*3, W, H] of it (same
-        values; a different view object every step).  sliding=False: the shifting stack in one fixed contiguous tensor."""
+        values; a different view object every step).  sliding=False: the shifting stack in one fixed contiguous tensor.
+        fused=True (implies sliding): reset() / step() write each new frame into the window themselves, straight from the render
+        kernel's LDS frame, and zero the history of the envs they regenerate - stack_update() then only returns the view."""
         torch = self.torch
         is_f = {"float32": 1, "uint8": 0}[dtype]
-        _lib.check(self.L.mwb_stack_enable(self.h, int(nstack), is_f | (_lib.STACK_SLIDING if sliding else 0)))
+        sliding = sliding or fused
+        _lib.check(self.L.mwb_stack_enable(self.h, int(nstack), is_f | (_lib.STACK_SLIDING if sliding else 0) | (_lib.STACK_FUSED if fused else 0)))
         out = _lib.MwbOutputs()
         _lib.check(self.L.mwb_get_outputs(self.h, ctypes.byref(out)))
         first, planes = ctypes.c_int32(), ctypes.c_int32()

@@ -63,6 +63,7 @@ struct mwb_handle {
     size_t pack_bytes;
     void *stack;
     int stack_n, stack_dtype;
+    int stack_fused;               // the render kernels write the frames into the window themselves (MWB_STACK_FUSED)
     int stack_planes, stack_pos;   // sliding-window stack: planes per env (0 = the classic shifting stack), the window's first plane
     size_t stack_bytes;
     hipStream_t side;
@@ -314,7 +315,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     h->timing = false; h->timing_now = false; h->timing_period = 1; h->timing_tick = 0; h->ev_used = 0; h->ev = nullptr;
     { const char *no = getenv("MWB_NO_OVERLAP"); h->overlap_reset = !(no && atoi(no)); }
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
-    h->stack = nullptr; h->stack_n = 0; h->stack_dtype = 0; h->stack_bytes = 0; h->stack_planes = 0; h->stack_pos = 0;
+    h->stack = nullptr; h->stack_n = 0; h->stack_dtype = 0; h->stack_bytes = 0; h->stack_planes = 0; h->stack_pos = 0; h->stack_fused = 0;
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // numerically lowest = highest priority
     if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
@@ -476,6 +477,21 @@ static int render_tail(mwb_handle *h, int mode, hipStream_t s) {
     return MWB_OK;
 }
 
+// Fused frame stack: move the window on for the pass that is about to render (0 = a step, 2 = a reset of everything), copying
+// the history back to the front first when the window has reached the end of its planes.
+static int stack_advance(mwb_handle *h, int after_reset, hipStream_t s) {
+    if (!h->stack_fused) return MWB_OK;
+    const int C = h->stack_n * 3, from = h->stack_pos;
+    int pos = after_reset ? 0 : from + 3;
+    if (!after_reset && pos + C > h->stack_planes) {
+        mwb_launch_stack_slide(h->dev, h->stack, h->stack_n, h->stack_planes, h->stack_dtype, 0, from, 3, s);
+        int rc = check_launch("stack_slide_kernel"); if (rc) return rc;
+        pos = 0;
+    }
+    h->stack_pos = pos; h->dev.stk_pos = pos;
+    return MWB_OK;
+}
+
 static int ensure_ready(mwb_handle *h) {   // the caller holds the device guard
     if (!h->seeded) return set_err(MWB_ESTATE, "mwb_seed must be called before reset/step (the reference seeds from entropy; this library refuses to)");
     if (h->textures_dirty || !h->have_textures) { int rc = upload_textures(h); if (rc) return rc; }
@@ -488,6 +504,7 @@ extern "C" int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream) {
     int rc = ensure_ready(h); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     rc = timing_begin(h, s); if (rc) return rc;
+    rc = stack_advance(h, mask_dev == nullptr, s); if (rc) return rc;   // a full reset restarts the window; a partial one is a step for the others
     mwb_launch_mark_reset(h->dev, mask_dev, s);
     rc = check_launch("mark_reset_kernel"); if (rc) return rc;
     TMARK(1); TMARK(5);
@@ -509,6 +526,7 @@ extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t
     if (!actions_dev) return set_err(MWB_EINVAL, "mwb_step: null actions");
     hipStream_t s = (hipStream_t)stream;
     rc = timing_begin(h, s); if (rc) return rc;
+    rc = stack_advance(h, 0, s); if (rc) return rc;
     mwb_launch_step(h->dev, actions_dev, skip_mask_dev, s);
     rc = check_launch("step_kernel"); if (rc) return rc;
     TMARK(1);
@@ -602,12 +620,14 @@ extern "C" int mwb_check(mwb_handle *h) {
 extern "C" int mwb_stack_enable(mwb_handle *h, int nstack, int dtype) {
     if (!h) return set_err(MWB_EINVAL, "mwb_stack_enable: null handle");
     const MwbDev &d = h->dev;
-    const int sliding = (dtype & MWB_STACK_SLIDING) != 0;
-    dtype &= ~MWB_STACK_SLIDING;
+    const int fused = (dtype & MWB_STACK_FUSED) != 0;
+    const int sliding = fused || (dtype & MWB_STACK_SLIDING) != 0;
+    dtype &= ~(MWB_STACK_SLIDING | MWB_STACK_FUSED);
     if (nstack < 1 || nstack > 16 || (dtype != 0 && dtype != 1)) return set_err(MWB_EINVAL, "mwb_stack_enable: bad nstack / dtype");
     if (d.layout != MWB_LAYOUT_CWH) return set_err(MWB_EINVAL, "mwb_stack_enable: the frame stack is channel-first, create the handle with MWB_LAYOUT_CWH");
     if ((d.W * d.H) % 4) return set_err(MWB_EINVAL, "mwb_stack_enable: W*H must be a multiple of 4");
     if (h->stack) return set_err(MWB_ESTATE, "mwb_stack_enable: already enabled");
+    if (fused && dtype == 0 && (d.W * d.H) % 16) return set_err(MWB_EINVAL, "mwb_stack_enable: a fused uint8 stack needs W*H to be a multiple of 16");
     USE_DEVICE(h->cfg.device);
     const int planes = sliding ? nstack * 3 + 3 * MWB_STACK_SLACK_FRAMES : nstack * 3;
     size_t bytes = (size_t)d.N * planes * d.W * d.H * (dtype == 1 ? 4 : 1);
@@ -615,13 +635,18 @@ extern "C" int mwb_stack_enable(mwb_handle *h, int nstack, int dtype) {
     int rc = dev_alloc(h, &p, bytes);
     if (rc) return rc;
     h->stack = p; h->stack_n = nstack; h->stack_dtype = dtype; h->stack_bytes = bytes;
-    h->stack_planes = sliding ? planes : 0; h->stack_pos = 0;
+    h->stack_planes = sliding ? planes : 0; h->stack_pos = 0; h->stack_fused = fused;
+    if (fused) {
+        MwbDev &dd = h->dev;
+        dd.stk = p; dd.stk_float = dtype == 1; dd.stk_C = nstack * 3; dd.stk_K = planes; dd.stk_pos = 0;
+    }
     return MWB_OK;
 }
 
 extern "C" int mwb_stack_update(mwb_handle *h, int after_reset, void *stream) {
     if (!h || !h->stack) return set_err(MWB_ESTATE, "mwb_stack_update: call mwb_stack_enable first");
     USE_DEVICE(h->cfg.device);
+    if (h->stack_fused) return MWB_OK;   // the step / reset that produced the observation has already put it into the window
     if (h->stack_planes) {   // sliding window: the host owns the window position (mwb_stack_window)
         const int C = h->stack_n * 3, from = h->stack_pos;
         int mode = 0, pos = from + 3;

@@ -130,6 +130,8 @@ struct MwbDev {
     float *rooms;           // [N][R_max][room_words]
     double *segs;           // [S_max][4][N]
     float *frame;           // [N][frame_words]
+    void *stk;              // fused frame stack (MWB_STACK_FUSED) or null: base of [N][stk_K][W][H] planes, f32 (stk_float) or u8;
+    int stk_float, stk_C, stk_K, stk_pos;   // the window the frame being rendered belongs to starts at plane stk_pos
     double *world_ext;      // [N][4] min_x max_x min_z max_z of the floorplan (miniworld.py:576-579), written by reset_kernel
     const uint32_t *texels;
     const MwbTexDesc *tex_desc;   // [MWB_MAX_TEX] in device memory

@@ -2308,6 +2308,38 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             const int xa = part ? midx : 0, xb = part ? W : midx;
             for (int q = 0; q < 3; q++) copy_frame_range<THREADS>(dst, fb, (q * W + xa) * H, (q * W + xb) * H, tid);
         }
+        // Fused frame stack (mwb_stack_enable with MWB_STACK_FUSED; CWH frames): the new frame also goes straight into the
+        // newest three planes of the env's sliding window - u8 -> f32 on the way out of LDS - and an env that was
+        // regenerated in this pass gets its history planes zeroed (VecPyTorchFrameStack, envs.py:149-156): no stack pass.
+        if (d.stk && d.layout == MWB_LAYOUT_CWH) {
+            const int plane = W * H, C = d.stk_C;
+            const size_t env_base = ((size_t)e * d.stk_K + d.stk_pos) * plane;   // first element of the window
+            int xa = 0, xb = W;
+            if (part >= 0) { const int midx = half_strips * (TILE_CX - 1) < W ? half_strips * (TILE_CX - 1) : W; xa = part ? midx : 0; xb = part ? W : midx; }
+            if (LOOPED || d.reset_set[e]) {   // regenerated env (side-stream list, or a pass that regenerates in place; never the bulk pass)
+                const int n4 = (C - 3) * plane / 4;   // a half-frame workgroup zeroes half of the history
+                const int i0 = part < 0 ? 0 : (part ? n4 / 2 : 0), i1 = part < 0 ? n4 : (part ? n4 : n4 / 2);
+                if (d.stk_float) { float4 *z = (float4 *)((float *)d.stk + env_base); for (int i = i0 + tid; i < i1; i += THREADS) z[i] = make_float4(0, 0, 0, 0); }
+                else { uint32_t *z = (uint32_t *)((uint8_t *)d.stk + env_base); for (int i = i0 + tid; i < i1; i += THREADS) z[i] = 0u; }
+            }
+            for (int q = 0; q < 3; q++) {
+                const int b0 = (q * W + xa) * H, b1 = (q * W + xb) * H;   // byte range of this channel plane's columns in fb (multiples of 4: W*H % 4 == 0 checked, H*15 ... see host check)
+                const size_t dst0 = env_base + (size_t)(C - 3) * plane;
+                if (d.stk_float) {
+                    float *o = (float *)d.stk + dst0;
+                    if (((b0 | b1) & 3) == 0) {
+                        for (int i = b0 / 4 + tid; i < b1 / 4; i += THREADS) {
+                            const uint32_t p = ((const uint32_t *)fb)[i];
+                            ((float4 *)o)[i] = make_float4((float)(p & 255u), (float)((p >> 8) & 255u), (float)((p >> 16) & 255u), (float)(p >> 24));
+                        }
+                    } else {
+                        for (int i = b0 + tid; i < b1; i += THREADS) o[i] = (float)fb[i];
+                    }
+                } else {
+                    copy_frame_range<THREADS>((uint8_t *)d.stk + dst0, fb, b0, b1, tid);
+                }
+            }
+        }
     }
 }
 
@@ -2392,9 +2424,13 @@ __global__ void __launch_bounds__(256) stack_slide_kernel(MwbDev d, V *__restric
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= plane4) return;
     V *base = stack + (size_t)e * K * plane4;
-    const bool clear = mode == 2 || d.done[e];
+    const bool clear = mode == 2 || (mode < 3 && d.done[e]);
     V zero;
     memset(&zero, 0, sizeof(V));
+    if (mode == 3) {   // fused stack: the history back to the front, nothing else (the render kernels write frames and zero finished envs)
+        for (int c = 0; c < C - 3; c++) base[(size_t)c * plane4 + j] = base[(size_t)(from + 3 + c) * plane4 + j];
+        return;
+    }
     if (mode == 1 && !clear) {
         for (int c = 0; c < C - 3; c++) base[(size_t)c * plane4 + j] = base[(size_t)(from + 3 + c) * plane4 + j];
     } else if (clear) {

@@ -137,9 +137,11 @@ class MiniWorldVecEnv(VecEnv):
         if self.nstack:
             assert transpose, "frame stacking follows VecPyTorchFrameStack: channel-first observations"
             shape = (shape[0] * self.nstack,) + shape[1:]
-            # fused in the library: zero-on-done + append + uint8->float in one HBM pass over a sliding window (the new
-            # frame is all a step writes; a replayed graph would freeze the window position: the shifting stack there)
-            self.stackedobs = b.stack_enable(self.nstack, "float32" if to_float else "uint8", sliding=not graph)
+            # fused in the library: the render kernels write each new frame (uint8 -> float on the way out of LDS) into a
+            # sliding window of planes and zero the history of the envs they regenerate: no stack pass at all (a replayed
+            # graph would freeze the host-side window position: the shifting stack there)
+            fuse = not graph and (to_float or (b.W * b.H) % 16 == 0)
+            self.stackedobs = b.stack_enable(self.nstack, "float32" if to_float else "uint8", sliding=not graph, fused=fuse)
         VecEnv.__init__(self, num_envs, Box(0, 255, shape, np.float32 if to_float else np.uint8), Discrete(b.n_actions))
         self.device = b.device
         self.feature_info = feature_info

@@ -195,6 +195,11 @@ int mwb_stack_enable(mwb_handle *h, int nstack, int dtype);
  * of mwb_stack_update must not be replayed with this flag. */
 #define MWB_STACK_SLIDING 16
 #define MWB_STACK_SLACK_FRAMES 8
+/* dtype | MWB_STACK_FUSED (implies the sliding window): mwb_reset / mwb_step move the window themselves and the render
+ * kernels write each new frame straight into its newest three planes (u8 -> f32 on the way out of LDS), zeroing the history of
+ * the envs they regenerate: mwb_stack_update becomes a no-op and the observation never takes a second trip through HBM.
+ * Read the window with mwb_stack_window after every mwb_reset / mwb_step. */
+#define MWB_STACK_FUSED 32
 int mwb_stack_window(mwb_handle *h, int *first_plane, int *planes_per_env);
 int mwb_stack_update(mwb_handle *h, int after_reset, void *stream);
 

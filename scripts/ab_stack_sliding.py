@@ -1,4 +1,6 @@
-import sys; sys.path.insert(0,'/root/repo')
+"""Frame stack three ways: fused into the render kernels, sliding window with its own pass, shifting stack.  Equality of the
+values (incl. window wraps and episode ends), then the time of a whole step.  usage: ab_stack_sliding.py"""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, time
 from gym_miniworld_amd.batch import BatchedMiniWorld
 # uint8 + float32, sliding vs shifting equality incl. wraps and dones
@@ -6,7 +8,8 @@ for dt in ("uint8","float32"):
     a=BatchedMiniWorld("MiniWorld-OneRoomS6-v0", num_envs=64, seed=2, layout="CWH")
     b=BatchedMiniWorld("MiniWorld-OneRoomS6-v0", num_envs=64, seed=2, layout="CWH")
     a.reset(); b.reset()
-    a.stack_enable(4, dt, sliding=True); b.stack_enable(4, dt, sliding=False)
+    a.stack_enable(4, dt, fused=True); b.stack_enable(4, dt, sliding=False)
+    a.reset(); b.reset()   # the fused stack is written by reset / step themselves
     sa=a.stack_update(True); sb=b.stack_update(True)
     assert torch.equal(sa, sb)
     g=torch.Generator().manual_seed(0); dones=0
@@ -18,14 +21,15 @@ for dt in ("uint8","float32"):
         dones+=int(a.done.sum())
     print(dt,'ok dones',dones, sa.shape, sa.stride())
     a.close(); b.close()
-# timing
-for sliding in (True, False):
+# timing: a whole step incl. the stack, three ways
+from bench import make_actions
+for name, kw in (("fused", dict(fused=True)), ("sliding", dict(sliding=True)), ("shifting", dict(sliding=False))):
     e=BatchedMiniWorld("MiniWorld-Maze-v0", num_envs=8192, seed=1, layout="CWH")
-    e.reset(); e.stack_enable(4,"float32",sliding=sliding); e.stack_update(True)
-    torch.cuda.synchronize(); 
-    ev0=torch.cuda.Event(enable_timing=True); ev1=torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for t in range(90): e.stack_update()
-    ev1.record(); torch.cuda.synchronize()
-    print('sliding',sliding,'stack pass %.4f ms avg' % (ev0.elapsed_time(ev1)/90))
+    e.stack_enable(4,"float32",**kw); e.reset(); e.stack_update(True)
+    acts=make_actions(140, 0, 8192, e.device)
+    for t in range(40): e.step(acts[t]); e.stack_update()
+    torch.cuda.synchronize(); t0=time.perf_counter()
+    for t in range(40,140): e.step(acts[t]); e.stack_update()
+    torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/100
+    print(name,'step + stack %.4f ms  %.2f M env-steps/s' % (dt*1e3, 8192/dt/1e6))
     e.close()
