@@ -56,7 +56,7 @@ EXPORTS = [
     "mwb_create", "mwb_destroy", "mwb_last_error", "mwb_abi_version", "mwb_set_texture", "mwb_seed", "mwb_reset",
     "mwb_step", "mwb_render", "mwb_get_outputs", "mwb_get_state", "mwb_set_agent", "mwb_intersect",
     "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read", "mwb_stack_enable", "mwb_stack_update", "mwb_stack_window", "mwb_check", "mwb_seed_key",
-    "mwb_set_task_state", "mwb_set_domain_rand", "mwb_num_textures", "mwb_debug_wg_times", "mwb_set_state", "mwb_num_boxes", "mwb_room_words", "mwb_render_top_view", "mwb_visible_ents",
+    "mwb_set_task_state", "mwb_set_domain_rand", "mwb_num_textures", "mwb_debug_wg_times", "mwb_set_state", "mwb_num_boxes", "mwb_room_words", "mwb_step_i64", "mwb_render_top_view", "mwb_visible_ents",
 ]
 
 _lib = None
@@ -86,6 +86,7 @@ def load():
     L.mwb_seed.argtypes = [vp, vp]
     L.mwb_reset.argtypes = [vp, vp, vp]
     L.mwb_step.argtypes = [vp, vp, vp, vp]
+    L.mwb_step_i64.argtypes = [vp, vp, vp, vp]
     L.mwb_render.argtypes = [vp, vp]
     L.mwb_render_top_view.argtypes = [vp, vp, i32, i32, vp]
     L.mwb_visible_ents.argtypes = [vp, vp, vp]

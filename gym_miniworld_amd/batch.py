@@ -215,13 +215,15 @@ class BatchedMiniWorld:
         """actions: int tensor [N] (any int dtype / device); returns views (obs, reward, done) of the
         library-owned buffers, valid until the next call."""
         torch = self.torch
-        a = torch.as_tensor(actions).to(device=self.device, dtype=torch.int32).reshape(-1).contiguous()
+        a = torch.as_tensor(actions)
+        i64 = a.dtype == torch.int64 and a.device == self.device   # the policy's LongTensor: read in place (mwb_step_i64)
+        a = (a if i64 else a.to(device=self.device, dtype=torch.int32)).reshape(-1).contiguous()
         assert a.numel() == self.num_envs
         m = None
         if skip_mask is not None:
             skip_mask = torch.as_tensor(skip_mask).to(device=self.device, dtype=torch.uint8).contiguous()
             m = ctypes.c_void_p(skip_mask.data_ptr())
-        _lib.check(self.L.mwb_step(self.h, ctypes.c_void_p(a.data_ptr()), m, self._stream()))
+        _lib.check((self.L.mwb_step_i64 if i64 else self.L.mwb_step)(self.h, ctypes.c_void_p(a.data_ptr()), m, self._stream()))
         self._keep = (a, skip_mask)   # keep inputs alive until the async kernels have consumed them
         return self.obs, self.reward, self.done
 

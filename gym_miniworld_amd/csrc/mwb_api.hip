@@ -519,8 +519,18 @@ extern "C" int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream) {
     return check_launch("order_kernel");
 }
 
+static int step_impl(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask_dev, void *stream);
 extern "C" int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask_dev, void *stream) {
     if (!h) return set_err(MWB_EINVAL, "null handle");
+    h->dev.act_stride = 1;
+    return step_impl(h, actions_dev, skip_mask_dev, stream);
+}
+extern "C" int mwb_step_i64(mwb_handle *h, const int64_t *actions_dev, const uint8_t *skip_mask_dev, void *stream) {
+    if (!h) return set_err(MWB_EINVAL, "null handle");
+    h->dev.act_stride = 2;   // little-endian: the low word of each int64 (actions are small non-negative integers)
+    return step_impl(h, (const int32_t *)actions_dev, skip_mask_dev, stream);
+}
+static int step_impl(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask_dev, void *stream) {
     USE_DEVICE(h->cfg.device);
     int rc = ensure_ready(h); if (rc) return rc;
     if (!actions_dev) return set_err(MWB_EINVAL, "mwb_step: null actions");

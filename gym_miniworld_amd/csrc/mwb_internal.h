@@ -102,6 +102,7 @@ struct MwbDev {
     int frame_words;   // MWB_FRAME_WORDS_FOR(n_boxes)
     int n_tex;         // leading texture slots the task can draw (7, or MWB_NUM_TEXTURES for the sim-to-real rinks)
     int split_envs;    // the last split_envs envs of a bulk render launch are rendered by two half-frame workgroups each
+    int act_stride;    // int32 words between consecutive envs' actions: 1, or 2 when the caller hands over int64 actions
     int poly;          // rooms are general convex polygons (YMaze): polygon room table, POLY render kernels
     int room_words;    // f32 words per room of d.rooms: MWB_ROOM_WORDS or MWB_POLY_ROOM_WORDS
     int no_ceiling;    // the task's rooms have no ceiling (sim-to-real rinks): selects the NOCEIL render kernels

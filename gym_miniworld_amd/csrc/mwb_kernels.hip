@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
             d.feature[e * 2] = 0.0f; d.feature[e * 2 + 1] = 0.0f;   // info = {"feature": [0, 0]}
         }
         if (live) {
-            a = actions[e];
+            a = actions[(size_t)e * d.act_stride];   // stride 2: the low words of an int64 action tensor (mwb_step_i64)
             ax = d.agent_x[e]; az = d.agent_z[e]; adir = d.agent_dir[e];
 #pragma unroll
             for (int b = 0; b < NBX; b++)

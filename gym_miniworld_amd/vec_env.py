@@ -191,7 +191,11 @@ class MiniWorldVecEnv(VecEnv):
         else:
             a = torch.as_tensor(np.asarray(actions).reshape(-1))
         assert a.numel() == self.num_envs
-        self._a_static.copy_(a, non_blocking=True)   # any int dtype / device -> the int32 device buffer the kernels read
+        # the policy's LongTensor on this device is read by the step kernel in place (mwb_step_i64): no conversion pass;
+        # anything else (and the captured-graph path, whose kernels read one fixed buffer) goes through the int32 buffer
+        direct = (not self._use_graph) and a.dtype == torch.int64 and a.device == self.device and a.is_contiguous()
+        if not direct:
+            self._a_static.copy_(a, non_blocking=True)
         skip = None
         self._skip_host = None
         if isinstance(mask, np.ndarray):   # subproc_vec_env.py:59: only ndarray masks are honoured
@@ -204,7 +208,7 @@ class MiniWorldVecEnv(VecEnv):
             self._graph.replay()
             self._obs_now = self._obs_static
         else:
-            self._obs_now = self._device_step(self._a_static, skip)
+            self._obs_now = self._device_step(a if direct else self._a_static, skip)
             self._eager_steps += 1
         self._pending = True
 

@@ -176,6 +176,9 @@ int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream);
  * move_back, pickup, drop, toggle, done - every task executes all of them as the base class does); skip_mask: device u8[num_envs] or NULL (mask[i]!=0 -> env i is not
  * stepped, reward -99, done 0, observation re-rendered). */
 int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask_dev, void *stream);
+/* the same with the LongTensor the reference's policy produces (VecPyTorch.step_async, envs.py:121-125): int64 actions [N] in
+ * device memory are read in place (no conversion pass) */
+int mwb_step_i64(mwb_handle *h, const int64_t *actions_dev, const uint8_t *skip_mask_dev, void *stream);
 /* replaces: MiniWorldEnv.render_obs / render_depth (miniworld.py:1160-1220) for the whole batch */
 int mwb_render(mwb_handle *h, void *stream);
 int mwb_get_outputs(mwb_handle *h, mwb_outputs *out);
