@@ -59,7 +59,7 @@ struct mwb_handle {
     hipEvent_t *ev;   // the current pass' events: 0-4 on the caller's stream, 5-6 around reset_kernel
     // mwb_step overlaps world generation of the finished envs with the bulk render on a side stream
     bool overlap_reset;
-    void *pack;          // reward64 | goal_pos | reward | feature | ep_steps | done in one allocation
+    void *pack;          // done | reward | feature | goal_pos | ep_steps | reward64 in one allocation
     size_t pack_bytes;
     void *stack;
     int stack_n, stack_dtype;
@@ -272,8 +272,10 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     if (d.want_depth) { A(d.depth, N * d.W * d.H); }
     {   // the small per-step outputs share one allocation (one D2H copy for a host-side consumer); 16-byte aligned parts
         auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
-        const size_t o_r64 = 0, o_goal = o_r64 + up(N * 8), o_rew = o_goal + up(N * 24), o_feat = o_rew + up(N * 4),
-                     o_eps = o_feat + up(N * 8), o_done = o_eps + up(N * 4), total = o_done + up(N);
+        // ordered by how often a host-side consumer needs them, so that it can copy a PREFIX: done | reward (what every step of a
+        // VecEnv returns) | feature | goal_pos (the T-/Y-maze infos) | ep_steps | reward64
+        const size_t o_done = 0, o_rew = o_done + up(N), o_feat = o_rew + up(N * 4), o_goal = o_feat + up(N * 8),
+                     o_eps = o_goal + up(N * 24), o_r64 = o_eps + up(N * 4), total = o_r64 + up(N * 8);
         uint8_t *pack = nullptr;
         A(pack, total);
         if (rc == MWB_OK) {

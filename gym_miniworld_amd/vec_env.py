@@ -149,7 +149,15 @@ class MiniWorldVecEnv(VecEnv):
         self._pending = False
         # host mirrors of the small per-step outputs: pinned, filled by asynchronous copies, ONE wait per step
         pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)   # noqa: E731
-        self._h_pack = pin(tuple(b.pack.shape), torch.uint8)   # reward64 | goal_pos | reward | feature | ep_steps | done
+        # done | reward | feature | goal_pos | ep_steps | reward64 in one allocation: only the prefix this view returns is copied
+        off_ = b.pack_offsets
+        need = off_["feature"] if torch_api else int(b.pack.numel())   # done + float32 reward ...
+        if torch_api and b.has_features:
+            need = off_["goal_pos"]
+        if torch_api and b.has_goal_pos:
+            need = off_["ep_steps"]
+        self._pack_need = int(need)
+        self._h_pack = pin((self._pack_need,), torch.uint8)
         hp, off, n = self._h_pack.numpy(), b.pack_offsets, num_envs
         part = lambda key, dt, cnt: np.frombuffer(hp, dtype=dt, count=cnt, offset=off[key])   # noqa: E731
         self._h_done = part("done", np.uint8, n)
@@ -181,7 +189,7 @@ class MiniWorldVecEnv(VecEnv):
         b = self.batch
         b.step(a, skip_mask=skip)
         obs = self._obs_out(done=b.done)
-        self._h_pack.copy_(b.pack, non_blocking=True)   # one copy: all the small outputs share an allocation
+        self._h_pack.copy_(b.pack[:self._pack_need], non_blocking=True)   # one copy: the small outputs share an allocation
         return obs
 
     def step_async(self, actions, mask=None):

@@ -107,7 +107,8 @@ typedef struct mwb_outputs {
     double *goal_pos;   /* f64 [N][3] info['goal_pos'] of the transition, T-maze family (tmaze.py:66,206); else zeros */
     /* reward64, goal_pos, reward, feature, ep_steps and done live in ONE allocation [pack, pack + pack_bytes) so that a
      * host-side consumer (the VecEnv contract returns numpy dones, CPU rewards and info dicts every step,
-     * vec_env/subproc_vec_env.py:69-75) fetches them with a single device-to-host copy; each pointer above = pack + offset */
+     * vec_env/subproc_vec_env.py:69-75) fetches them with a single device-to-host copy; each pointer above = pack + offset.  Order inside the allocation: done,
+     * reward, feature, goal_pos, ep_steps, reward64 - a consumer that needs only the first few copies that prefix */
     void *pack;
     size_t pack_bytes;
 } mwb_outputs;
