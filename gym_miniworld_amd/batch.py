@@ -227,6 +227,14 @@ class BatchedMiniWorld:
         self._keep = (a, skip_mask)   # keep inputs alive until the async kernels have consumed them
         return self.obs, self.reward, self.done
 
+    def step_longtensor(self, actions):
+        """step() for the one shape a trainer's loop produces every time - a contiguous int64 tensor [N] on this device - without
+        the generic conversions (the host time before the first kernel launch is on the critical path of a VecEnv step)"""
+        rc = self.L.mwb_step_i64(self.h, actions.data_ptr(), None, self._stream())
+        if rc:
+            _lib.check(rc)
+        self._keep = (actions, None)
+
     def render(self):
         _lib.check(self.L.mwb_render(self.h, self._stream()))
         return self.obs

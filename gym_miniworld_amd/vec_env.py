@@ -187,7 +187,10 @@ class MiniWorldVecEnv(VecEnv):
         """everything of a step that runs on the device: the stepper + renderer, the learner-side layout pass and the
         asynchronous copies of the small outputs into the pinned host mirrors"""
         b = self.batch
-        b.step(a, skip_mask=skip)
+        if skip is None and a.dtype == self.torch.int64:
+            b.step_longtensor(a)
+        else:
+            b.step(a, skip_mask=skip)
         obs = self._obs_out(done=b.done)
         self._h_pack.copy_(b.pack[:self._pack_need], non_blocking=True)   # one copy: the small outputs share an allocation
         return obs
