@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The step at which every env times out together (fixed-length episodes: Maze's 1536-step limit under a random policy)
-regenerates the whole batch on the side chain.  Times that step beside an ordinary one.  usage: mass_timeout.py [n]"""
+regenerates the whole batch on the side chain.  Times that step beside an ordinary one.  usage: mass_timeout.py [env_id] [n]"""
 import os
 import sys
 import time
@@ -11,8 +11,9 @@ import torch  # noqa: E402
 from bench import make_actions  # noqa: E402
 from gym_miniworld_amd.batch import BatchedMiniWorld  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-env = BatchedMiniWorld("MiniWorld-Maze-v0", num_envs=n, seed=1, max_episode_steps=30)
+env_id = sys.argv[1] if len(sys.argv) > 1 else "MiniWorld-Maze-v0"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+env = BatchedMiniWorld(env_id, num_envs=n, seed=1, max_episode_steps=30)
 acts = make_actions(100, 0, n, env.device)
 env.reset()
 times = []
@@ -24,4 +25,4 @@ for t in range(95):
     times.append(((time.perf_counter() - t0) * 1e3, int(env.done.sum())))
 ordinary = [x for x, dn in times[5:] if dn < n // 100]
 mass = [(x, dn) for x, dn in times if dn > n // 2]
-print("ordinary step %.3f ms (synchronous);  mass-timeout steps: %s" % (sum(ordinary) / len(ordinary), ["%.2f ms / %d envs" % m for m in mass]))
+print(env_id, "ordinary step %.3f ms (synchronous);  mass-timeout steps: %s" % (sum(ordinary) / len(ordinary), ["%.2f ms / %d envs" % m for m in mass]))
