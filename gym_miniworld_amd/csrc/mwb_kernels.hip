@@ -2533,7 +2533,7 @@ int mwb_prepare_kernels(const MwbDev &d) {
     return 0;
 }
 
-#define LIST_GRID 512   // blocks that walk the compact list of regenerated envs: a handful per step - but ALL of them in the step at
+#define LIST_GRID 1280   // blocks that walk the compact list of regenerated envs: a handful per step - but ALL of them in the step at
                         // which a whole batch hits the episode limit together (a block with nothing to do exits at once)
 void mwb_launch_reset(const MwbDev &d, int max_blocks, hipStream_t s) {
     hipLaunchKernelGGL(reset_kernel, dim3(d.N < max_blocks ? d.N : max_blocks), dim3(WAVE), mwb_reset_lds_bytes(d), s, d);
