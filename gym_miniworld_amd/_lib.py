@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("MWB_LIB") or os.path.join(HERE, "libmwbatch.so")   # 
 NPARAM = 13
 STACK_SLIDING = 16   # MWB_STACK_SLIDING
 STACK_FUSED = 32     # MWB_STACK_FUSED
+STACK_SLACK_FRAMES = 8   # MWB_STACK_SLACK_FRAMES
 ROOM_WORDS = 24
 POLY_ROOM_WORDS = 52   # MWB_TASK_YMAZE (include/miniworld_batch.h)
 ABI_VERSION = 4

@@ -48,6 +48,7 @@ struct mwb_handle {
     uint32_t *texels_dev;
     MwbTexDesc *tex_desc_dev;
     bool seeded, textures_dirty, have_textures;
+    bool have_obs;   // some pass has rendered an observation since creation
     int *scratch_int_dev;
     // timing
     // timing: five events per pipeline pass, drawn from a pool and only read back in
@@ -313,7 +314,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     if (hipMemset(d.carrying, 0xFF, N * sizeof(int32_t)) != hipSuccess) { mwb_destroy(h); return set_err(MWB_EHIP, "mwb_create: hipMemset failed"); }   // -1: nothing carried
     d.tex_desc = h->tex_desc_dev;
     h->texels_dev = nullptr; d.texels = nullptr;
-    h->seeded = false; h->textures_dirty = false; h->have_textures = false;
+    h->seeded = false; h->textures_dirty = false; h->have_textures = false; h->have_obs = false;
     h->timing = false; h->timing_now = false; h->timing_period = 1; h->timing_tick = 0; h->ev_used = 0; h->ev = nullptr;
     { const char *no = getenv("MWB_NO_OVERLAP"); h->overlap_reset = !(no && atoi(no)); }
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
@@ -494,9 +495,10 @@ static int stack_advance(mwb_handle *h, int after_reset, hipStream_t s) {
     return MWB_OK;
 }
 
-static int ensure_ready(mwb_handle *h) {   // the caller holds the device guard
+static int ensure_ready(mwb_handle *h, bool renders = true) {   // the caller holds the device guard
     if (!h->seeded) return set_err(MWB_ESTATE, "mwb_seed must be called before reset/step (the reference seeds from entropy; this library refuses to)");
     if (h->textures_dirty || !h->have_textures) { int rc = upload_textures(h); if (rc) return rc; }
+    if (renders) h->have_obs = true;
     return MWB_OK;
 }
 
@@ -586,7 +588,7 @@ extern "C" int mwb_render_top_view(mwb_handle *h, uint8_t *out_dev, int width, i
     if (!h || !out_dev) return set_err(MWB_EINVAL, "mwb_render_top_view: null argument");
     if (width < 1 || height < 1 || width > 4096 || height > 4096) return set_err(MWB_EINVAL, "mwb_render_top_view: bad frame size");
     USE_DEVICE(h->cfg.device);
-    int rc = ensure_ready(h); if (rc) return rc;
+    int rc = ensure_ready(h, false); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     mwb_launch_prep(h->dev, 0, s);   // the state may have been set from outside since the last render
     rc = check_launch("prep_kernel"); if (rc) return rc;
@@ -597,7 +599,7 @@ extern "C" int mwb_render_top_view(mwb_handle *h, uint8_t *out_dev, int width, i
 extern "C" int mwb_visible_ents(mwb_handle *h, uint32_t *mask_dev, void *stream) {
     if (!h || !mask_dev) return set_err(MWB_EINVAL, "mwb_visible_ents: null argument");
     USE_DEVICE(h->cfg.device);
-    int rc = ensure_ready(h); if (rc) return rc;
+    int rc = ensure_ready(h, false); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     mwb_launch_prep(h->dev, 0, s);   // the state may have been set from outside since the last render
     rc = check_launch("prep_kernel"); if (rc) return rc;
@@ -639,6 +641,9 @@ extern "C" int mwb_stack_enable(mwb_handle *h, int nstack, int dtype) {
     if (d.layout != MWB_LAYOUT_CWH) return set_err(MWB_EINVAL, "mwb_stack_enable: the frame stack is channel-first, create the handle with MWB_LAYOUT_CWH");
     if ((d.W * d.H) % 4) return set_err(MWB_EINVAL, "mwb_stack_enable: W*H must be a multiple of 4");
     if (h->stack) return set_err(MWB_ESTATE, "mwb_stack_enable: already enabled");
+    // a fused window is filled by the render kernels as they produce frames: enabled after the first observation it would
+    // lack the current frame until the next pass (the non-fused forms rebuild theirs from the observation buffer)
+    if (fused && h->have_obs) return set_err(MWB_ESTATE, "mwb_stack_enable: MWB_STACK_FUSED must be enabled before the first mwb_reset / mwb_step / mwb_render");
     if (fused && dtype == 0 && (d.W * d.H) % 16) return set_err(MWB_EINVAL, "mwb_stack_enable: a fused uint8 stack needs W*H to be a multiple of 16");
     USE_DEVICE(h->cfg.device);
     const int planes = sliding ? nstack * 3 + 3 * MWB_STACK_SLACK_FRAMES : nstack * 3;
@@ -784,6 +789,17 @@ extern "C" int mwb_set_state(mwb_handle *h, int first, int count, const mwb_stat
     if (in->rng_state)
         for (int i = 0; i < count; i++)
             if (in->rng_state[(size_t)i * MWB_MT_WORDS + 624] > 624u) return set_err(MWB_EINVAL, "mwb_set_state: MT19937 position must be 0..624");
+    {   // poses, sizes and camera parameters go straight into the step and render kernels: no NaN / inf, no empty boxes
+        auto finite = [](const double *v, size_t n) { if (v) for (size_t i = 0; i < n; i++) if (!std::isfinite(v[i])) return false; return true; };
+        const size_t c = (size_t)count, B_ = (size_t)h->dev.n_boxes;
+        if (!finite(in->agent_pos, c * 3) || !finite(in->agent_dir, c) || !finite(in->box_pos, c * B_ * 3) || !finite(in->box_dir, c * B_) ||
+            !finite(in->box_color, c * B_ * 3) || !finite(in->box_size, c * B_) || !finite(in->cam, c * 4) || !finite(in->sky_color, c * 3) ||
+            !finite(in->light_pos, c * 3) || !finite(in->light_color, c * 3) || !finite(in->light_ambient, c * 3) || !finite(in->goal_dist, c))
+            return set_err(MWB_EINVAL, "mwb_set_state: non-finite value");
+        if (in->box_size)
+            for (size_t i = 0; i < c * B_; i++)
+                if (!(in->box_size[i] > 0)) return set_err(MWB_EINVAL, "mwb_set_state: box_size must be > 0");
+    }
     USE_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
     const size_t N = (size_t)d.N;

@@ -155,6 +155,9 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
         }
         if (live) {
             a = actions[(size_t)e * d.act_stride];   // stride 2: the low words of an int64 action tensor (mwb_step_i64)
+            // an int64 value outside int32 is no action of the enum: the reference's `if action == ...` chain ignores it
+            // (miniworld.py:670-695), so must this - not alias 2^32 + 2 to move_forward
+            if (d.act_stride == 2 && actions[(size_t)e * 2 + 1] != (a >> 31)) a = -1;
             ax = d.agent_x[e]; az = d.agent_z[e]; adir = d.agent_dir[e];
 #pragma unroll
             for (int b = 0; b < NBX; b++)
@@ -1398,7 +1401,7 @@ __device__ __forceinline__ uint32_t trace_rooms_poly(const float *__restrict__ r
         ts = INFINITY; s = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float4 a = *(const float4 *)(r + PW_EDGE0 + PW_EDGE_WORDS * k);       // p.x p.z dir.x dir.z
+            const float2 a = *(const float2 *)(r + PW_EDGE0 + PW_EDGE_WORDS * k);       // p.x p.z (the direction is read for the exit edge only)
             const float2 n = *(const float2 *)(r + PW_EDGE0 + PW_EDGE_WORDS * k + 4);   // n.x n.z
             const float den = fmaf(n.y, dv[2], n.x * dv[0]);
             const float num = fmaf(n.y, a.y - o[2], n.x * (a.x - o[0]));
@@ -1603,7 +1606,7 @@ struct RenderCtx {
     float *depth;   // this env's depth map or null
     Cam cam;
     int n_rooms, cam_room, W, H, layout;
-    float cull_cc[NBOX], cull_oc[NBOX][3], zA, zB;
+    float cull_cc[1], cull_oc[1][3], zA, zB;   // the box's cull constants (NBOX == 1 only: scalar registers)
     bool boxes_in_view;   // workgroup-uniform (scalar): false = no ray of this frame can touch a box
     // per work item (15 x 15 pixels), which boxes can touch any of its rays at all (frame-level pre-test pass; null = unknown)
     const uint4 *item_res;
@@ -1654,18 +1657,6 @@ struct RenderCtx {
         const uint32_t tex_id = (wall ? texw : floor_ ? (texw >> 8) : (texw >> 16)) & 255u;
         const TexLds &T = tex[tex_id];
         const float sc_s = T.sc_s, sc_t = T.sc_t;
-        float lit[3];
-        {   // flat face with the edge's inward normal (fixed-function lighting, miniworld.py:1026-1045)
-            const float *Ld = fc + FC_LIGHT_DIR, *amb = fc + FC_LIGHT_AMB, *dif = fc + FC_LIGHT_DIF;
-            float ndl = n.x * Ld[0] + 0.0f * Ld[1] + n.y * Ld[2];
-            ndl = ndl < 0.0f ? 0.0f : ndl;
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const float v = (0.2f + amb[q]) + ndl * dif[q];
-                const float wv = v > 1.0f ? 1.0f : v;
-                lit[q] = wall ? wv : (floor_ ? fc[FC_LIT_FLOOR + q] : fc[FC_LIT_CEIL + q]);
-            }
-        }
         const float plane = floor_ ? 0.0f : height;
         auto texcoord = [&](const float *dv, float &s, float &t) {
             if (wall) {
@@ -1693,8 +1684,20 @@ struct RenderCtx {
         }
         float texel[3];
         sample_texture(texels, T, s0, t0, s1, t1, s2, t2, valid, texel);
+        {   // flat face with the edge's inward normal (fixed-function lighting, miniworld.py:1026-1045); evaluated after the
+            // texel fetch, the normal read again from LDS, so that no lit colour is carried through the fetch (registers)
+            const float2 nn = *(const float2 *)(ed + 4);
+            const float *Ld = fc + FC_LIGHT_DIR, *amb = fc + FC_LIGHT_AMB, *dif = fc + FC_LIGHT_DIF;
+            float ndl = nn.x * Ld[0] + 0.0f * Ld[1] + nn.y * Ld[2];
+            ndl = ndl < 0.0f ? 0.0f : ndl;
 #pragma unroll
-        for (int q = 0; q < 3; q++) col[q] = lit[q] * (texel[q] * (1.0f / 255.0f));
+            for (int q = 0; q < 3; q++) {
+                const float v = (0.2f + amb[q]) + ndl * dif[q];
+                const float wv = v > 1.0f ? 1.0f : v;
+                const float lit = wall ? wv : (floor_ ? fc[FC_LIT_FLOOR + q] : fc[FC_LIT_CEIL + q]);
+                col[q] = lit * (texel[q] * (1.0f / 255.0f));
+            }
+        }
     }
 
     // INTERIOR: the caller guarantees a room surface (floor / ceiling / wall) whose plane the pixel's centre ray meets
@@ -2008,13 +2011,11 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     }
     const float zn = 0.04f, zf = 100.0f;   // gluPerspective near / far, miniworld.py:1186-1187
     ctx.zA = (zf + zn) / (zf - zn); ctx.zB = (2.0f * zf * zn) / (zf - zn);
-    float cull_cc_px[NBOX];   // sphere inflated by a pixel footprint (prep_kernel)
-#pragma unroll
-    for (int bi = 0; bi < NBOX; bi++) {
-        const float *fb_ = fc + bi * FC_BOX_STRIDE;
-        ctx.cull_cc[bi] = uni(fb_[FC_CULL_CC]);
-        ctx.cull_oc[bi][0] = uni(fb_[FC_CULL_OC]); ctx.cull_oc[bi][1] = uni(fb_[FC_CULL_OC + 1]); ctx.cull_oc[bi][2] = uni(fb_[FC_CULL_OC + 2]);
-        cull_cc_px[bi] = uni(fb_[FC_CULL_CC_PIXEL]);
+    float cull_cc_px[1] = {0.0f};   // sphere inflated by a pixel footprint (prep_kernel)
+    if constexpr (NBOX == 1) {   // one box: its cull constants live in scalar registers; more boxes: read from LDS where used
+        ctx.cull_cc[0] = uni(fc[FC_CULL_CC]);
+        ctx.cull_oc[0][0] = uni(fc[FC_CULL_OC]); ctx.cull_oc[0][1] = uni(fc[FC_CULL_OC + 1]); ctx.cull_oc[0][2] = uni(fc[FC_CULL_OC + 2]);
+        cull_cc_px[0] = uni(fc[FC_CULL_CC_PIXEL]);
     }
     (void)cull_cc_px;
     ctx.boxes_in_view = __builtin_amdgcn_readfirstlane(__float_as_int(fc[FC_BOX_IN_VIEW])) != 0;
@@ -2029,7 +2030,8 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     // unless the box may intrude, the pixel is shaded once ("interior").  All other pixels are resolved
     // by the full 8-sample path.  Both kinds go through per-wave LDS queues and are processed 64 at a
     // time, so that the shading and the 8-sample path always run with dense lanes.
-    const int wave = tid / WAVE, lane = tid % WAVE, n_waves = THREADS / WAVE;
+    // the wave index is wave-uniform: in a scalar register, so are the queue addresses derived from it (VGPRs are the budget)
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE), lane = tid % WAVE, n_waves = THREADS / WAVE;
     // queued pixels are packed as (py << wshift) | px (host checks that it fits 16 bits): no integer division
     const int wshift = 32 - __builtin_clz((unsigned)(W > 1 ? W - 1 : 1));
     const int wmask = (1 << wshift) - 1;
@@ -2084,10 +2086,19 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         make_ray(cam, (float)px + 0.5f, (float)(H - 1 - py) + 0.5f, dc);
         const float dd = dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2];
         bool touch = false;
-#pragma unroll
-        for (int bi = 0; bi < NBOX; bi++) {
-            const float b = dc[0] * ctx.cull_oc[bi][0] + dc[1] * ctx.cull_oc[bi][1] + dc[2] * ctx.cull_oc[bi][2];
-            if ((NBOX == 1 || ((boxes >> bi) & 1u)) && (cull_cc_px[bi] <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc_px[bi]))) touch = true;
+        if constexpr (NBOX == 1) {   // cull constants pinned to scalar registers
+            const float b = dc[0] * ctx.cull_oc[0][0] + dc[1] * ctx.cull_oc[0][1] + dc[2] * ctx.cull_oc[0][2];
+            touch = cull_cc_px[0] <= 0.0f || (b > 0.0f && b * b >= dd * cull_cc_px[0]);
+        } else {
+            // a real loop over the item's boxes, constants from LDS (workgroup-uniform addresses): six boxes' constants pinned
+            // to scalar registers overflow the SGPR file into VGPRs and those into scratch
+#pragma unroll 1
+            for (uint32_t bm = boxes & ((1u << NBOX) - 1u); bm; bm &= bm - 1u) {
+                const float *fb_ = fc + __builtin_ctz(bm) * FC_BOX_STRIDE;
+                const float ccp = fb_[FC_CULL_CC_PIXEL];
+                const float b = dc[0] * fb_[FC_CULL_OC] + dc[1] * fb_[FC_CULL_OC + 1] + dc[2] * fb_[FC_CULL_OC + 2];
+                touch = touch || ccp <= 0.0f || (b > 0.0f && b * b >= dd * ccp);
+            }
         }
         return touch;
     };

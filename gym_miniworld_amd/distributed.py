@@ -189,7 +189,6 @@ class ShardExchange:
         return buf[self.rank * self.n:(self.rank + 1) * self.n]
 
 
-ObsGatherer = ShardExchange   # round-1 name
 
 
 def unpack_aux(aux):

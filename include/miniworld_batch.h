@@ -174,11 +174,12 @@ int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream);
  * MiniWorldEnv.step miniworld.py:658-716 + task rule e.g. envs/maze.py:106-113), including the
  * worker's auto-reset and the fork's `mask` ('dummy') semantics.
  * actions: device i32[num_envs], MiniWorldEnv.Actions values 0..7 (miniworld.py:437-454: turn_left, turn_right, move_forward,
- * move_back, pickup, drop, toggle, done - every task executes all of them as the base class does); skip_mask: device u8[num_envs] or NULL (mask[i]!=0 -> env i is not
+ * move_back, pickup, drop, toggle, done - every task executes all of them as the base class does; any other value does
+ * nothing but count a step, as the reference's if-chain does); skip_mask: device u8[num_envs] or NULL (mask[i]!=0 -> env i is not
  * stepped, reward -99, done 0, observation re-rendered). */
 int mwb_step(mwb_handle *h, const int32_t *actions_dev, const uint8_t *skip_mask_dev, void *stream);
 /* the same with the LongTensor the reference's policy produces (VecPyTorch.step_async, envs.py:121-125): int64 actions [N] in
- * device memory are read in place (no conversion pass) */
+ * device memory are read in place (no conversion pass); a value outside int32 is an unknown action (never aliased) */
 int mwb_step_i64(mwb_handle *h, const int64_t *actions_dev, const uint8_t *skip_mask_dev, void *stream);
 /* replaces: MiniWorldEnv.render_obs / render_depth (miniworld.py:1160-1220) for the whole batch */
 int mwb_render(mwb_handle *h, void *stream);
@@ -202,7 +203,12 @@ int mwb_stack_enable(mwb_handle *h, int nstack, int dtype);
 /* dtype | MWB_STACK_FUSED (implies the sliding window): mwb_reset / mwb_step move the window themselves and the render
  * kernels write each new frame straight into its newest three planes (u8 -> f32 on the way out of LDS), zeroing the history of
  * the envs they regenerate: mwb_stack_update becomes a no-op and the observation never takes a second trip through HBM.
- * Read the window with mwb_stack_window after every mwb_reset / mwb_step. */
+ * Read the window with mwb_stack_window after every mwb_reset / mwb_step.  Must be enabled before the first mwb_reset /
+ * mwb_step / mwb_render (MWB_ESTATE otherwise: the window would lack the frame already rendered).  A PARTIAL mwb_reset(mask)
+ * is a step for the window: it moves three planes on, the masked envs get a zeroed history and their first frame, the others
+ * get their re-rendered current frame appended once more (VecPyTorchFrameStack has no partial reset to compare with).
+ * A view of an earlier window position is guaranteed only until the next pass: the history planes of an env that ends are
+ * zeroed in place; for envs that keep running it stays intact for MWB_STACK_SLACK_FRAMES + 1 - nstack further steps. */
 #define MWB_STACK_FUSED 32
 int mwb_stack_window(mwb_handle *h, int *first_plane, int *planes_per_env);
 int mwb_stack_update(mwb_handle *h, int after_reset, void *stream);
@@ -218,7 +224,8 @@ int mwb_num_boxes(mwb_handle *h);   /* B: boxes per env of the handle's task */
 int mwb_get_state(mwb_handle *h, int first_env, int count, mwb_state *out);          /* synchronous */
 /* replaces: assigning env.agent.pos / env.box.pos / env.rand.np_random.set_state(...) etc. on the reference's
  * Python objects - overwrite the state of an env range with every non-NULL, non-read-only field of `in`
- * (test hook: inject oracle / reference states; also restores a snapshot taken with mwb_get_state). Synchronous. */
+ * (test hook: inject oracle / reference states; also restores a snapshot taken with mwb_get_state). Synchronous.
+ * MWB_EINVAL for non-finite values, box_size <= 0, carrying / goal_idx / MT19937 position out of range. */
 int mwb_set_state(mwb_handle *h, int first_env, int count, const mwb_state *in);
 /* overwrite pose / step counter of env range (NULL = leave); used to inject oracle states */
 int mwb_set_agent(mwb_handle *h, int first_env, int count, const double *pos_xz, const double *dir,

@@ -257,3 +257,35 @@ def test_vecenv_graph_replay_equals_eager_steps():
         assert torch.equal(oa, ob) and torch.equal(ra, rb) and np.array_equal(da, db), t
     assert a._graph is not None and b._graph is None
     a.close(); b.close()
+
+
+def test_round2_advisor_findings():
+    """int64 actions outside int32 are unknown actions (never aliased to a real one); mwb_set_state refuses NaN / empty boxes;
+    a fused frame stack cannot be enabled once an observation exists."""
+    import torch
+    from gym_miniworld_amd import _lib
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    n = 6
+    b = BatchedMiniWorld("MiniWorld-OneRoom-v0", num_envs=n, seed=5, layout="CWH")
+    b.reset()
+    s0 = b.get_state()
+    # 2^32 + 2 has the low word of move_forward, -1 / 2^40 / int64 min are no actions either: nobody moves or turns
+    weird = torch.tensor([2 ** 32 + 2, 2 ** 32 + 0, -1, 2 ** 40 + 1, -2 ** 63, 2 ** 31 + 2], dtype=torch.int64, device=b.device)
+    b.step(weird)
+    s1 = b.get_state()
+    assert np.array_equal(s0["agent_pos"], s1["agent_pos"]) and np.array_equal(s0["agent_dir"], s1["agent_dir"])
+    assert list(s1["step_count"]) == [1] * n                                  # the step itself counts (miniworld.py:663)
+    b.step(torch.full((n,), 2, dtype=torch.int64, device=b.device))           # a proper LongTensor action still moves
+    s2 = b.get_state()
+    assert not np.array_equal(s1["agent_pos"], s2["agent_pos"])
+    for bad in (dict(agent_pos=np.full((1, 3), np.nan)), dict(agent_dir=np.array([np.inf])), dict(boxes_size=np.zeros((1, 1))),
+                dict(boxes_size=np.full((1, 1), -0.8)), dict(cam=np.array([[1.5, 0.0, np.nan, 60.0]]))):
+        with pytest.raises(_lib.MwbError, match="mwb_set_state"):
+            b.set_state(0, **bad)
+    assert np.array_equal(b.get_state()["agent_pos"], s2["agent_pos"])        # a refused call changed nothing
+    with pytest.raises(_lib.MwbError, match="before the first"):
+        b.stack_enable(4, fused=True)                                         # an observation exists: the window would lack it
+    b.stack_enable(4, fused=False)                                            # the non-fused forms rebuild theirs from the obs buffer
+    b.close()
+    import gym_miniworld_amd.distributed as D
+    assert not hasattr(D, "ObsGatherer")                                      # the round-1 alias was not API compatible: gone

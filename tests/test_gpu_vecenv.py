@@ -182,3 +182,32 @@ def test_every_covered_env_id_loads_and_steps_like_run_tests():
                 if done:
                     env.reset()
         env.close()
+
+
+def test_held_stack_view_lifetime():
+    """The sliding-window stack hands out a new VIEW every step.  What an older view is worth: only until the next
+    step in general - an env that ends later gets its history planes zeroed in place - and, for envs that keep running,
+    MWB_STACK_SLACK_FRAMES + 1 - nstack = 5 further steps from ANY window position (then the wrap copy or a new frame gets there)."""
+    import torch
+    from gym_miniworld_amd import _lib
+    from gym_miniworld_amd.vec_env import MiniWorldVecEnv
+    n, nstack = 4, 4
+    keep = _lib.STACK_SLACK_FRAMES + 1 - nstack
+    assert keep == 5
+    v = MiniWorldVecEnv("MiniWorld-OneRoomS6-v0", n, seed=11, frame_stack=nstack, max_episode_steps=10 ** 6)
+    held = [(0, v.reset(), None)]
+    held[0] = (0, held[0][1], held[0][1].clone())
+    turn = torch.zeros((n, 1), dtype=torch.int64)                     # turning only: nobody reaches the box, no episode ends
+    clobbered_at = set()
+    for t in range(1, 40):
+        st, _, done, _ = v.step(turn)
+        assert not done.any()
+        for (t0, view, copy) in held:
+            same = bool(torch.equal(view, copy))
+            if t - t0 <= keep:
+                assert same, (t0, t)                                  # every window position keeps the promise
+            elif not same:
+                clobbered_at.add(t - t0)
+        held = [h for h in held if t - h[0] <= keep + 3] + [(t, st, st.clone())]
+    assert clobbered_at and min(clobbered_at) == keep + 1             # and the bound is tight: some view dies on step 6
+    v.close()

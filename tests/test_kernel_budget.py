@@ -1,0 +1,57 @@
+"""Register / scratch budget of the render kernels, checked at compile time (no GPU: hipcc cross-compiles gfx950 and
+reports per-kernel resource usage with -Rpass-analysis=kernel-resource-usage).
+
+Round 2 let the polygon-room and six-box instantiations drift to 52 / 44 B/lane of scratch (2.1x the algorithmic HBM
+traffic in YMaze) without anybody noticing; this test pins the budget: every render_kernel instantiation fits 96 VGPRs (5
+workgroups per CU), the bulk instantiations (MODE 0 and 2) spill at most 12 B/lane, the side-stream ones (MODE 1, the
+body inside a loop over the regenerated-env list) at most 96 B/lane."""
+import os
+import re
+import shutil
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+
+
+@pytest.fixture(scope="module")
+def table():
+    from kernel_resources import kernel_resources
+    return kernel_resources()
+
+
+def _render(table):
+    out = {}
+    for name, r in table.items():
+        m = re.search(r"render_kernelILi256ELi(\d)ELi(\d)ELb(\d)E", name) or re.search(r"render_kernel<256, (\d), (\d), (true|false)>", name)
+        if m:
+            out[(int(m.group(1)), int(m.group(2)), m.group(3) in ("1", "true"))] = r
+    return out
+
+
+def test_every_render_instantiation_is_reported(table):
+    r = _render(table)
+    want = {(m, nb, False) for m in (0, 1, 2) for nb in (1, 2, 6)} | {(m, 1, True) for m in (0, 1, 2)}
+    assert want <= set(r), sorted(want - set(r))
+
+
+def test_render_kernels_fit_five_workgroups_per_cu(table):
+    for key, r in _render(table).items():
+        assert r["vgprs"] <= 96 and r["agprs"] == 0, (key, r)
+        assert r["occupancy"] >= 5, (key, r)
+
+
+def test_bulk_render_scratch_budget(table):
+    for (mode, nbox, poly), r in _render(table).items():
+        limit = 96 if mode == 1 else 12
+        assert r["scratch"] <= limit, ((mode, nbox, poly), r["scratch"], limit)
+
+
+def test_reset_kernel_scratch_budget(table):
+    rk = [r for n, r in table.items() if "reset_kernel" in n and "mark" not in n]
+    assert len(rk) == 1
+    assert rk[0]["scratch"] <= 1400, rk[0]   # tightened when the world generator's spills are moved to LDS
