@@ -164,13 +164,39 @@ typedef struct {
     double floor_texcs[4][2], ceil_texcs[4][2];
 } Room;
 
-typedef struct { double pos[3], dir, radius, height; } Ent;
+/* one entity of self.entities.  kind / geom / flags: reference entity.py; rad_f32: the radius is a numpy float32 scalar
+ * (MeshEnt under NumPy >= 2, entity.py:118-127) - sums of it with Python floats are then evaluated in float32 */
+typedef struct {
+    double pos[3], dir, radius, height;
+    int kind, geom, is_static, alive, rad_f32;
+    double scale;
+    double frame_w, frame_h, frame_d;   /* ImageFrame / TextFrame: width, height, depth */
+    int tex[8], n_chars;                /* ImageFrame: tex[0]; TextFrame: one texture per character, -1 = space */
+} Ent;
+#define AGENT_SLOT (-2)
 
 /* texture families (name -> list of <name>_<i>.png, opengl.py:40-69) */
 enum { TEXF_FLOOR_TILES_BW = 0, TEXF_CONCRETE, TEXF_CONCRETE_TILES, TEXF_BRICK_WALL,
-       TEXF_CARDBOARD, TEXF_WOOD, TEXF_WOOD_PLANKS, TEXF_DRYWALL, TEXF_STUCCO, TEXF_CEILING_TILES, N_TEXF };
-static const int TEXF_FIRST[N_TEXF] = {0, 1, 5, 6, 7, 11, 13, 14, 15, 16};
-static const int TEXF_COUNT[N_TEXF] = {1, 4, 1, 1, 4, 2, 1, 1, 1, 1};
+       TEXF_CARDBOARD, TEXF_WOOD, TEXF_WOOD_PLANKS, TEXF_DRYWALL, TEXF_STUCCO, TEXF_CEILING_TILES,
+       TEXF_ASPHALT, TEXF_SLIME, TEXF_CINDER_BLOCKS, TEXF_LOGO_MILA, N_TEXF };
+static const int TEXF_FIRST[N_TEXF] = {0, 1, 5, 6, 7, 11, 13, 14, 15, 16, 17, 18, 19, 20};
+static const int TEXF_COUNT[N_TEXF] = {1, 4, 1, 1, 4, 2, 1, 1, 1, 1, 1, 1, 1, 1};
+/* texture slots 21-24: the images of the textured meshes (medkit, duckie, building, cone); 25 + 9 c + v: variant v + 1 of the
+ * c-th character of "BLUERDGN" (textures/chars/ch_0x<ord>_<v + 1>.png, entity.py:268-278) */
+#define TEX_MESH0 21
+#define TEX_CHAR0 25
+static const char SIGN_CHARS[] = "BLUERDGN";
+
+typedef struct {
+    int n_tris, tex_id;
+    float *verts, *norms, *texcs;   /* [n][3][3], [n][3][3], [n][3][2] as objmesh.py builds them */
+    float *e1, *e2;                 /* [n][3]: v1 - v0, v2 - v0 in float32 (the ray / triangle test's inputs) */
+    float min_c[3], max_c[3];
+} Mesh;
+static Mesh g_mesh[MWO_NMESH];
+typedef struct { int geom; double height, scale, radius; int is_f32; } MeshDims;
+static MeshDims g_mesh_dims[32];
+static int g_n_mesh_dims;
 
 typedef struct {
     int w, h, n_levels;
@@ -195,9 +221,11 @@ struct MwoEnv {
     int n_segs;
     double (*wall_segs)[2][3];
     double room_probs[MWO_MAX_ROOMS], room_cdf[MWO_MAX_ROOMS];
-    Ent boxes[MWO_MAX_BOXES], agent;
-    int n_boxes; /* 1; 2 for the two-box T-maze (red, blue) and SimToRealPush (red, yellow); 6 for PutNext (COLOR_NAMES order) */
-    int n_ents; /* entities placed so far, in list order: the boxes, then the agent */
+    Ent boxes[MWO_MAX_BOXES], agent;   /* "boxes" = every entity but the agent, by slot (its position in the episode's first list) */
+    int n_boxes; /* 1; 2 for the two-box T-maze (red, blue) and SimToRealPush (red, yellow); 6 for PutNext (COLOR_NAMES order); ... */
+    int order[MWO_MAX_BOXES + 1], n_order; /* self.entities now, as slots (AGENT_SLOT = the agent): PickupObjs removes entries,
+                                              CollectHealth moves a respawned kit to the end (collecthealth.py:56-57) */
+    double health; int num_picked;          /* CollectHealth.health, PickupObjs.num_picked_up */
     double box_s[MWO_MAX_BOXES]; /* edge length of each box (Box(size=s), entity.py:366-378) */
     double box_colors[MWO_MAX_BOXES][3]; /* Box.color_vec after randomize (entity.py:381-383) */
     int box_base[MWO_MAX_BOXES]; /* index into COLORS (entity.py:8-15) */
@@ -215,6 +243,29 @@ struct MwoEnv {
 static void fail(const char *msg) {
     fprintf(stderr, "mw_oracle: %s\n", msg);
     abort();
+}
+
+int mwo_set_mesh(int geom, int n_tris, const float *verts, const float *norms, const float *texcs, int tex_id,
+                 const float *min_coords, const float *max_coords) {
+    if (geom < 0 || geom >= MWO_NMESH || n_tris <= 0) return -1;
+    Mesh *m = &g_mesh[geom];
+    free(m->verts); free(m->norms); free(m->texcs); free(m->e1); free(m->e2);
+    m->n_tris = n_tris; m->tex_id = tex_id;
+    m->verts = malloc(sizeof(float) * 9 * n_tris); m->norms = malloc(sizeof(float) * 9 * n_tris); m->texcs = malloc(sizeof(float) * 6 * n_tris);
+    m->e1 = malloc(sizeof(float) * 3 * n_tris); m->e2 = malloc(sizeof(float) * 3 * n_tris);
+    memcpy(m->verts, verts, sizeof(float) * 9 * n_tris); memcpy(m->norms, norms, sizeof(float) * 9 * n_tris);
+    memcpy(m->texcs, texcs, sizeof(float) * 6 * n_tris);
+    for (int i = 0; i < n_tris; i++)
+        for (int k = 0; k < 3; k++) { m->e1[i * 3 + k] = verts[i * 9 + 3 + k] - verts[i * 9 + k]; m->e2[i * 3 + k] = verts[i * 9 + 6 + k] - verts[i * 9 + k]; }
+    for (int k = 0; k < 3; k++) { m->min_c[k] = min_coords[k]; m->max_c[k] = max_coords[k]; }
+    return 0;
+}
+int mwo_set_mesh_dims(int geom, double height, double scale, double radius, int is_f32) {
+    for (int i = 0; i < g_n_mesh_dims; i++)
+        if (g_mesh_dims[i].geom == geom && g_mesh_dims[i].height == height) { g_mesh_dims[i] = (MeshDims){geom, height, scale, radius, is_f32}; return 0; }
+    if (g_n_mesh_dims >= 32) return -1;
+    g_mesh_dims[g_n_mesh_dims++] = (MeshDims){geom, height, scale, radius, is_f32};
+    return 0;
 }
 
 int mwo_set_texture(int id, int w, int h, int n_levels, const uint8_t *rgba) {
@@ -268,10 +319,19 @@ static void sample_param(MwoEnv *e, int use_rng, int name, double *out) {
 MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int domain_rand, const double *params) {
     MwoEnv *e = (MwoEnv *)calloc(1, sizeof(MwoEnv));
     e->task = task;
-    static const double dflt[10][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}, {12, 0, 0, 0}, {0, 0, 0, 0}};
-    if (task < 0 || task > MWO_YMAZE) fail("unknown task");
+    static const double dflt[MWO_NTASKS][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}, {12, 0, 0, 0}, {0, 0, 0, 0},
+                                               {12, 5, 0, 0}, {10, 0, 0, 0}, {16, 0, 0, 0}, {0, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (task < 0 || task >= MWO_NTASKS) fail("unknown task");
     for (int i = 0; i < 4; i++) e->task_args[i] = task_args ? task_args[i] : dflt[task][i];
+    if (task == MWO_PICKUPOBJS && e->task_args[1] == 0) e->task_args[1] = 5;
     e->n_boxes = (task == MWO_TMAZE_TWOBOX || task == MWO_SIM2REAL_PUSH) ? 2 : task == MWO_PUTNEXT ? 6 : 1;
+    if (task == MWO_PICKUPOBJS) e->n_boxes = (int)e->task_args[1];
+    else if (task == MWO_ROOMOBJS) e->n_boxes = 3;
+    else if (task == MWO_COLLECTHEALTH) e->n_boxes = 18;
+    else if (task == MWO_THREEROOMS) e->n_boxes = 6;
+    else if (task == MWO_SIGN || task == MWO_SIDEWALK) e->n_boxes = 7;
+    else if (task == MWO_WALLGAP) e->n_boxes = 2;
+    if (e->n_boxes < 1 || e->n_boxes > MWO_MAX_BOXES) fail("too many entities");
     e->carrying = -1;
     if (max_episode_steps <= 0) {
         /* hallway.py:18, oneroom.py:14, fourrooms.py:15, maze.py:27 */
@@ -283,6 +343,13 @@ MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int
         else if (task == MWO_SIM2REAL_PUSH) max_episode_steps = 150; /* simtorealpush.py:29 */
         else if (task == MWO_PUTNEXT) max_episode_steps = 250; /* putnext.py:16 */
         else if (task == MWO_YMAZE) max_episode_steps = 280; /* ymaze.py:21 */
+        else if (task == MWO_PICKUPOBJS) max_episode_steps = 400;      /* pickupobjs.py:19 */
+        else if (task == MWO_ROOMOBJS) max_episode_steps = 2147483647; /* roomobjs.py:19: math.inf */
+        else if (task == MWO_COLLECTHEALTH) max_episode_steps = 1000;  /* collecthealth.py:24 */
+        else if (task == MWO_THREEROOMS) max_episode_steps = 400;      /* threerooms.py:14 */
+        else if (task == MWO_SIGN) max_episode_steps = 20;             /* sign.py:41 */
+        else if (task == MWO_SIDEWALK) max_episode_steps = 150;        /* sidewalk.py:15 */
+        else if (task == MWO_WALLGAP) max_episode_steps = 300;         /* wallgap.py:14 */
         else max_episode_steps = (int)e->task_args[0] * (int)e->task_args[1] * 24;
     }
     e->max_episode_steps = max_episode_steps;
@@ -360,6 +427,11 @@ static Room *add_room(MwoEnv *e, const double outline2[4][2], double wall_height
 static Room *add_rect_room(MwoEnv *e, double min_x, double max_x, double min_z, double max_z, int wall_tex) {
     double o[4][2] = {{max_x, max_z}, {max_x, min_z}, {min_x, min_z}, {min_x, max_z}};
     return add_room(e, o, 2.74, wall_tex, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES, 0);
+}
+
+static Room *add_rect_room_ex(MwoEnv *e, double min_x, double max_x, double min_z, double max_z, int wall_tex, int floor_tex, int ceil_tex, int no_ceiling) {
+    double o[4][2] = {{max_x, max_z}, {max_x, min_z}, {min_x, min_z}, {min_x, max_z}};
+    return add_room(e, o, 2.74, wall_tex, floor_tex, ceil_tex, no_ceiling);
 }
 
 /* Room.add_portal, miniworld.py:140-218.  mode 0: start/end given; 1: min_x/max_x; 2: min_z/max_z */
@@ -551,18 +623,30 @@ int mwo_intersect_circle_segs(const double *point, double radius, const double *
 }
 
 /* MiniWorldEnv.intersect, miniworld.py:933-959. returns 1 wall, 2+k entity k, 0 none */
-static int intersect(MwoEnv *e, const Ent *self, const double *pos, double radius) {
+/* a + b as the reference's interpreter evaluates it when either operand may be a numpy float32 SCALAR and the other a Python
+ * float (NumPy >= 2, NEP 50): the Python float is cast to float32 and the sum is a float32; two Python floats add in float64 */
+static double tagged_add(double a, int a_f32, double b, int b_f32, int *res_f32) {
+    if (a_f32 || b_f32) { if (res_f32) *res_f32 = 1; return (double)((float)a + (float)b); }
+    if (res_f32) *res_f32 = 0;
+    return a + b;
+}
+
+/* MiniWorldEnv.intersect(ent, pos, radius), miniworld.py:933-959; radius_f32: `radius` is a numpy float32 scalar.
+ * Returns 0 none, 1 wall, 2 + slot for an entity, 2 + n_boxes for the agent */
+static int intersect_t(MwoEnv *e, const Ent *self, const double *pos, double radius, int radius_f32) {
     double p[3] = {pos[0], 0, pos[2]};
     if (mwo_intersect_circle_segs(p, radius, &e->wall_segs[0][0][0], e->n_segs)) return 1;
-    for (int k = 0; k < e->n_ents && k <= e->n_boxes; k++) { /* self.entities in list order: the boxes, then the agent */
-        const Ent *o = k < e->n_boxes ? &e->boxes[k] : &e->agent;
+    for (int k = 0; k < e->n_order; k++) { /* self.entities in list order */
+        const int slot = e->order[k];
+        const Ent *o = slot == AGENT_SLOT ? &e->agent : &e->boxes[slot];
         if (o == self) continue;
         double d3[3] = {o->pos[0] - p[0], 0 - p[1], o->pos[2] - p[2]}; /* ent2's y is flattened too (miniworld.py:951-952) */
         double d = sqrt(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
-        if (d < radius + o->radius) return 2 + k;
+        if (d < tagged_add(radius, radius_f32, o->radius, o->rad_f32, NULL)) return 2 + (slot == AGENT_SLOT ? e->n_boxes : slot);
     }
     return 0;
 }
+static int intersect(MwoEnv *e, const Ent *self, const double *pos, double radius) { return intersect_t(e, self, pos, radius, 0); }
 
 /* ent: index in the entity list (boxes, then the agent = n_boxes); legacy callers pass 0 = first box, 1 = agent, 2 = second box */
 int mwo_intersect(MwoEnv *e, int ent, double x, double z, double radius) {
@@ -601,13 +685,21 @@ static void place_entity_in(MwoEnv *e, Ent *ent, int room, int has_dir, double d
         pos[1] = rs_uniform(&e->rng, 0, 0);
         pos[2] = rs_uniform(&e->rng, lz + ent->radius, hz - ent->radius);
         if (!point_inside(r, pos)) continue;
-        if (intersect(e, ent, pos, ent->radius)) continue;
+        if (intersect_t(e, ent, pos, ent->radius, ent->rad_f32)) continue;
         double d = has_dir ? dir : rs_uniform(&e->rng, -M_PI, M_PI);
         memcpy(ent->pos, pos, sizeof(pos));
         ent->dir = d;
         break;
     }
-    e->n_ents++;
+    e->order[e->n_order++] = ent == &e->agent ? AGENT_SLOT : (int)(ent - e->boxes);   /* self.entities.append(ent) */
+}
+
+/* place_entity with pos given (miniworld.py:869-873): no tests, the heading drawn unless given */
+static void place_entity_at(MwoEnv *e, Ent *ent, double x, double y, double z, int has_dir, double dir) {
+    if (!e->static_done) gen_static_data(e);
+    ent->dir = has_dir ? dir : rs_uniform(&e->rng, -M_PI, M_PI);
+    ent->pos[0] = x; ent->pos[1] = y; ent->pos[2] = z;
+    e->order[e->n_order++] = ent == &e->agent ? AGENT_SLOT : (int)(ent - e->boxes);
 }
 
 static void place_entity(MwoEnv *e, Ent *ent, int has_dir, double dir, double min_x, double max_x, double min_z, double max_z) {
@@ -620,6 +712,18 @@ static void size_box(MwoEnv *e, int b, double s) {
     e->box_s[b] = s;
     ent->radius = sqrt(s * s + s * s) / 2;
     ent->height = s;
+    ent->kind = MWO_ENT_BOX; ent->is_static = 0; ent->alive = 1; ent->rad_f32 = 0;
+}
+/* MeshEnt(mesh_name, height, static) (entity.py:100-128): scale / radius as registered with mwo_set_mesh_dims */
+static void make_mesh_ent(MwoEnv *e, int b, int geom, double height, int is_static, int color) {
+    Ent *ent = &e->boxes[b];
+    const MeshDims *md = NULL;
+    for (int i = 0; i < g_n_mesh_dims; i++) if (g_mesh_dims[i].geom == geom && g_mesh_dims[i].height == height) md = &g_mesh_dims[i];
+    if (!md) fail("mesh dimensions not registered (mwo_set_mesh_dims)");
+    memset(ent, 0, sizeof(*ent));
+    ent->kind = MWO_ENT_MESH; ent->geom = geom; ent->is_static = is_static; ent->alive = 1;
+    ent->scale = md->scale; ent->radius = md->radius; ent->rad_f32 = md->is_f32; ent->height = height;
+    e->box_s[b] = height; e->box_base[b] = color;   /* colour index into COLORS: the mesh's Kd (ball_<c>.mtl / key_<c>.mtl); -1 = white */
 }
 static void new_box(MwoEnv *e) { for (int b = 0; b < MWO_MAX_BOXES; b++) size_box(e, b, 0.8); }
 
@@ -751,7 +855,7 @@ static void gen_world(MwoEnv *e) {
                 place_entity(e, &e->boxes[1], 0, 0, min_pos, max_pos, min_pos, max_pos);
                 double dx = e->boxes[0].pos[0] - e->boxes[1].pos[0], dy = e->boxes[0].pos[1] - e->boxes[1].pos[1], dz = e->boxes[0].pos[2] - e->boxes[1].pos[2];
                 if (sqrt((dx * dx + dy * dy) + dz * dz) > e->goal_dist) break;
-                e->n_ents = 0; /* entities.remove(box1), entities.remove(box2) */
+                e->n_order = 0; /* entities.remove(box1), entities.remove(box2) */
             }
         } else {
             place_entity(e, &e->boxes[0], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
@@ -801,6 +905,130 @@ static void gen_world(MwoEnv *e) {
         place_entity_in(e, &e->agent, 0, 1, dir, NOVAL, NOVAL, NOVAL, NOVAL);
         break;
     }
+    case MWO_PICKUPOBJS: { /* envs/pickupobjs.py:28-54 */
+        double size = e->task_args[0];
+        add_rect_room_ex(e, 0, size, 0, size, TEXF_BRICK_WALL, TEXF_ASPHALT, TEXF_CONCRETE_TILES, 1);
+        for (int i = 0; i < e->n_boxes; i++) {
+            int type = (int)rs_randint(&e->rng, 0, 3);    /* self.rand.choice([Ball, Box, Key]) */
+            int color = (int)rs_randint(&e->rng, 0, 6);   /* self.rand.color(): choice(COLOR_NAMES) */
+            if (type == 1) { size_box(e, i, 0.9); e->box_base[i] = color; }
+            else if (type == 0) make_mesh_ent(e, i, MWO_MESH_BALL, 0.9, 0, color);
+            else make_mesh_ent(e, i, MWO_MESH_KEY, 0.35, 0, color);
+            place_entity(e, &e->boxes[i], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        }
+        place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        e->num_picked = 0;
+        break;
+    }
+    case MWO_ROOMOBJS: { /* envs/roomobjs.py:24-47 */
+        double size = e->task_args[0];
+        add_rect_room_ex(e, 0, size, 0, size, TEXF_BRICK_WALL, TEXF_ASPHALT, TEXF_CONCRETE_TILES, 1);
+        e->agent.radius = 1.5;   /* "Reduce chances that objects are too close to see" */
+        int color = (int)rs_randint(&e->rng, 0, 6);   /* the colour is an argument of the constructor: drawn before the placement */
+        size_box(e, 0, 0.9); e->box_base[0] = color;
+        place_entity(e, &e->boxes[0], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        color = (int)rs_randint(&e->rng, 0, 6);
+        make_mesh_ent(e, 1, MWO_MESH_BALL, 0.9, 0, color);
+        place_entity(e, &e->boxes[1], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        color = (int)rs_randint(&e->rng, 0, 6);
+        make_mesh_ent(e, 2, MWO_MESH_KEY, 0.35, 0, color);
+        place_entity(e, &e->boxes[2], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        break;
+    }
+    case MWO_COLLECTHEALTH: { /* envs/collecthealth.py:28-49 */
+        double size = e->task_args[0];
+        add_rect_room_ex(e, 0, size, 0, size, TEXF_CINDER_BLOCKS, TEXF_SLIME, TEXF_CONCRETE_TILES, 0);
+        for (int i = 0; i < 18; i++) {
+            make_mesh_ent(e, i, MWO_MESH_MEDKIT, 0.40, 0, -1);
+            place_entity(e, &e->boxes[i], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        }
+        place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        e->health = 100;
+        break;
+    }
+    case MWO_THREEROOMS: { /* envs/threerooms.py:22-69 */
+        add_rect_room(e, -7, 7, 0.5, 7, TEXF_CONCRETE);
+        add_rect_room(e, -7, -1, -7, -0.5, TEXF_CONCRETE);
+        add_rect_room(e, 1, 7, -7, -0.5, TEXF_CONCRETE);
+        connect_rooms(e, 0, 1, 1, -5.25, -2.75, 0, 0);
+        connect_rooms(e, 0, 2, 1, 2.75, 5.25, 0, 0);
+        size_box(e, 0, 0.8); e->box_base[0] = 4;   /* red */
+        place_entity(e, &e->boxes[0], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        size_box(e, 1, 0.6); e->box_base[1] = 1;   /* green */
+        place_entity(e, &e->boxes[1], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        {   /* self.entities.append(ImageFrame(pos=[0, 1.35, 7], dir=pi/2, width=1.8, tex_name='logo_mila')) */
+            Ent *f = &e->boxes[2];
+            memset(f, 0, sizeof(*f));
+            f->kind = MWO_ENT_IMAGE; f->is_static = 1; f->alive = 1; f->radius = 0; f->rad_f32 = 0;
+            f->pos[0] = 0; f->pos[1] = 1.35; f->pos[2] = 7; f->dir = M_PI / 2;
+            f->tex[0] = TEXF_FIRST[TEXF_LOGO_MILA];
+            f->frame_w = 1.8; f->frame_d = 0.05;
+            f->frame_h = ((double)tex_height(f->tex[0]) / tex_width(f->tex[0])) * 1.8;   /* (float(tex.height) / tex.width) * width */
+            f->height = f->frame_h;
+            e->order[e->n_order++] = 2;
+        }
+        make_mesh_ent(e, 3, MWO_MESH_DUCKIE, 0.25, 0, -1);
+        place_entity(e, &e->boxes[3], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        make_mesh_ent(e, 4, MWO_MESH_KEY, 0.35, 0, 0);    /* Key(color='blue') */
+        place_entity(e, &e->boxes[4], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        make_mesh_ent(e, 5, MWO_MESH_BALL, 0.6, 0, 1);    /* Ball(color='green'), size 0.6 */
+        place_entity(e, &e->boxes[5], 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        place_entity(e, &e->agent, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        break;
+    }
+    case MWO_SIGN: { /* envs/sign.py:75-113 */
+        const double size = e->task_args[0], gap = 0.25;
+        add_rect_room(e, 0, size, 0, size * 0.65, TEXF_CONCRETE);
+        add_rect_room(e, 0, size * 3 / 5, size * 0.65 + gap, size * 1.3, TEXF_CONCRETE);
+        add_rect_room(e, size * 3 / 5, size, size * 0.65 + gap, size * 1.3, TEXF_CONCRETE);
+        connect_rooms(e, 0, 1, 1, 0, size * 3 / 5, 0, 0);
+        connect_rooms(e, 1, 2, 2, size * 0.65 + gap, size * 1.3, 0, 0);
+        static const int box_col[3] = {0, 4, 1};   /* blue, red, green */
+        static const double box_at[3][2] = {{1, 1}, {9, 1}, {9, 5}}, key_at[3][2] = {{5, 1}, {1, 5}, {1, 9}};
+        for (int i = 0; i < 3; i++) { size_box(e, i, 0.8); e->box_base[i] = box_col[i]; place_entity_at(e, &e->boxes[i], box_at[i][0], 0, box_at[i][1], 0, 0); }
+        for (int i = 0; i < 3; i++) { make_mesh_ent(e, 3 + i, MWO_MESH_KEY, 0.6, 0, box_col[i]); place_entity_at(e, &e->boxes[3 + i], key_at[i][0], 0, key_at[i][1], 0, 0); }   /* BigKey */
+        {   /* TextFrame(pos=[size, 1.35, size + gap], dir=pi, str=text, height=1) appended to the list */
+            static const char *TEXT[3] = {"BLUE", "RED", "GREEN"};
+            const char *txt = TEXT[(int)e->task_args[1]];
+            Ent *f = &e->boxes[6];
+            memset(f, 0, sizeof(*f));
+            f->kind = MWO_ENT_TEXT; f->is_static = 1; f->alive = 1;
+            f->pos[0] = size; f->pos[1] = 1.35; f->pos[2] = size + gap; f->dir = M_PI;
+            f->n_chars = (int)strlen(txt);
+            f->frame_h = 1; f->frame_d = 0.05; f->frame_w = f->n_chars * 1.0; f->height = 1;
+            for (int c = 0; c < f->n_chars; c++) f->tex[c] = TEX_CHAR0 + 9 * (int)(strchr(SIGN_CHARS, txt[c]) - SIGN_CHARS);   /* variant 1 until randomize() */
+            e->order[e->n_order++] = 6;
+        }
+        place_entity(e, &e->agent, 0, 0, 4, 5, 4, 6);
+        break;
+    }
+    case MWO_SIDEWALK: { /* envs/sidewalk.py:22-72 */
+        add_rect_room_ex(e, -3, 0, 0, 12, TEXF_BRICK_WALL, TEXF_CONCRETE_TILES, TEXF_CONCRETE_TILES, 1);
+        add_rect_room_ex(e, 0, 6, -80, 80, TEXF_CONCRETE, TEXF_ASPHALT, TEXF_CONCRETE_TILES, 1);
+        connect_rooms(e, 0, 1, 2, 0, 12, 0, 0);
+        make_mesh_ent(e, 0, MWO_MESH_BUILDING, 30, 1, -1);
+        place_entity_at(e, &e->boxes[0], 30, 0, 30, 1, -M_PI);
+        for (int i = 1; i < 6; i++) {   /* range(1, sidewalk.max_z // 2) */
+            make_mesh_ent(e, i, MWO_MESH_CONE, 0.75, 1, -1);
+            place_entity_at(e, &e->boxes[i], 1, 0, 2 * i, 0, 0);
+        }
+        size_box(e, 6, 0.8); e->box_base[6] = 4;
+        place_entity_in(e, &e->boxes[6], 0, 0, 0, NOVAL, NOVAL, e->rooms[0].max_z - 2, e->rooms[0].max_z);
+        place_entity_in(e, &e->agent, 0, 0, 0, NOVAL, NOVAL, 0, 1.5);
+        break;
+    }
+    case MWO_WALLGAP: { /* envs/wallgap.py:21-52 */
+        add_rect_room_ex(e, -7, 7, 0.5, 8, TEXF_BRICK_WALL, TEXF_ASPHALT, TEXF_CONCRETE_TILES, 1);
+        add_rect_room_ex(e, -7, 7, -8, -0.5, TEXF_BRICK_WALL, TEXF_ASPHALT, TEXF_CONCRETE_TILES, 1);
+        connect_rooms(e, 0, 1, 1, -1.5, 1.5, 0, 0);
+        size_box(e, 0, 0.8); e->box_base[0] = 4;
+        place_entity_in(e, &e->boxes[0], 1, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        make_mesh_ent(e, 1, MWO_MESH_BUILDING, 30, 1, -1);
+        place_entity_at(e, &e->boxes[1], 30, 0, 30, 1, -M_PI);
+        place_entity_in(e, &e->agent, 0, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+        break;
+    }
     default: fail("unknown task");
     }
 }
@@ -821,11 +1049,11 @@ void mwo_reset(MwoEnv *e) {
     e->feature[0] = e->feature[1] = 0;
     e->step_count = 0;
     free_rooms(e);
-    e->n_ents = 0;
+    e->n_order = 0;
     memset(&e->agent, 0, sizeof(Ent));
     e->agent.radius = 0.4; e->agent.height = 1.6; /* entity.py:436-455 */
     e->carrying = -1; /* a fresh Agent() carries nothing (entity.py:446) */
-    for (int b = 0; b < MWO_MAX_BOXES; b++) { memset(&e->boxes[b], 0, sizeof(Ent)); e->box_base[b] = 4; /* red */ }
+    for (int b = 0; b < MWO_MAX_BOXES; b++) { memset(&e->boxes[b], 0, sizeof(Ent)); e->box_base[b] = 4; /* red */ e->box_s[b] = 0; }
     if (e->task == MWO_TMAZE_TWOBOX) e->box_base[1] = 0;          /* blue, tmaze.py:168 */
     else if (e->task == MWO_SIM2REAL_PUSH) e->box_base[1] = 5;    /* yellow, simtorealpush.py:93 */
     else if (e->task == MWO_PUTNEXT) for (int b = 0; b < 6; b++) e->box_base[b] = b;   /* for color in COLOR_NAMES, putnext.py:31 */
@@ -839,12 +1067,23 @@ void mwo_reset(MwoEnv *e) {
     /* Box.randomize, entity.py:381-383: COLORS[color] + bias, clipped - entities are randomized in list order */
     static const double COLORS[6][3] = {{0.0, 0.0, 1.0}, {0.0, 1.0, 0.0}, {0.39, 0.39, 0.39}, {0.44, 0.15, 0.76},
                                         {1.0, 0.0, 0.0}, {1.00, 1.00, 0.00}}; /* COLOR_NAMES order: blue green grey purple red yellow */
-    for (int b = 0; b < e->n_boxes; b++) {
-        double bias[3];
-        sample_param(e, dr, MWO_P_OBJ_COLOR_BIAS, bias);
-        const double *c = COLORS[e->box_base[b]];
-        for (int k = 0; k < 3; k++) { double v = c[k] + bias[k]; e->box_colors[b][k] = v < 0 ? 0 : (v > 1 ? 1 : v); }
+    for (int k = 0; k < e->n_order; k++) {   /* for ent in self.entities: ent.randomize(params, rand) (miniworld.py:572-573) */
+        const int b = e->order[k];
+        if (b == AGENT_SLOT) continue;   /* the agent is the last entry in every task: its draws follow below */
+        Ent *ent = &e->boxes[b];
+        if (ent->kind == MWO_ENT_BOX) {
+            double bias[3];
+            sample_param(e, dr, MWO_P_OBJ_COLOR_BIAS, bias);
+            const double *c = COLORS[e->box_base[b]];
+            for (int q = 0; q < 3; q++) { double v = c[q] + bias[q]; e->box_colors[b][q] = v < 0 ? 0 : (v > 1 ? 1 : v); }
+        } else if (ent->kind == MWO_ENT_MESH) {   /* MeshEnt has no randomize(); the vertex colour is the material's Kd */
+            for (int q = 0; q < 3; q++) e->box_colors[b][q] = e->box_base[b] >= 0 ? COLORS[e->box_base[b]][q] : 1.0;
+        } else if (ent->kind == MWO_ENT_TEXT) {   /* TextFrame.randomize (entity.py:268-278): Texture.get(name, rng) per character */
+            for (int c = 0; c < ent->n_chars; c++)
+                if (ent->tex[c] >= 0) ent->tex[c] = ent->tex[c] + (dr ? (int)rs_randint(&e->rng, 0, 9) : 0);
+        }
     }
+    if (e->n_order < 1 || e->order[e->n_order - 1] != AGENT_SLOT) fail("the agent must be the last entity placed");
     /* Agent.randomize, entity.py:486-492 */
     sample_param(e, dr, MWO_P_CAM_HEIGHT, &e->cam_height);
     sample_param(e, dr, MWO_P_CAM_FWD_DISP, &e->cam_fwd_disp);
@@ -857,19 +1096,32 @@ void mwo_reset(MwoEnv *e) {
 static int near_ent(MwoEnv *e, const Ent *b) {
     double d[3] = {b->pos[0] - e->agent.pos[0], b->pos[1] - e->agent.pos[1], b->pos[2] - e->agent.pos[2]};
     double dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    return dist < b->radius + e->agent.radius + 1.1 * e->max_forward_step;
+    int f32;   /* (ent0.radius + ent1.radius) + 1.1 * max_forward_step, float32 all the way once a float32 radius is in it */
+    double thr = tagged_add(b->radius, b->rad_f32, e->agent.radius, 0, &f32);
+    thr = tagged_add(thr, f32, 1.1 * e->max_forward_step, 0, NULL);
+    return dist < thr;
 }
 static int near_box(MwoEnv *e) { return near_ent(e, &e->boxes[0]); }
 
 /* MiniWorldEnv._get_carry_pos, miniworld.py:594-606 */
 static void carry_pos(MwoEnv *e, const double *agent_pos, const Ent *ent, double *out) {
-    double dist = (e->agent.radius + ent->radius) + e->max_forward_step;
+    int f32;
+    double dist = tagged_add(e->agent.radius, 0, ent->radius, ent->rad_f32, &f32);   /* self.agent.radius + ent.radius + self.max_forward_step */
+    dist = tagged_add(dist, f32, e->max_forward_step, 0, NULL);
     double dv[3] = {cos(e->agent.dir), 0, -sin(e->agent.dir)};
     for (int k = 0; k < 3; k++) out[k] = agent_pos[k] + (dv[k] * 1.05) * dist;   /* agent_pos + self.agent.dir_vec * 1.05 * dist */
     double y_pos = (e->cam_height - ent->height) - 0.3;
     if (!(y_pos > 0)) y_pos = 0;   /* max(cam_height - ent.height - 0.3, 0) */
     out[1] = out[1] + 1.0 * y_pos;  /* pos + Y_VEC * y_pos */
     out[0] = out[0] + 0.0 * y_pos; out[2] = out[2] + 0.0 * y_pos;
+}
+
+static void remove_from_order(MwoEnv *e, int slot) {   /* self.entities.remove(ent) */
+    int k = 0;
+    while (k < e->n_order && e->order[k] != slot) k++;
+    if (k == e->n_order) fail("entity not in the list");
+    for (; k + 1 < e->n_order; k++) e->order[k] = e->order[k + 1];
+    e->n_order--;
 }
 
 /* MiniWorldEnv.step miniworld.py:658-716 + task rule (e.g. envs/maze.py:106-113) */
@@ -911,7 +1163,7 @@ void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
             double cp[3];
             if (carried) { /* the carried entity must fit where it would go (miniworld.py:622-629) */
                 carry_pos(e, np_, carried, cp);
-                if (intersect(e, carried, cp, carried->radius)) ok = 0;
+                if (intersect_t(e, carried, cp, carried->radius, carried->rad_f32)) ok = 0;
                 else memcpy(carried->pos, cp, sizeof(cp));
             }
             if (ok) memcpy(e->agent.pos, np_, sizeof(np_));
@@ -924,7 +1176,7 @@ void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
         if (carried) {
             double cp[3];
             carry_pos(e, e->agent.pos, carried, cp);
-            if (intersect(e, carried, cp, carried->radius)) e->agent.dir = orig;
+            if (intersect_t(e, carried, cp, carried->radius, carried->rad_f32)) e->agent.dir = orig;
             else { memcpy(carried->pos, cp, sizeof(cp)); carried->dir = e->agent.dir; }
         }
     } else if (action == 4) { /* pickup, miniworld.py:682-689: the first entity within 1.2 r of a point 1.5 r ahead */
@@ -932,7 +1184,7 @@ void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
         double tp[3];
         for (int k = 0; k < 3; k++) tp[k] = e->agent.pos[k] + (dv[k] * 1.5) * e->agent.radius;
         int hit = intersect(e, &e->agent, tp, 1.2 * e->agent.radius);
-        if (e->carrying < 0 && hit >= 2 && hit - 2 < e->n_boxes) e->carrying = hit - 2; /* Box.is_static is False (entity.py:40-46) */
+        if (e->carrying < 0 && hit >= 2 && hit - 2 < e->n_boxes && !e->boxes[hit - 2].is_static) e->carrying = hit - 2; /* `if not ent.is_static` */
     } else if (action == 5) { /* drop, miniworld.py:692-695 */
         if (e->carrying >= 0) { e->boxes[e->carrying].pos[1] = 0; e->carrying = -1; }
     }
@@ -965,6 +1217,35 @@ void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
             double dist = sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]);
             if (dist < a->radius + b->radius + 1.1 * e->max_forward_step) { r += 1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps); d = 1; }
         }
+    } else if (e->task == MWO_PICKUPOBJS) { /* pickupobjs.py:56-69: a picked object leaves the list (AFTER the frame was rendered) */
+        if (e->carrying >= 0) {
+            remove_from_order(e, e->carrying);
+            e->boxes[e->carrying].alive = 0;
+            e->carrying = -1;
+            e->num_picked += 1;
+            r = 1;
+            if (e->num_picked == e->n_boxes) d = 1;
+        }
+    } else if (e->task == MWO_ROOMOBJS || e->task == MWO_THREEROOMS) { /* roomobjs.py:49-51, threerooms.py:71-74: nothing */
+    } else if (e->task == MWO_COLLECTHEALTH) { /* collecthealth.py:51-77 */
+        e->health -= 2;
+        if (action == 4 && e->carrying >= 0) {   /* respawn the kit: entities.remove(), place_entity() appends it to the END of the list */
+            Ent *kit = &e->boxes[e->carrying];
+            remove_from_order(e, e->carrying);
+            place_entity(e, kit, 0, 0, NOVAL, NOVAL, NOVAL, NOVAL);
+            e->carrying = -1;
+            e->health = 100;
+        }
+        if (e->health > 0) r = 2;
+        else { r = -100; d = 1; }
+    } else if (e->task == MWO_SIGN) { /* sign.py:115-128 */
+        if (action == 3) d = 1;   /* move_forward + 1: the custom end-of-episode action (the base class has moved the agent back) */
+        for (int obj = 0; obj < 2; obj++)
+            for (int ci = 0; ci < 3; ci++)
+                if (near_ent(e, &e->boxes[obj * 3 + ci])) { d = 1; r = (double)(ci == (int)e->task_args[1] && obj == (int)e->task_args[2]) * 2 - 1; }
+    } else if (e->task == MWO_SIDEWALK) { /* sidewalk.py:74-87 */
+        if (point_inside(&e->rooms[1], e->agent.pos)) { r = 0; d = 1; }   /* walking into the street ends the episode */
+        if (near_ent(e, &e->boxes[6])) { r += 1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps); d = 1; }
     } else if (near_box(e)) { r += 1.0 - 0.2 * ((double)e->step_count / e->max_episode_steps); d = 1; }
     *reward = r; *done = d;
 }
@@ -1029,6 +1310,14 @@ void mwo_get_state(MwoEnv *e, MwoState *s) {
         memcpy(s->boxes_color[b], e->box_colors[b], 24); s->boxes_size[b] = b < e->n_boxes ? e->box_s[b] : 0;
     }
     s->carrying = e->carrying;
+    for (int b = 0; b < MWO_MAX_BOXES; b++) {
+        const Ent *t = &e->boxes[b];
+        s->ents_kind[b] = t->kind; s->ents_mesh[b] = t->geom; s->ents_alive[b] = b < e->n_boxes ? t->alive : 0; s->ents_static[b] = t->is_static;
+        s->ents_rad_f32[b] = t->rad_f32; s->ents_radius[b] = t->radius; s->ents_height[b] = t->height; s->ents_scale[b] = t->scale;
+        for (int c = 0; c < 8; c++) s->ents_tex[b][c] = t->kind == MWO_ENT_TEXT ? (c < t->n_chars ? t->tex[c] : -1) : (c == 0 && t->kind == MWO_ENT_IMAGE ? t->tex[0] : -1);
+    }
+    for (int k = 0; k <= MWO_MAX_BOXES; k++) s->order[k] = k < e->n_order ? e->order[k] : -1;
+    s->n_order = e->n_order; s->health = e->health; s->num_picked = e->num_picked;
 }
 void mwo_set_counters(MwoEnv *e, long long episode_count, long long task_step_count, int goal_idx) {
     e->episode_count = episode_count; e->task_step_count = task_step_count; e->goal_idx = goal_idx;

@@ -25,7 +25,15 @@ extern "C" {
 #endif
 
 enum { MWO_HALLWAY = 0, MWO_ONEROOM = 1, MWO_FOURROOMS = 2, MWO_MAZE = 3, MWO_TMAZE = 4, MWO_TMAZE_TWOBOX = 5,
-       MWO_SIM2REAL_GOTO = 6, MWO_SIM2REAL_PUSH = 7, MWO_PUTNEXT = 8, MWO_YMAZE = 9 };
+       MWO_SIM2REAL_GOTO = 6, MWO_SIM2REAL_PUSH = 7, MWO_PUTNEXT = 8, MWO_YMAZE = 9,
+       /* tasks with a general entity list (mesh entities, frames; entities that leave or re-enter the list) */
+       MWO_PICKUPOBJS = 10, MWO_ROOMOBJS = 11, MWO_COLLECTHEALTH = 12, MWO_THREEROOMS = 13, MWO_SIGN = 14,
+       MWO_SIDEWALK = 15, MWO_WALLGAP = 16, MWO_NTASKS };
+
+/* entity kinds (reference entity.py): Box 362-408, MeshEnt / Key / Ball 100-146, 410-434, ImageFrame 148-242, TextFrame 244-360 */
+enum { MWO_ENT_BOX = 0, MWO_ENT_MESH = 1, MWO_ENT_IMAGE = 2, MWO_ENT_TEXT = 3 };
+/* mesh geometries: gym_miniworld/meshes/<name>.obj; ball_<c> / key_<c> share one geometry each, the colour is the entity's */
+enum { MWO_MESH_BALL = 0, MWO_MESH_KEY, MWO_MESH_MEDKIT, MWO_MESH_DUCKIE, MWO_MESH_BUILDING, MWO_MESH_CONE, MWO_NMESH };
 
 /* domain parameters, reference params.py:110-123, same order */
 enum {
@@ -34,10 +42,10 @@ enum {
     MWO_P_CAM_FOV_Y, MWO_P_CAM_HEIGHT, MWO_P_CAM_FWD_DISP, MWO_NPARAM
 };
 
-#define MWO_MAX_BOXES 6
+#define MWO_MAX_BOXES 20   /* entity slots besides the agent (CollectHealth has 18) */
 #define MWO_MAX_ROOMS 512
 #define MWO_MAX_PORTALS 2 /* per edge */
-#define MWO_MAX_TEX 32
+#define MWO_MAX_TEX 128
 #define MWO_MAX_LEVELS 12
 
 typedef struct MwoEnv MwoEnv;
@@ -52,6 +60,8 @@ int mwo_set_texture(int tex_id, int width, int height, int n_levels, const uint8
  * SimToRealGoTo {} / SimToRealPush {} (envs/simtorealgoto.py, simtorealpush.py: pass their sim_params table and domain_rand = 1),
  * PutNext {size} (envs/putnext.py: six boxes in COLOR_NAMES order - blue green grey purple red yellow - of random sizes; actions 0..7
  * incl. pickup 4 / drop 5 with the carry physics of miniworld.py:594-702; done when red is next to yellow and nothing is carried).
+ * PickupObjs {size, num_objs}, RoomObjs {size}, CollectHealth {size}, ThreeRooms {}, Sign {size, color_index, goal},
+ * Sidewalk {}, WallGap {} (envs/pickupobjs.py, roomobjs.py, collecthealth.py, threerooms.py, sign.py, sidewalk.py, wallgap.py).
  * params: MWO_NPARAM x 9 doubles (default[3], min[3], max[3]); NULL = reference defaults. */
 MwoEnv *mwo_create(int task, const double *task_args, int max_episode_steps, int domain_rand,
                    const double *params);
@@ -81,7 +91,22 @@ typedef struct {
     /* all boxes in entity-list order (y = pos[1] > 0 while carried), and agent.carrying as a box index or -1 */
     double boxes_pos[MWO_MAX_BOXES][3], boxes_dir[MWO_MAX_BOXES], boxes_color[MWO_MAX_BOXES][3], boxes_size[MWO_MAX_BOXES];
     int carrying;
+    /* general entity list: per slot (= position in the episode's first list) kind, mesh geometry, flags, radius / height / scale;
+     * `order` = the entity list now, as slots (-2 = the agent), n_order entries */
+    int ents_kind[MWO_MAX_BOXES], ents_mesh[MWO_MAX_BOXES], ents_alive[MWO_MAX_BOXES], ents_static[MWO_MAX_BOXES], ents_rad_f32[MWO_MAX_BOXES];
+    double ents_radius[MWO_MAX_BOXES], ents_height[MWO_MAX_BOXES], ents_scale[MWO_MAX_BOXES];
+    int order[MWO_MAX_BOXES + 1], n_order;
+    double health; int num_picked;
+    int ents_tex[MWO_MAX_BOXES][8];   /* ImageFrame: [0] = texture id; TextFrame: one id per character (-1 = space) */
 } MwoState;
+
+/* meshes: global table like the textures.  Arrays as objmesh.py builds them (float32, draw order): verts / norms [n][3][3],
+ * texcs [n][3][2]; tex_id = texture slot of the mesh's image or -1.  The vertex colour (Kd) is the entity's colour. */
+int mwo_set_mesh(int geom, int n_tris, const float *verts, const float *norms, const float *texcs, int tex_id,
+                 const float *min_coords, const float *max_coords);
+/* MeshEnt.__init__ (entity.py:118-127) evaluated by the caller with the reference's expressions and the installed NumPy's
+ * scalar types: scale and radius of geometry `geom` at `height`, and whether they are float32 scalars (NumPy >= 2) */
+int mwo_set_mesh_dims(int geom, double height, double scale, double radius, int is_f32);
 void mwo_get_state(MwoEnv *e, MwoState *out);
 void mwo_set_agent(MwoEnv *e, double x, double z, double dir); /* test hook */
 void mwo_set_step_count(MwoEnv *e, int step_count);

@@ -23,6 +23,8 @@ import types
 import numpy as np
 
 GL_LOG = []          # (name, args) tuples, appended by every gl*/glu* call
+TEX_PATHS = {}       # texture id handed out by the image stand-in -> path of the PNG it was loaded from
+VLISTS = []          # every pyglet.graphics.vertex_list the reference created (mesh chunks), by id
 GL_LOG_ENABLED = [False]
 
 
@@ -221,8 +223,10 @@ def _install_pyglet(reference_root):
     image = types.ModuleType("pyglet.image")
 
     class _Tex:
-        def __init__(self, w, h):
-            self.width, self.height, self.target, self.id = w, h, gl.GL_TEXTURE_2D, 1
+        def __init__(self, w, h, path=None):
+            self.width, self.height, self.target = w, h, gl.GL_TEXTURE_2D
+            self.id = 1 + len(TEX_PATHS)      # a distinct id per loaded image: glBindTexture's argument names the file
+            TEX_PATHS[self.id] = path
 
     class _ImgData:
         def get_data(self, fmt, pitch):
@@ -236,7 +240,7 @@ def _install_pyglet(reference_root):
             self.path = path
 
         def get_texture(self):
-            return _Tex(self.width, self.height)
+            return _Tex(self.width, self.height, self.path)
 
         def get_image_data(self):
             return _ImgData()
@@ -244,7 +248,20 @@ def _install_pyglet(reference_root):
     pyglet.image = image
 
     graphics = types.ModuleType("pyglet.graphics")
-    graphics.vertex_list = lambda *a, **k: None
+
+    class _VertexList:
+        """pyglet.graphics.vertex_list(count, ('v3f', data), ...): keeps the arrays it was given (objmesh.py:190-196); draw()
+        records that it was drawn - the arrays themselves are looked up in VLISTS by the logged id"""
+        def __init__(self, count, *data):
+            self.count = count
+            self.data = {fmt: np.array(arr, dtype=np.float32) for fmt, arr in data}
+            self.uid = len(VLISTS)
+            VLISTS.append(self)
+
+        def draw(self, mode):
+            if GL_LOG_ENABLED[0]:
+                GL_LOG.append(("vlist_draw", (self.uid, mode)))
+    graphics.vertex_list = lambda count, *data: _VertexList(count, *data)
     pyglet.graphics = graphics
 
     for name, mod in [("pyglet", pyglet), ("pyglet.gl", gl), ("pyglet.gl.gl_info", gl_info),
