@@ -226,6 +226,9 @@ struct MwoEnv {
     int order[MWO_MAX_BOXES + 1], n_order; /* self.entities now, as slots (AGENT_SLOT = the agent): PickupObjs removes entries,
                                               CollectHealth moves a respawned kit to the end (collecthealth.py:56-57) */
     double health; int num_picked;          /* CollectHealth.health, PickupObjs.num_picked_up */
+    /* what the reference's step() rendered: the entities as they were after the base step, before the task rule changed the list */
+    double frame_pos[MWO_MAX_BOXES][3], frame_dir[MWO_MAX_BOXES];
+    int frame_alive[MWO_MAX_BOXES], render_step_frame;
     double box_s[MWO_MAX_BOXES]; /* edge length of each box (Box(size=s), entity.py:366-378) */
     double box_colors[MWO_MAX_BOXES][3]; /* Box.color_vec after randomize (entity.py:381-383) */
     int box_base[MWO_MAX_BOXES]; /* index into COLORS (entity.py:8-15) */
@@ -1090,6 +1093,9 @@ void mwo_reset(MwoEnv *e) {
     sample_param(e, dr, MWO_P_CAM_PITCH, &e->cam_pitch);
     sample_param(e, dr, MWO_P_CAM_FOV_Y, &e->cam_fov_y);
     if (!e->static_done) gen_static_data(e);
+    for (int b = 0; b < MWO_MAX_BOXES; b++) {
+        memcpy(e->frame_pos[b], e->boxes[b].pos, sizeof(e->frame_pos[b])); e->frame_dir[b] = e->boxes[b].dir; e->frame_alive[b] = e->boxes[b].alive;
+    }
 }
 
 /* MiniWorldEnv.near, miniworld.py:961-971 */
@@ -1194,6 +1200,9 @@ void mwo_step(MwoEnv *e, int action, double *reward, int *done) {
         carry_pos(e, e->agent.pos, c, cp);
         memcpy(c->pos, cp, sizeof(cp));
         c->dir = e->agent.dir;
+    }
+    for (int b = 0; b < MWO_MAX_BOXES; b++) {   /* obs = self.render_obs() happens here (miniworld.py:705) */
+        memcpy(e->frame_pos[b], e->boxes[b].pos, sizeof(e->frame_pos[b])); e->frame_dir[b] = e->boxes[b].dir; e->frame_alive[b] = e->boxes[b].alive;
     }
     double r = 0; int d = 0;
     if (e->step_count >= e->max_episode_steps) { d = 1; r = 0; }
@@ -1331,6 +1340,9 @@ void mwo_set_box(MwoEnv *e, int b, double x, double z, double dir) {
 }
 void mwo_set_box_y(MwoEnv *e, int b, double y) { e->boxes[b].pos[1] = y; }
 void mwo_set_carrying(MwoEnv *e, int b) { e->carrying = b; }
+/* 1: mwo_render draws the entities as the last step's own frame saw them (PickupObjs removes, CollectHealth respawns an entity
+ * AFTER the frame was rendered, pickupobjs.py:56-69, collecthealth.py:51-64); 0: the current state */
+void mwo_render_step_frame(MwoEnv *e, int on) { e->render_step_frame = on; }
 
 void mwo_get_geometry(MwoEnv *e, double *outline, double *heights, double *portals, int *portal_count, double *segs,
                       double *room_probs, double *qv, double *qn, float *qt, int *qoff, double *ftex, double *ctex, int *tex_ids) {
@@ -1617,6 +1629,68 @@ static int trace_box(const RBox *b, const float *o, const float *d, float *t_out
     return face;
 }
 
+/* ---- mesh entities (MeshEnt.render, entity.py:130-141: glTranslatef(pos) glScalef(scale) glRotatef(dir) mesh.render()) --------
+ * Spec ("meshes"): a sample ray is taken into the mesh's frame - origin lo = R^T (eye - pos) / scale, direction
+ * ld = R^T d / scale, so that the ray parameter stays the world's - and meets front-facing triangles only (GL_CULL_FACE is on,
+ * miniworld.py:498-499): Moeller-Trumbore in float32 with the products written out, e1 = v1 - v0, e2 = v2 - v0 in float32;
+ * det = e1 . (ld x e2) > 0, 0 <= u <= det, v >= 0, u + v <= det, t = (e2 . q) / det > 0; the nearest t wins, the lower triangle
+ * index on a tie (GL_LESS: the first one drawn). */
+typedef struct {
+    float pos[3], c, s, inv_s;     /* translation, cos / sin of the heading, 1 / scale */
+    float lo[3];                   /* the eye in the mesh's frame */
+    float Ll[3];                   /* the light direction in the mesh's frame, divided by the scale: n . Ll = (R n / scale) . L */
+    float kd[3];                   /* vertex colour: the material's Kd */
+    const Mesh *m;
+    double gate_c[3], gate_r2;     /* conservative bounding sphere (world), for the oracle's own speed only */
+} RMesh;
+
+static void cross3f(const float *a, const float *b, float *o) {
+    o[0] = fmaf(a[1], b[2], -(a[2] * b[1])); o[1] = fmaf(a[2], b[0], -(a[0] * b[2])); o[2] = fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+static float dot3f(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+
+static void mesh_local_dir(const RMesh *rm, const float *d, float *ld) {
+    ld[0] = fmaf(d[0], rm->c, -(d[2] * rm->s)) * rm->inv_s; ld[1] = d[1] * rm->inv_s; ld[2] = fmaf(d[0], rm->s, d[2] * rm->c) * rm->inv_s;
+}
+/* one triangle: 1 if the ray (rm->lo, ld) meets its front; ub, vb = u, v (NOT divided by det), det, t */
+static int mesh_tri(const RMesh *rm, int i, const float *ld, float *t_out, float *u_out, float *v_out, float *det_out, int need_inside) {
+    const Mesh *m = rm->m;
+    const float *v0 = m->verts + i * 9, *e1 = m->e1 + i * 3, *e2 = m->e2 + i * 3;
+    float pv[3], qv[3];
+    cross3f(ld, e2, pv);
+    const float det = dot3f(e1, pv);
+    *det_out = det;
+    if (!(det > 0.0f)) return 0;
+    const float tv[3] = {rm->lo[0] - v0[0], rm->lo[1] - v0[1], rm->lo[2] - v0[2]};
+    const float u = dot3f(tv, pv);
+    cross3f(tv, e1, qv);
+    const float v = dot3f(ld, qv);
+    *u_out = u; *v_out = v;
+    if (need_inside && (u < 0.0f || u > det || v < 0.0f || u + v > det)) return 0;
+    const float t = dot3f(e2, qv) / det;
+    *t_out = t;
+    return need_inside ? t > 0.0f : 1;
+}
+/* nearest front-facing triangle along (eye, d): its index or -1 */
+static int trace_mesh(const RMesh *rm, const float *o, const float *d, float *t_out) {
+    {   /* conservative sphere gate in float64 (never rejects a ray that meets the mesh) */
+        double oc[3] = {rm->gate_c[0] - o[0], rm->gate_c[1] - o[1], rm->gate_c[2] - o[2]};
+        double oc2 = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2], b = oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2];
+        double dd = (double)d[0] * d[0] + (double)d[1] * d[1] + (double)d[2] * d[2];
+        if (oc2 > rm->gate_r2 && !(b > 0 && b * b >= dd * (oc2 - rm->gate_r2))) return -1;
+    }
+    float ld[3];
+    mesh_local_dir(rm, d, ld);
+    int best = -1;
+    float bt = INFINITY;
+    for (int i = 0; i < rm->m->n_tris; i++) {
+        float t, u, v, det;
+        if (mesh_tri(rm, i, ld, &t, &u, &v, &det, 1) && t < bt) { bt = t; best = i; }
+    }
+    *t_out = bt;
+    return best;
+}
+
 static void fetch_texel(const Tex *t, int l, int i, int j, float *rgb) {
     const uint8_t *p = t->data + t->level_off[l] + ((size_t)j * t->lw[l] + i) * 4;
     rgb[0] = p[0]; rgb[1] = p[1]; rgb[2] = p[2];
@@ -1710,6 +1784,104 @@ static int surf_texcoord(const RRoom *rr, const Hit *h, const float *o, const fl
     return 1;
 }
 
+/* One shade per (pixel, triangle), attributes evaluated at the PIXEL CENTRE (extrapolated beyond the triangle's edges, as a
+ * multisampling rasteriser without centroid sampling does): lit vertex colours - fixed-function lighting per vertex with the
+ * normal as the modelview matrix leaves it, R n / scale, NOT renormalised (GL_NORMALIZE is off, entity.py:131-141), clamped to 1 -
+ * interpolated with the centre ray's barycentrics u / det, v / det; if the centre ray sees the triangle's back or edge (det <= 0)
+ * the covering sample's own ray is used.  A textured mesh modulates by its image (trilinear, LOD from the +1 pixel neighbours). */
+static void shade_mesh(const RMesh *rm, const Light *L, int tri, const float *dc, const float *dx, const float *dy, const float *ds, float *col) {
+    const Mesh *m = rm->m;
+    float vc[3][3];
+    for (int k = 0; k < 3; k++) {
+        const float *n = m->norms + tri * 9 + k * 3;
+        float ndl = n[0] * rm->Ll[0] + n[1] * rm->Ll[1] + n[2] * rm->Ll[2];
+        if (ndl < 0) ndl = 0;
+        for (int q = 0; q < 3; q++) {
+            float v = (0.2f * rm->kd[q] + L->amb[q] * rm->kd[q]) + ndl * L->diff[q] * rm->kd[q];
+            vc[k][q] = v > 1.0f ? 1.0f : v;
+        }
+    }
+    float ld[3], t, u, v, det, ub, vb;
+    mesh_local_dir(rm, dc, ld);
+    int centre_ok = mesh_tri(rm, tri, ld, &t, &u, &v, &det, 0);
+    if (!centre_ok) { mesh_local_dir(rm, ds, ld); mesh_tri(rm, tri, ld, &t, &u, &v, &det, 0); }
+    ub = u / det; vb = v / det;
+    for (int q = 0; q < 3; q++) col[q] = fmaf(vb, vc[2][q] - vc[0][q], fmaf(ub, vc[1][q] - vc[0][q], vc[0][q]));
+    if (m->tex_id >= 0) {
+        const float *tc = m->texcs + tri * 6;
+        float s0 = fmaf(vb, tc[4] - tc[0], fmaf(ub, tc[2] - tc[0], tc[0])), t0 = fmaf(vb, tc[5] - tc[1], fmaf(ub, tc[3] - tc[1], tc[1]));
+        float s1 = s0, t1 = t0, s2 = s0, t2 = t0;
+        int valid = 0;
+        if (centre_ok) {
+            float l1[3], l2[3], tt, u1, v1, d1, u2, v2, d2;
+            mesh_local_dir(rm, dx, l1); mesh_local_dir(rm, dy, l2);
+            const int ok1 = mesh_tri(rm, tri, l1, &tt, &u1, &v1, &d1, 0), ok2 = mesh_tri(rm, tri, l2, &tt, &u2, &v2, &d2, 0);
+            valid = ok1 && ok2;
+            if (valid) {
+                u1 /= d1; v1 /= d1; u2 /= d2; v2 /= d2;
+                s1 = fmaf(v1, tc[4] - tc[0], fmaf(u1, tc[2] - tc[0], tc[0])); t1 = fmaf(v1, tc[5] - tc[1], fmaf(u1, tc[3] - tc[1], tc[1]));
+                s2 = fmaf(v2, tc[4] - tc[0], fmaf(u2, tc[2] - tc[0], tc[0])); t2 = fmaf(v2, tc[5] - tc[1], fmaf(u2, tc[3] - tc[1], tc[1]));
+            }
+        }
+        float texel[3];
+        sample_texture(m->tex_id, s0, t0, s1, t1, s2, t2, valid, texel);
+        for (int q = 0; q < 3; q++) col[q] = col[q] * (texel[q] * (1.0f / 255.0f));
+    }
+}
+
+/* ---- ImageFrame / TextFrame (entity.py:148-360): a slab [0, depth] x [-h/2, h/2] x [-w/2, w/2] in the frame's axes whose +x face
+ * shows the picture (or one texture per character, a space is plain white), whose +-y and +-z faces are black and whose -x face
+ * (against the wall) does not exist; front faces only.  Hit codes: 0 .. n_chars-1 the front's character cell, 100 a black side. */
+typedef struct { float pos[3], c, s, sx, hy, hz, cw, lit_front[3]; int n_chars, tex[8]; } RFrame;
+static int frame_cell(const RFrame *f, float z) {   /* character index of local z on the front: cell i spans [hz - cw (i + 1), hz - cw i] */
+    int i = (int)floorf((f->hz - z) / f->cw);
+    return i < 0 ? 0 : (i >= f->n_chars ? f->n_chars - 1 : i);
+}
+static int trace_frame(const RFrame *f, const float *o, const float *d, float *t_out) {
+    float ro[3] = {o[0] - f->pos[0], o[1] - f->pos[1], o[2] - f->pos[2]};
+    float lo_[3] = {ro[0] * f->c - ro[2] * f->s, ro[1], ro[0] * f->s + ro[2] * f->c};
+    float ld[3] = {fmaf(d[0], f->c, -(d[2] * f->s)), d[1], fmaf(d[0], f->s, d[2] * f->c)};
+    float lo[3] = {0.0f, -f->hy, -f->hz}, hi[3] = {f->sx, f->hy, f->hz};
+    float tn = -INFINITY, tf = INFINITY; int face = -1;
+    for (int a = 0; a < 3; a++) {
+        if (ld[a] == 0) { if (lo_[a] < lo[a] || lo_[a] > hi[a]) return -1; continue; }
+        float inv = 1.0f / ld[a];
+        float t1 = (lo[a] - lo_[a]) * inv, t2 = (hi[a] - lo_[a]) * inv;
+        float tmin = t1 < t2 ? t1 : t2, tmax = t1 < t2 ? t2 : t1;
+        if (tmin > tn) { tn = tmin; face = a * 2 + (ld[a] > 0 ? 0 : 1); }
+        if (tmax < tf) tf = tmax;
+    }
+    if (face < 0 || !(tn <= tf) || !(tn > 0)) return -1;
+    if (face == 0) return -1;   /* entered through the -x face: it is not drawn, and the inner faces are culled */
+    *t_out = tn;
+    if (face != 1) return 100;
+    return frame_cell(f, fmaf(tn, ld[2], lo_[2]));
+}
+static int frame_front_tc(const RFrame *f, int cell, const float *o, const float *d, float *s, float *t) {
+    float ro[3] = {o[0] - f->pos[0], o[1] - f->pos[1], o[2] - f->pos[2]};
+    float lo_[3] = {ro[0] * f->c - ro[2] * f->s, ro[1], ro[0] * f->s + ro[2] * f->c};
+    float ld[3] = {fmaf(d[0], f->c, -(d[2] * f->s)), d[1], fmaf(d[0], f->s, d[2] * f->c)};
+    if (ld[0] == 0) return 0;
+    float tt = (f->sx - lo_[0]) / ld[0];
+    if (!(tt > 0)) return 0;
+    float y = fmaf(tt, ld[1], lo_[1]), z = fmaf(tt, ld[2], lo_[2]);
+    float z1 = f->hz - f->cw * (float)cell;          /* the cell's right edge: texcoord 0 (glTexCoord2f(0, *) at z_1) */
+    *s = (z1 - z) / f->cw; *t = (y + f->hy) / (2.0f * f->hy);
+    return 1;
+}
+static void shade_frame(const RFrame *f, int code, const float *o, const float *dc, const float *dx, const float *dy, const float *ds, float *col) {
+    if (code >= 100) { col[0] = col[1] = col[2] = 0.0f; return; }   /* glColor3f(0, 0, 0): lit black is black */
+    const int tex = f->tex[code];
+    if (tex < 0) { col[0] = f->lit_front[0]; col[1] = f->lit_front[1]; col[2] = f->lit_front[2]; return; }   /* a space: texturing off */
+    float s0 = 0, t0 = 0, s1 = 0, t1 = 0, s2 = 0, t2 = 0;
+    int valid = 1;
+    if (!frame_front_tc(f, code, o, dc, &s0, &t0)) { frame_front_tc(f, code, o, ds, &s0, &t0); valid = 0; s1 = s2 = s0; t1 = t2 = t0; }
+    else valid = frame_front_tc(f, code, o, dx, &s1, &t1) && frame_front_tc(f, code, o, dy, &s2, &t2);
+    float texel[3];
+    sample_texture(tex, s0, t0, s1, t1, s2, t2, valid, texel);
+    for (int q = 0; q < 3; q++) col[q] = f->lit_front[q] * (texel[q] * (1.0f / 255.0f));
+}
+
 void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
     const int poly = e->task == MWO_YMAZE;   /* rooms with arbitrary edges: the polygon formulation */
     RRoom *rr = (RRoom *)malloc(sizeof(RRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));   /* per call: thread-safe */
@@ -1743,9 +1915,49 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
     { static const float wn[4][3] = {{-1, 0, 0}, {0, 0, 1}, {1, 0, 0}, {0, 0, -1}};
       for (int k = 0; k < 4; k++) lit_color(&L, wn[k], white, lit_wall[k]); }
     RBox bxs[MWO_MAX_BOXES];
+    RMesh rms[MWO_MAX_BOXES];
+    RFrame rfs[MWO_MAX_BOXES];
+    int ekind[MWO_MAX_BOXES];   /* what to draw for slot b: -1 nothing (left the list), else MWO_ENT_* */
     float lit_boxes[MWO_MAX_BOXES][6][3];
     for (int b = 0; b < e->n_boxes; b++) {
-        const Ent *be = &e->boxes[b];
+        Ent frame_ent = e->boxes[b];
+        if (e->render_step_frame) {   /* the frame the reference's step() renders: BEFORE the task rule removes / respawns an entity */
+            memcpy(frame_ent.pos, e->frame_pos[b], sizeof(frame_ent.pos)); frame_ent.dir = e->frame_dir[b]; frame_ent.alive = e->frame_alive[b];
+        }
+        const Ent *be = &frame_ent;
+        ekind[b] = be->alive ? be->kind : -1;
+        if (ekind[b] == MWO_ENT_MESH) {
+            RMesh *rm = &rms[b];
+            rm->m = &g_mesh[be->geom];
+            if (!rm->m->n_tris) fail("mesh not loaded (mwo_set_mesh)");
+            for (int k = 0; k < 3; k++) { rm->pos[k] = (float)be->pos[k]; rm->kd[k] = (float)e->box_colors[b][k]; }
+            rm->c = (float)cos(be->dir); rm->s = (float)sin(be->dir); rm->inv_s = (float)(1.0 / be->scale);
+            const float ro[3] = {c.eye[0] - rm->pos[0], c.eye[1] - rm->pos[1], c.eye[2] - rm->pos[2]};
+            rm->lo[0] = (ro[0] * rm->c - ro[2] * rm->s) * rm->inv_s; rm->lo[1] = ro[1] * rm->inv_s; rm->lo[2] = (ro[0] * rm->s + ro[2] * rm->c) * rm->inv_s;
+            rm->Ll[0] = (L.light_dir[0] * rm->c - L.light_dir[2] * rm->s) * rm->inv_s; rm->Ll[1] = L.light_dir[1] * rm->inv_s;
+            rm->Ll[2] = (L.light_dir[0] * rm->s + L.light_dir[2] * rm->c) * rm->inv_s;
+            double lc[3], ext2 = 0;   /* bounding sphere of the mesh's box, 5 % larger */
+            for (int k = 0; k < 3; k++) { lc[k] = 0.5 * ((double)rm->m->min_c[k] + rm->m->max_c[k]); double h = 0.5 * ((double)rm->m->max_c[k] - rm->m->min_c[k]); ext2 += h * h; }
+            const double cd_ = cos(be->dir), sd_ = sin(be->dir);
+            rm->gate_c[0] = be->pos[0] + be->scale * (lc[0] * cd_ + lc[2] * sd_);
+            rm->gate_c[1] = be->pos[1] + be->scale * lc[1];
+            rm->gate_c[2] = be->pos[2] + be->scale * (-lc[0] * sd_ + lc[2] * cd_);
+            rm->gate_r2 = ext2 * be->scale * be->scale * 1.05 * 1.05;
+            continue;
+        }
+        if (ekind[b] == MWO_ENT_IMAGE || ekind[b] == MWO_ENT_TEXT) {
+            RFrame *rf = &rfs[b];
+            for (int k = 0; k < 3; k++) rf->pos[k] = (float)be->pos[k];
+            rf->c = (float)cos(be->dir); rf->s = (float)sin(be->dir);
+            rf->sx = (float)be->frame_d; rf->hy = (float)(be->frame_h / 2); rf->hz = (float)(be->frame_w / 2);
+            rf->n_chars = ekind[b] == MWO_ENT_TEXT ? be->n_chars : 1;
+            rf->cw = ekind[b] == MWO_ENT_TEXT ? (float)be->frame_h : (float)be->frame_w;   /* char_width = self.height (entity.py:303) */
+            for (int k = 0; k < 8; k++) rf->tex[k] = be->tex[k];
+            float n[3] = {rf->c, 0.0f, -rf->s};   /* the front's normal (1, 0, 0) turned by the heading */
+            lit_color(&L, n, white, rf->lit_front);
+            continue;
+        }
+        if (ekind[b] != MWO_ENT_BOX) continue;
         RBox bx;
         float bcol[3];
         for (int k = 0; k < 3; k++) { bx.pos[k] = (float)be->pos[k]; bcol[k] = (float)e->box_colors[b][k]; }
@@ -1782,9 +1994,18 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
                 float d[3];
                 make_ray(&c, cx + SAMPLE_X[k] * 0.0625f, cy + SAMPLE_Y[k] * 0.0625f, d);
                 hits[k] = poly ? trace_rooms_poly(pr, n_rooms, cam_room, c.eye, d) : trace_rooms(rr, n_rooms, cam_room, c.eye, d);
-                for (int b = 0; b < e->n_boxes; b++) { /* entity order; a later box wins only when strictly nearer */
-                    float tb; int fc = trace_box(&bxs[b], c.eye, d, &tb);
-                    if (fc >= 0 && tb < hits[k].t) { hits[k].kind = 4; hits[k].t = tb; hits[k].room = b; hits[k].side = fc; }
+                for (int b = 0; b < e->n_boxes; b++) { /* slot order; a later entity wins only when strictly nearer */
+                    float tb;
+                    if (ekind[b] == MWO_ENT_BOX) {
+                        int fc = trace_box(&bxs[b], c.eye, d, &tb);
+                        if (fc >= 0 && tb < hits[k].t) { hits[k].kind = 4; hits[k].t = tb; hits[k].room = b; hits[k].side = fc; }
+                    } else if (ekind[b] == MWO_ENT_MESH) {
+                        int tri = trace_mesh(&rms[b], c.eye, d, &tb);
+                        if (tri >= 0 && tb < hits[k].t) { hits[k].kind = 5; hits[k].t = tb; hits[k].room = b; hits[k].side = tri; }
+                    } else if (ekind[b] == MWO_ENT_IMAGE || ekind[b] == MWO_ENT_TEXT) {
+                        int fc = trace_frame(&rfs[b], c.eye, d, &tb);
+                        if (fc >= 0 && tb < hits[k].t) { hits[k].kind = 6; hits[k].t = tb; hits[k].room = b; hits[k].side = fc; }
+                    }
                 }
             }
             float dc[3], dx[3], dy[3];
@@ -1800,6 +2021,14 @@ void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
                 const Hit *h = &hits[k];
                 if (h->kind == 0) { col[0] = L.sky[0]; col[1] = L.sky[1]; col[2] = L.sky[2]; }
                 else if (h->kind == 4) { const float *lb = lit_boxes[h->room][h->side]; col[0] = lb[0]; col[1] = lb[1]; col[2] = lb[2]; }
+                else if (h->kind == 5) {
+                    float ds[3]; make_ray(&c, cx + SAMPLE_X[k] * 0.0625f, cy + SAMPLE_Y[k] * 0.0625f, ds);
+                    shade_mesh(&rms[h->room], &L, h->side, dc, dx, dy, ds, col);
+                }
+                else if (h->kind == 6) {
+                    float ds[3]; make_ray(&c, cx + SAMPLE_X[k] * 0.0625f, cy + SAMPLE_Y[k] * 0.0625f, ds);
+                    shade_frame(&rfs[h->room], h->side, c.eye, dc, dx, dy, ds, col);
+                }
                 else {
                     float s0 = 0, t0 = 0, s1 = 0, t1 = 0, s2 = 0, t2 = 0;
                     int tex;

@@ -113,6 +113,7 @@ void mwo_set_step_count(MwoEnv *e, int step_count);
 void mwo_set_box(MwoEnv *e, int box /* index in the entity list */, double x, double z, double dir); /* test hook */
 void mwo_set_box_y(MwoEnv *e, int box, double y);
 void mwo_set_carrying(MwoEnv *e, int box /* or -1 */);
+void mwo_render_step_frame(MwoEnv *e, int on); /* 1: render the entities as the last step's own frame saw them (before the task rule) */
 int mwo_intersect_ent(MwoEnv *e, int ent_index /* -1 nobody, 0..B-1 box, B agent */, double x, double z, double radius);
 void mwo_set_counters(MwoEnv *e, long long episode_count, long long task_step_count, int goal_idx); /* test hook */
 /* geometry dumps (sizes from MwoState): outline R*4*2, heights R, portals R*4*MAXP*4 (nan pad),

@@ -223,3 +223,156 @@ def render_stream(g, textures, W=80, H=60, ortho=False):
         acc[idx] += cnt[idx][:, None] * col
     img = np.clip(acc / 8.0, 0, 1)
     return np.floor(img * 255 + 0.5).astype(np.uint8).reshape(H, W, 3)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Entity tasks (tests/golden/gen_fixtures_ents.py streams): rooms + glBegin polygons (boxes, image / text frames) + mesh draws
+# (pyglet vertex lists: per-vertex normals and colours -> smooth shading).  Same brute force, vectorised over blocks of polygons.
+def _xform(ops):
+    """glTranslatef / glScalef / glRotatef(a, 0, 1, 0) in call order -> (M 3x3, T 3): v_world = M v + T"""
+    M, T = np.eye(3), np.zeros(3)
+    for op in ops:
+        if op[0] == "translate":
+            T = T + M @ np.array(op[1:4])
+        elif op[0] == "scale":
+            M = M @ np.diag(op[1:4])
+        else:
+            assert op[2:5] == [0.0, 1.0, 0.0]
+            M = M @ _roty(op[1])
+    return M, T
+
+
+def _lit(normals, colors, Ldir, amb, dif):
+    ndl = np.maximum(normals @ Ldir, 0.0)[:, None]
+    return np.minimum(1.0, 0.2 * colors + amb[None] * colors + ndl * dif[None] * colors)
+
+
+def ent_stream_triangles(g, mesh_arrays):
+    """-> list of dicts: verts (n, 3) world, vcol (n, 3) lit vertex colours, texcs (n, 2) or None, tex name or None.
+    mesh_arrays: mesh name -> (verts, norms, texcs, colors) float32 [F, 3, *] as handed to pyglet (pinned by meshes.json).
+    Vertex lighting is OpenGL's fixed function: eye-space normal = inverse-transpose(modelview) n, NOT renormalised (GL_NORMALIZE
+    off): for M = R * scale that is R n / scale."""
+    Lp = np.array(g["lights"]["GL_POSITION"])
+    assert Lp[3] == 0.0
+    Ldir = _norm(Lp[:3])
+    amb, dif = np.array(g["lights"]["GL_AMBIENT"][:3]), np.array(g["lights"]["GL_DIFFUSE"][:3])
+    out = []
+    for p in polygons_from_stream({"polys": g["room_polys"], "room_tex": g["room_tex"]}):
+        n = len(p["verts"])
+        col = _lit(np.broadcast_to(p["normal"], (n, 3)), np.broadcast_to(p["color"], (n, 3)), Ldir, amb, dif)
+        out.append({"verts": p["verts"], "vcol": col, "texcs": p["texcs"], "tex": p["tex"]})
+    for it in g["static_items"] + g["dynamic_items"]:
+        M, T = _xform(it["xform"])
+        Nmat = np.linalg.inv(M).T
+        if it["type"] == "poly":
+            verts = np.array(it["verts"], float) @ M.T + T
+            norms = np.array(it["norms"], float) @ Nmat.T
+            cols = _lit(norms, np.array(it["colors"], float), Ldir, amb, dif)
+            texcs = np.array(it["texcs"], float) if it["tex_on"] else None
+            n_per = {"GL_QUADS": 4, "GL_TRIANGLES": 3}[it["mode"]]
+            for k in range(0, len(verts), n_per):
+                out.append({"verts": verts[k:k + n_per], "vcol": cols[k:k + n_per], "texcs": None if texcs is None else texcs[k:k + n_per],
+                            "tex": it["tex"] if it["tex_on"] else None})
+        else:
+            v, nr, tc, cl = mesh_arrays[it["mesh"]]
+            assert it["mode"] == "GL_TRIANGLES" and it["chunk"] == 0
+            F = v.shape[0]
+            verts = v.reshape(-1, 3).astype(float) @ M.T + T
+            cols = _lit(nr.reshape(-1, 3).astype(float) @ Nmat.T, cl.reshape(-1, 3).astype(float), Ldir, amb, dif)
+            for k in range(F):
+                out.append({"verts": verts[3 * k:3 * k + 3], "vcol": cols[3 * k:3 * k + 3], "texcs": tc[k].astype(float) if it["tex_on"] else None,
+                            "tex": it["tex"] if it["tex_on"] else None})
+    return out
+
+
+def render_ent_stream(g, textures, mesh_arrays, W=80, H=60, block=256):
+    """textures: name -> mip levels (row 0 = bottom).  8 samples per pixel, nearest front-facing polygon (winding), one shade per
+    (pixel, polygon) with the attributes interpolated at the PIXEL CENTRE (barycentric on the polygon's plane, extrapolated); where
+    the centre ray sees the polygon's back, at the first covering sample instead."""
+    polys = ent_stream_triangles(g, mesh_arrays)
+    fovy, aspect, _, _ = g["misc"]["gluPerspective"]
+    la = g["misc"]["gluLookAt"]
+    eye, center, up = np.array(la[0:3]), np.array(la[3:6]), np.array(la[6:9])
+    f = _norm(center - eye)
+    s_ = _norm(np.cross(f, up))
+    u_ = np.cross(s_, f)
+    th = np.tan(np.radians(fovy) / 2)
+    tw = th * aspect
+    sky = np.array(g["misc"]["glClearColor"][:3])
+
+    def rays(wx, wy):
+        return f[None] + s_[None] * ((2 * wx / W - 1) * tw)[:, None] + u_[None] * ((2 * wy / H - 1) * th)[:, None]
+    py, px = np.mgrid[0:H, 0:W]
+    cx, cy = (px + 0.5).ravel(), (H - 1 - py + 0.5).ravel()
+    npx = W * H
+    best_t = np.full((8, npx), np.inf)
+    best_p = np.full((8, npx), -1)
+    # triangles (fans of the quads / polygons) in blocks: Moeller-Trumbore in float64
+    tri_v0, tri_e1, tri_e2, tri_owner = [], [], [], []
+    for pi, p in enumerate(polys):
+        v = p["verts"]
+        for k in range(1, len(v) - 1):
+            tri_v0.append(v[0]); tri_e1.append(v[k] - v[0]); tri_e2.append(v[k + 1] - v[0]); tri_owner.append(pi)
+    tri_v0, tri_e1, tri_e2, tri_owner = np.array(tri_v0), np.array(tri_e1), np.array(tri_e2), np.array(tri_owner)
+    for k in range(8):
+        d = rays(cx + SAMPLE_X[k], cy + SAMPLE_Y[k])            # [P, 3]
+        for b0 in range(0, len(tri_owner), block):
+            v0, e1, e2, own = tri_v0[b0:b0 + block], tri_e1[b0:b0 + block], tri_e2[b0:b0 + block], tri_owner[b0:b0 + block]
+            pv = np.cross(d[None, :, :], e2[:, None, :])          # [B, P, 3]
+            det = np.einsum("bk,bpk->bp", e1, pv)
+            tv = eye[None] - v0                                    # [B, 3]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                u = np.einsum("bk,bpk->bp", tv, pv) / det
+                qv = np.cross(tv, e1)                              # [B, 3]
+                vv = (d @ qv.T).T / det
+                t = np.einsum("bk,bk->b", e2, qv)[:, None] / det
+            ok = (det > 0) & (u >= -1e-12) & (vv >= -1e-12) & (u + vv <= 1 + 1e-12) & (t > 0)
+            t = np.where(ok, t, np.inf)
+            j = np.argmin(t, axis=0)
+            tb = t[j, np.arange(npx)]
+            better = tb < best_t[k]
+            best_t[k] = np.where(better, tb, best_t[k])
+            best_p[k] = np.where(better, own[j], best_p[k])
+    acc = (best_p == -1).sum(axis=0)[:, None] * sky[None]
+    dc, dx, dy = rays(cx, cy), rays(cx + 1, cy), rays(cx, cy + 1)
+    first_k = np.argmax(best_p[:, None, :] == best_p[None, :, :], axis=0)   # [8, P]: first sample with the same polygon
+    for pi in np.unique(best_p[best_p >= 0]):
+        p = polys[pi]
+        hit = best_p == pi
+        cnt = hit.sum(axis=0)
+        idx = np.nonzero(cnt)[0]
+        v = p["verts"]
+        e1, e2 = v[1] - v[0], v[-1] - v[0]
+        ng = np.cross(e1, v[2] - v[0])
+        kfirst = np.argmax(hit[:, idx], axis=0)
+        ds = rays(cx[idx] + SAMPLE_X[kfirst], cy[idx] + SAMPLE_Y[kfirst])
+        M2 = np.array([[e1 @ e1, e1 @ e2], [e1 @ e2, e2 @ e2]])
+
+        def bary(d):
+            den = d @ ng
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = ((v[0] - eye) @ ng) / den
+            P = eye[None] + t[:, None] * d - v[0][None]
+            ab = np.linalg.solve(M2, np.stack([P @ e1, P @ e2]))
+            return ab, den < 0
+        ab0, front0 = bary(dc[idx])
+        abs_, _ = bary(ds)
+        ab = np.where(front0[None], ab0, abs_)
+        interp = lambda A: A[0][None] + ab[0][:, None] * (A[1] - A[0])[None] + ab[1][:, None] * (A[-1] - A[0])[None]  # noqa: E731
+        col = interp(p["vcol"])
+        if p["tex"] is not None:
+            levels = textures[p["tex"]]
+            h0, w0 = levels[0].shape[:2]
+            tc = p["texcs"]
+            st0 = interp(tc)
+            abx, fx = bary(dx[idx])
+            aby, fy = bary(dy[idx])
+            stx = tc[0][None] + abx[0][:, None] * (tc[1] - tc[0])[None] + abx[1][:, None] * (tc[-1] - tc[0])[None]
+            sty = tc[0][None] + aby[0][:, None] * (tc[1] - tc[0])[None] + aby[1][:, None] * (tc[-1] - tc[0])[None]
+            r1 = ((stx[:, 0] - st0[:, 0]) * w0) ** 2 + ((stx[:, 1] - st0[:, 1]) * h0) ** 2
+            r2 = ((sty[:, 0] - st0[:, 0]) * w0) ** 2 + ((sty[:, 1] - st0[:, 1]) * h0) ** 2
+            rho2 = np.where(front0 & fx & fy, np.maximum(r1, r2), np.inf)
+            col = col * _trilinear(levels, st0[:, 0], st0[:, 1], rho2) / 255.0
+        acc[idx] += cnt[idx][:, None] * col
+    img = np.clip(acc / 8.0, 0, 1)
+    return np.floor(img * 255 + 0.5).astype(np.uint8).reshape(H, W, 3)

@@ -26,10 +26,10 @@ def make_pair(O, n, seed, dr, depth=False, layout="HWC", **kw):
 def assert_putnext_state_equal(st, envs, tag=""):
     os_ = [e.state() for e in envs]
     arr = lambda f: np.array([f(s) for s in os_])   # noqa: E731
-    assert np.array_equal(st["boxes_pos"], arr(lambda s: np.array(s.boxes_pos))), (tag, "boxes_pos")
-    assert np.array_equal(st["boxes_dir"], arr(lambda s: list(s.boxes_dir))), (tag, "boxes_dir")
-    assert np.array_equal(st["boxes_color"], arr(lambda s: np.array(s.boxes_color))), (tag, "boxes_color")
-    assert np.array_equal(st["boxes_size"], arr(lambda s: list(s.boxes_size))), (tag, "boxes_size")
+    assert np.array_equal(st["boxes_pos"], arr(lambda s: np.array(s.boxes_pos)[:6])), (tag, "boxes_pos")
+    assert np.array_equal(st["boxes_dir"], arr(lambda s: list(s.boxes_dir)[:6])), (tag, "boxes_dir")
+    assert np.array_equal(st["boxes_color"], arr(lambda s: np.array(s.boxes_color)[:6])), (tag, "boxes_color")
+    assert np.array_equal(st["boxes_size"], arr(lambda s: list(s.boxes_size)[:6])), (tag, "boxes_size")
     assert np.array_equal(st["carrying"], arr(lambda s: s.carrying)), (tag, "carrying")
     assert np.array_equal(st["agent_pos"], arr(lambda s: list(s.agent_pos))) and np.array_equal(st["agent_dir"], arr(lambda s: s.agent_dir)), (tag, "pose")
     assert np.array_equal(st["cam"], arr(lambda s: [s.cam_height, s.cam_fwd_disp, s.cam_pitch, s.cam_fov_y])), (tag, "cam")

@@ -149,7 +149,7 @@ def test_putnext_frame_with_a_carried_box(oracle_mod, dr):
         env.step(int(a))
     s = env.state()
     assert s.carrying == g["carrying"] >= 0 and s.n_boxes == 6
-    assert np.array_equal(np.array(s.boxes_pos), np.array(g["boxes_pos"])) and list(s.boxes_dir) == g["boxes_dir"]
+    assert np.array_equal(np.array(s.boxes_pos)[:6], np.array(g["boxes_pos"])) and list(s.boxes_dir)[:6] == g["boxes_dir"]
     assert np.array(s.boxes_pos)[s.carrying, 1] > 0.3
     polys = g["polys"]
     assert len(polys) == 3 + 6
