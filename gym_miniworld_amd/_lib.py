@@ -16,11 +16,16 @@ STACK_FUSED = 32     # MWB_STACK_FUSED
 STACK_SLACK_FRAMES = 8   # MWB_STACK_SLACK_FRAMES
 ROOM_WORDS = 24
 POLY_ROOM_WORDS = 52   # MWB_TASK_YMAZE (include/miniworld_batch.h)
-ABI_VERSION = 4
+ABI_VERSION = 5
 MT_WORDS = 625
 
 TASK_IDS = {"Hallway": 0, "OneRoom": 1, "FourRooms": 2, "Maze": 3, "TMaze": 4, "TMazeTwoBox": 5,
-            "SimToRealGoTo": 6, "SimToRealPush": 7, "PutNext": 8, "YMaze": 9}
+            "SimToRealGoTo": 6, "SimToRealPush": 7, "PutNext": 8, "YMaze": 9,
+            "PickupObjs": 10, "RoomObjs": 11, "CollectHealth": 12, "ThreeRooms": 13, "Sign": 14, "Sidewalk": 15, "WallGap": 16}
+ENT_TASK_FIRST = 10      # MWB_TASK_PICKUPOBJS: the tasks with a general entity list
+MAX_ENTS = 20            # MWB_MAX_ENTS
+MESH_GEOMS = ["ball", "key", "medkit", "duckie", "building", "cone"]   # MWB_MESH_*
+TEX_MESH0, TEX_CHAR0 = 21, 25
 LAYOUT_HWC, LAYOUT_CWH = 0, 1
 
 
@@ -50,7 +55,8 @@ class MwbState(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "agent_pos", "agent_dir", "box_pos", "box_dir", "box_color", "box_size", "cam", "sky_color", "light_pos",
         "light_color", "light_ambient", "step_count", "rng_pos", "rng_keysum", "n_rooms", "n_segs",
-        "goal_idx", "episode_count", "task_step_count", "goal_dist", "rng_state", "carrying")]
+        "goal_idx", "episode_count", "task_step_count", "goal_dist", "rng_state", "carrying",
+        "ent_meta", "ent_radius", "ent_height", "ent_scale", "ent_order", "task_f", "task_i", "text_tex")]
 
 
 EXPORTS = [
@@ -58,6 +64,7 @@ EXPORTS = [
     "mwb_step", "mwb_render", "mwb_get_outputs", "mwb_get_state", "mwb_set_agent", "mwb_intersect",
     "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read", "mwb_stack_enable", "mwb_stack_update", "mwb_stack_window", "mwb_check", "mwb_seed_key",
     "mwb_set_task_state", "mwb_set_domain_rand", "mwb_num_textures", "mwb_debug_wg_times", "mwb_set_state", "mwb_num_boxes", "mwb_room_words", "mwb_step_i64", "mwb_render_top_view", "mwb_visible_ents",
+    "mwb_set_mesh", "mwb_set_mesh_dims",
 ]
 
 _lib = None
@@ -84,6 +91,8 @@ def load():
     L.mwb_create.argtypes = [ctypes.POINTER(MwbConfig), ctypes.POINTER(vp)]
     L.mwb_destroy.argtypes = [vp]
     L.mwb_set_texture.argtypes = [vp, i32, i32, i32, vp]
+    L.mwb_set_mesh.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp]
+    L.mwb_set_mesh_dims.argtypes = [vp, i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, i32]
     L.mwb_seed.argtypes = [vp, vp]
     L.mwb_reset.argtypes = [vp, vp, vp]
     L.mwb_step.argtypes = [vp, vp, vp, vp]

@@ -16,8 +16,24 @@ TEX_FILES = ["floor_tiles_bw_1", "concrete_1", "concrete_2", "concrete_3", "conc
              "brick_wall_1",
              # the sim-to-real rinks' choices (envs/simtorealgoto.py:52-66); uploaded only for those tasks
              "cardboard_1", "cardboard_2", "cardboard_3", "cardboard_4", "wood_1", "wood_2", "wood_planks_1",
-             "drywall_1", "stucco_1", "ceiling_tiles_1"]
+             "drywall_1", "stucco_1", "ceiling_tiles_1",
+             # the tasks with mesh entities / frames: room textures, the ImageFrame's picture, the images of the textured meshes, and
+             # for Sign nine variants of each character of its words (Texture.get probes <name>_1 .. _9, opengl.py:50-58)
+             "asphalt_1", "slime_1", "cinder_blocks_1", "logo_mila_1",
+             "../meshes/medkit", "../meshes/duckie", "../meshes/building", "../meshes/cone"] + \
+            ["chars/ch_0x%d_%d" % (ord(c), v) for c in "BLUERDGN" for v in range(1, 10)]
 TEX_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "textures")
+# (mesh geometry, height) pairs each entity task builds: Ball(size) / Key 0.35 / BigKey 0.6 (entity.py:410-434, sign.py:9-20), MeshEnt(...)
+TASK_MESHES = {"PickupObjs": [("ball", 0.9), ("key", 0.35)], "RoomObjs": [("ball", 0.9), ("key", 0.35)], "CollectHealth": [("medkit", 0.40)],
+               "ThreeRooms": [("duckie", 0.25), ("key", 0.35), ("ball", 0.6)], "Sign": [("key", 0.6)],
+               "Sidewalk": [("building", 30), ("cone", 0.75)], "WallGap": [("building", 30)]}
+
+
+def _sign_params():   # Sign.__init__, sign.py:62-64
+    p = DEFAULT_PARAMS.no_random()
+    p.set("forward_step", 0.7)
+    p.set("turn_step", 45)
+    return p
 
 # registered ids of the reference (envs/__init__.py:43-49) that this package covers:
 # id -> (task, task_args, max_episode_steps or 0 for the class default, params override)
@@ -57,6 +73,13 @@ ENV_SPECS = {
     "MiniWorld-YMaze-v0": ("YMaze", [0, 0, 0], 0, None, None),
     "MiniWorld-YMazeLeft-v0": ("YMaze", [1, 3.9, -7.0], 0, None, None),    # ymaze.py:96-98
     "MiniWorld-YMazeRight-v0": ("YMaze", [1, 3.9, 7.0], 0, None, None),    # ymaze.py:100-102
+    # a general entity list: mesh entities (Ball, Key, MeshEnt), frames, entities leaving / re-entering the list
+    "MiniWorld-PickupObjs-v0": ("PickupObjs", [12, 5], 0, None, None),         # pickupobjs.py:13-22
+    "MiniWorld-RoomObjs-v0": ("RoomObjs", [10], 0, None, None),                # roomobjs.py:14-21
+    "MiniWorld-CollectHealth-v0": ("CollectHealth", [16], 0, None, None),      # collecthealth.py:19-26
+    "MiniWorld-Sign-v0": ("Sign", [10, 0, 0], 0, _sign_params, False),         # sign.py:41-71: its own params, domain_rand forced off
+    "MiniWorld-Sidewalk-v0": ("Sidewalk", [], 0, None, None),
+    "MiniWorld-WallGap-v0": ("WallGap", [], 0, None, None),
 }
 
 
@@ -132,6 +155,8 @@ class BatchedMiniWorld:
         _lib.check(self.L.mwb_create(ctypes.byref(cfg), ctypes.byref(h)))
         self.h = h
         self._load_textures()
+        if task in TASK_MESHES:
+            self._load_meshes(task)
         out = _lib.MwbOutputs()
         _lib.check(self.L.mwb_get_outputs(self.h, ctypes.byref(out)))
         N, W, H = self.num_envs, self.W, self.H
@@ -149,11 +174,13 @@ class BatchedMiniWorld:
         self.pack = as_t(out.pack, (out.pack_bytes,), "|u1")
         self.pack_offsets = {k: int(getattr(out, k)) - int(out.pack) for k in ("reward64", "goal_pos", "reward", "feature", "ep_steps", "done")}
         self.n_boxes = int(self.L.mwb_num_boxes(self.h))   # 1; 2 (TMazeTwoBox, SimToRealPush); 6 (PutNext)
-        self.agent_radius = 0.11 if task.startswith("SimToReal") else 0.4
+        self.agent_radius = 0.11 if task.startswith("SimToReal") else 1.5 if task == "RoomObjs" else 0.4
+        self.ent_task = _lib.TASK_IDS[task] >= _lib.ENT_TASK_FIRST
         # action_space: Discrete(move_forward + 1) in the navigation tasks (e.g. hallway.py:23), Discrete(move_back + 1)
         # in SimToRealPush (simtorealpush.py:37), the base class' Discrete(len(Actions)) = 8 where the task does not
         # narrow it (PutNext: miniworld.py:470)
-        self.n_actions = 4 if task == "SimToRealPush" else 8 if task == "PutNext" else 3
+        self.n_actions = {"SimToRealPush": 4, "PutNext": 8, "PickupObjs": 5, "RoomObjs": 8, "CollectHealth": 8, "Sign": 4}.get(task, 3)
+        self.has_health = task == "CollectHealth"   # info['health'] arrives in feature[:, 0]
         self.has_features = task == "TMazeTwoBox" and ta[0] != 0
         self.has_goal_pos = task in ("TMaze", "TMazeTwoBox", "YMaze")   # tmaze.py:66,206, ymaze.py:92
         self.max_episode_steps = self._max_steps(task, ta, max_episode_steps)
@@ -165,7 +192,8 @@ class BatchedMiniWorld:
         if mes:
             return int(mes)
         return {"Hallway": 250, "OneRoom": 180, "FourRooms": 250, "TMaze": 280, "TMazeTwoBox": 280,
-                "SimToRealGoTo": 100, "SimToRealPush": 150, "PutNext": 250, "YMaze": 280}.get(task) or int(ta[0] or 8) * int(ta[1] or 8) * 24
+                "SimToRealGoTo": 100, "SimToRealPush": 150, "PutNext": 250, "YMaze": 280, "PickupObjs": 400, "RoomObjs": 2 ** 31 - 1,
+                "CollectHealth": 1000, "ThreeRooms": 400, "Sign": 20, "Sidewalk": 150, "WallGap": 300}.get(task) or int(ta[0] or 8) * int(ta[1] or 8) * 24
 
     def _load_textures(self):
         from PIL import Image
@@ -174,6 +202,29 @@ class BatchedMiniWorld:
                 img = np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
             _lib.check(self.L.mwb_set_texture(self.h, tid, img.shape[1], img.shape[0],
                                               img.ctypes.data_as(ctypes.c_void_p)))
+
+    def _load_meshes(self, task):
+        """ObjMesh.get for every mesh the task's entities use (objmesh.py:16-216) + the BVH the render kernel walks, and
+        MeshEnt.__init__'s scale / radius (entity.py:118-127) evaluated here with the reference's expressions"""
+        from . import meshes as M
+        vp = ctypes.c_void_p
+        done = set()
+        for geom, height in TASK_MESHES[task]:
+            name = geom + "_red" if geom in ("ball", "key") else geom   # the colour variants share their geometry
+            m = M.get(name)
+            if geom not in done:
+                done.add(geom)
+                nodes, perm = M.build_bvh(m.verts)
+                tex = TEX_FILES.index("../meshes/" + geom) if m.chunks[0][2] is not None else -1
+                assert len(m.chunks) == 1, "one material per mesh"
+                arrs = [np.ascontiguousarray(a, np.float32) for a in (m.verts, m.norms, m.texcs, m.min_coords, m.max_coords, nodes)]
+                perm = np.ascontiguousarray(perm, np.int32)
+                _lib.check(self.L.mwb_set_mesh(self.h, _lib.MESH_GEOMS.index(geom), m.n_tris, arrs[0].ctypes.data_as(vp), arrs[1].ctypes.data_as(vp),
+                                               arrs[2].ctypes.data_as(vp), tex, arrs[3].ctypes.data_as(vp), arrs[4].ctypes.data_as(vp),
+                                               nodes.shape[0], arrs[5].ctypes.data_as(vp), perm.ctypes.data_as(vp)))
+            scale, radius = M.mesh_ent_dims(name, height)
+            _lib.check(self.L.mwb_set_mesh_dims(self.h, _lib.MESH_GEOMS.index(geom), float(height), float(scale), float(radius),
+                                                int(isinstance(radius, np.float32))))
 
     # -------------------------------------------------------------------------------- lifecycle
     def close(self):
@@ -281,7 +332,19 @@ class BatchedMiniWorld:
         st = _lib.MwbState()
         for k, v in list(out.items()) + list(boxes.items()):
             setattr(st, k, v.ctypes.data_as(ctypes.c_void_p))
+        ents = {}
+        if self.ent_task:   # the general entity list: per slot kind / flags / dimensions, the list order, the task's counters
+            ents = {"ent_meta": np.zeros((count, B), np.int32), "ent_radius": np.zeros((count, B)), "ent_height": np.zeros((count, B)),
+                    "ent_scale": np.zeros((count, B)), "ent_order": np.zeros((count, B + 1), np.int32), "task_f": np.zeros(count),
+                    "task_i": np.zeros(count, np.int32), "text_tex": np.zeros((count, 8), np.int32)}
+            for k, v in ents.items():
+                setattr(st, k, v.ctypes.data_as(ctypes.c_void_p))
         _lib.check(self.L.mwb_get_state(self.h, first, count, ctypes.byref(st)))
+        if self.ent_task:
+            m = ents["ent_meta"]
+            ents.update({"ent_kind": m & 15, "ent_geom": (m >> 4) & 15, "ent_static": (m >> 8) & 1, "ent_alive": (m >> 9) & 1,
+                         "ent_rad_f32": (m >> 10) & 1, "ent_color": ((m >> 12) & 15) - 1})
+        out.update(ents)
         for k, v in boxes.items():
             out["boxes_" + k[4:]] = v
             out[k] = v[:, 0]
@@ -305,6 +368,10 @@ class BatchedMiniWorld:
                 shape, dt = (-1, _lib.MT_WORDS), np.uint32
             elif name in ("step_count", "goal_idx", "episode_count", "task_step_count", "carrying"):
                 shape, dt = (-1,), self._STATE_INT[name]
+            elif name in ("ent_meta", "ent_order", "task_i"):
+                shape, dt = {"ent_meta": (-1, self.n_boxes), "ent_order": (-1, self.n_boxes + 1), "task_i": (-1,)}[name], np.int32
+            elif name == "task_f":
+                shape, dt = (-1,), np.float64
             else:
                 raise KeyError("set_state: %r is not a writable state field" % k)
             a = np.ascontiguousarray(np.asarray(v, dtype=dt).reshape(shape))

@@ -69,6 +69,12 @@ struct mwb_handle {
     size_t stack_bytes;
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
+    // entity tasks: mesh geometries (host copies until the first pass uploads them in one allocation)
+    struct HostMesh { bool set = false; int n_tris = 0, n_nodes = 0, tex_id = -1; float min_c[3], max_c[3]; std::vector<float> nodes, tris, tris2, shade; };
+    HostMesh meshes[MWB_NUM_MESHES];
+    bool meshes_dirty;
+    float4 *mesh_data_dev;
+    MwbMeshDesc *mesh_desc_dev;
 };
 
 extern "C" const char *mwb_last_error(void) { return g_err.c_str(); }
@@ -196,7 +202,8 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     if (!cfg || !out) return set_err(MWB_EINVAL, "mwb_create: null argument");
     if (cfg->abi_version != MWB_ABI_VERSION) return set_err(MWB_EINVAL, "mwb_create: abi_version mismatch");
     if (cfg->num_envs <= 0) return set_err(MWB_EINVAL, "mwb_create: num_envs must be > 0");
-    if (cfg->task < 0 || cfg->task > MWB_TASK_YMAZE) return set_err(MWB_EINVAL, "mwb_create: unknown task");
+    if (cfg->task < 0 || cfg->task >= MWB_NUM_TASKS) return set_err(MWB_EINVAL, "mwb_create: unknown task");
+    if (cfg->task == MWB_TASK_THREEROOMS) return set_err(MWB_EINVAL, "mwb_create: ThreeRooms needs two portals on one wall (not supported yet)");
     if (cfg->obs_width <= 0 || cfg->obs_height <= 0 || cfg->obs_width > 1024 || cfg->obs_height > 1024)
         return set_err(MWB_EINVAL, "mwb_create: bad observation size");
     if (cfg->layout != MWB_LAYOUT_HWC && cfg->layout != MWB_LAYOUT_CWH) return set_err(MWB_EINVAL, "mwb_create: bad layout");
@@ -214,21 +221,33 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     d.want_depth = cfg->want_depth ? 1 : 0; d.layout = cfg->layout; d.domain_rand = cfg->domain_rand ? 1 : 0;
     d.auto_reset = cfg->no_auto_reset ? 0 : 1;
     { const char *dbg = getenv("MWB_DEBUG"); d.debug_flags = dbg ? atoi(dbg) : 0; }
-    static const double dflt[10][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}, {12, 0, 0, 0}, {0, 0, 0, 0}};
+    static const double dflt[MWB_NUM_TASKS][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}, {12, 0, 0, 0}, {0, 0, 0, 0},
+                                                 {12, 5, 0, 0}, {10, 0, 0, 0}, {16, 0, 0, 0}, {0, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     const bool sim2real = cfg->task == MWB_TASK_SIM2REAL_GOTO || cfg->task == MWB_TASK_SIM2REAL_PUSH;
+    const int task = cfg->task;
+    d.ent_task = task >= MWB_TASK_PICKUPOBJS ? 1 : 0;
     d.n_boxes = (cfg->task == MWB_TASK_TMAZE_TWOBOX || cfg->task == MWB_TASK_SIM2REAL_PUSH) ? 2 : cfg->task == MWB_TASK_PUTNEXT ? 6 : 1;
-    d.frame_words = MWB_FRAME_WORDS_FOR(d.n_boxes);
-    d.n_tex = sim2real ? MWB_NUM_TEXTURES : 7;
+    if (task == MWB_TASK_PICKUPOBJS) {
+        const double no = cfg->task_args[1] != 0 ? cfg->task_args[1] : 5;
+        if (!(no >= 1 && no <= MWB_MAX_ENTS) || no != (double)(int)no) { delete h; return set_err(MWB_EINVAL, "PickupObjs: num_objs must be 1 .. 20"); }
+        d.n_boxes = (int)no;
+    } else if (task == MWB_TASK_ROOMOBJS) d.n_boxes = 3;
+    else if (task == MWB_TASK_COLLECTHEALTH) d.n_boxes = 18;
+    else if (task == MWB_TASK_THREEROOMS) d.n_boxes = 6;
+    else if (task == MWB_TASK_SIGN || task == MWB_TASK_SIDEWALK) d.n_boxes = 7;
+    else if (task == MWB_TASK_WALLGAP) d.n_boxes = 2;
+    d.frame_words = MWB_FRAME_WORDS_FOR(d.ent_task ? MWB_MAX_ENTS : d.n_boxes);   // the entity render kernels are compiled for every slot
+    d.n_tex = sim2real ? 17 : d.ent_task ? (task == MWB_TASK_SIGN ? MWB_NUM_TEXTURES : MWB_TEX_CHAR0) : 7;
     {   // the last ~0.6 round of resident workgroups (5 per CU x 256 CUs = 1280) of a bulk render launch drains in
         // half-frame units: measured best between 640 and 960 envs (+4 % at 8192 Maze envs); MWB_SPLIT overrides
         const char *sp = getenv("MWB_SPLIT");
         int split = sp ? atoi(sp) : 768;
         d.split_envs = split < 0 ? 0 : (split > cfg->num_envs ? cfg->num_envs : split);
     }
-    d.no_ceiling = sim2real ? 1 : 0;
+    d.no_ceiling = (sim2real || task == MWB_TASK_PICKUPOBJS || task == MWB_TASK_ROOMOBJS || task == MWB_TASK_SIDEWALK || task == MWB_TASK_WALLGAP) ? 1 : 0;
     d.poly = cfg->task == MWB_TASK_YMAZE ? 1 : 0;
     d.room_words = d.poly ? MWB_POLY_ROOM_WORDS : MWB_ROOM_WORDS;
-    d.agent_radius = sim2real ? 0.11 : 0.4;   // simtorealgoto.py:50 / entity.py:451
+    d.agent_radius = sim2real ? 0.11 : task == MWB_TASK_ROOMOBJS ? 1.5 : 0.4;   // simtorealgoto.py:50 / roomobjs.py:36 / entity.py:451
     for (int i = 0; i < 4; i++) d.task_args[i] = cfg->task_args[i] != 0 ? cfg->task_args[i] : dflt[cfg->task][i];
     int mes = cfg->max_episode_steps;
     if (mes <= 0) {   // hallway.py:18, oneroom.py:14, fourrooms.py:15, maze.py:27
@@ -240,6 +259,13 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
         else if (d.task == MWB_TASK_SIM2REAL_PUSH) mes = 150;   // simtorealpush.py:29
         else if (d.task == MWB_TASK_PUTNEXT) mes = 250;   // putnext.py:16
         else if (d.task == MWB_TASK_YMAZE) mes = 280;     // ymaze.py:21
+        else if (d.task == MWB_TASK_PICKUPOBJS) mes = 400;        // pickupobjs.py:19
+        else if (d.task == MWB_TASK_ROOMOBJS) mes = 2147483647;   // roomobjs.py:19: math.inf
+        else if (d.task == MWB_TASK_COLLECTHEALTH) mes = 1000;    // collecthealth.py:24
+        else if (d.task == MWB_TASK_THREEROOMS) mes = 400;        // threerooms.py:14
+        else if (d.task == MWB_TASK_SIGN) mes = 20;               // sign.py:41
+        else if (d.task == MWB_TASK_SIDEWALK) mes = 150;          // sidewalk.py:15
+        else if (d.task == MWB_TASK_WALLGAP) mes = 300;           // wallgap.py:14
         else mes = (int)d.task_args[0] * (int)d.task_args[1] * 24;
     }
     d.max_episode_steps = mes;
@@ -256,6 +282,17 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     } else if (sim2real) { d.R_max = 1; d.S_max = 4; }
     else if (d.task == MWB_TASK_YMAZE) { d.R_max = 6; d.S_max = 24; }   // corridor, hub, two arms, two connectors (the third pair of portals meets directly)
     else if (d.task == MWB_TASK_PUTNEXT) { if (!(d.task_args[0] >= 2)) { delete h; return set_err(MWB_EINVAL, "PutNext: size >= 2"); } d.R_max = 1; d.S_max = 4; }
+    else if (d.task == MWB_TASK_PICKUPOBJS || d.task == MWB_TASK_ROOMOBJS || d.task == MWB_TASK_COLLECTHEALTH) {
+        if (!(d.task_args[0] >= 2)) { delete h; return set_err(MWB_EINVAL, "size >= 2"); }
+        d.R_max = 1; d.S_max = 4;
+    } else if (d.ent_task) {
+        if (d.task == MWB_TASK_SIGN && (d.task_args[0] != 10 || d.task_args[1] < 0 || d.task_args[1] > 2 || d.task_args[2] < 0 || d.task_args[2] > 1 ||
+                                        d.task_args[1] != (double)(int)d.task_args[1] || d.task_args[2] != (double)(int)d.task_args[2])) {
+            delete h;   // the objects sit at fixed coordinates (sign.py:91-102): only the default room fits them
+            return set_err(MWB_EINVAL, "Sign: size must be 10, color_index 0..2, goal 0..1");
+        }
+        d.R_max = 8; d.S_max = 24;
+    }
     else {
         int rows = (int)d.task_args[0], cols = (int)d.task_args[1];
         if (rows < 1 || cols < 1 || rows * cols > 4096) { delete h; return set_err(MWB_EINVAL, "Maze: bad num_rows / num_cols"); }
@@ -268,6 +305,12 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N * d.n_boxes); A(d.box_z, N * d.n_boxes); A(d.box_y, N * d.n_boxes); A(d.box_dir, N * d.n_boxes); A(d.carrying, N);
     A(d.box_color, N * d.n_boxes * 3); A(d.box_size, N * d.n_boxes); A(d.goal_dist, N); A(d.episode_count, N); A(d.task_step_count, N); A(d.goal_idx, N); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
     A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.reset_set, N); A(d.reset_list, N); A(d.reset_count, (size_t)1);
+    if (d.ent_task) {
+        A(d.ent_meta, N * d.n_boxes); A(d.ent_radius, N * d.n_boxes); A(d.ent_height, N * d.n_boxes); A(d.ent_scale, N * d.n_boxes);
+        A(d.ent_order, N * MWB_ORDER_STRIDE); A(d.n_order, N); A(d.task_f, N); A(d.task_i, N); A(d.text_tex, N * 8);
+        A(d.ovr_slot, N); A(d.ovr_pose, N * 4);
+        A(h->mesh_desc_dev, (size_t)MWB_NUM_MESHES);
+    }
     A(d.rng, N * MWB_MT_WORDS); A(d.rooms, N * d.R_max * d.room_words); A(d.segs, N * d.S_max * 4); A(d.frame, N * d.frame_words); A(d.world_ext, N * 4);
     A(d.obs, N * d.W * d.H * 3);
     if (d.want_depth) { A(d.depth, N * d.W * d.H); }
@@ -318,6 +361,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     h->timing = false; h->timing_now = false; h->timing_period = 1; h->timing_tick = 0; h->ev_used = 0; h->ev = nullptr;
     { const char *no = getenv("MWB_NO_OVERLAP"); h->overlap_reset = !(no && atoi(no)); }
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
+    h->meshes_dirty = false; h->mesh_data_dev = nullptr; d.mesh_desc = h->mesh_desc_dev; d.mesh_data = nullptr;
     h->stack = nullptr; h->stack_n = 0; h->stack_dtype = 0; h->stack_bytes = 0; h->stack_planes = 0; h->stack_pos = 0; h->stack_fused = 0;
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // numerically lowest = highest priority
@@ -345,6 +389,7 @@ extern "C" int mwb_destroy(mwb_handle *h) {
     hipDeviceSynchronize();
     for (void *p : h->allocs) hipFree(p);
     if (h->texels_dev) hipFree(h->texels_dev);
+    if (h->mesh_data_dev) hipFree(h->mesh_data_dev);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -430,6 +475,107 @@ static int upload_textures(mwb_handle *h) {
     return MWB_OK;
 }
 
+// -------------------------------------------------------------------------------------- meshes
+extern "C" int mwb_set_mesh(mwb_handle *h, int geom, int n_tris, const float *verts, const float *norms, const float *texcs, int tex_slot,
+                            const float *min_coords, const float *max_coords, int n_nodes, const float *nodes, const int32_t *perm) {
+    if (!h || !verts || !norms || !texcs || !min_coords || !max_coords || !nodes || !perm) return set_err(MWB_EINVAL, "mwb_set_mesh: null argument");
+    if (geom < 0 || geom >= MWB_NUM_MESHES || n_tris <= 0 || n_tris >= (1 << 24) || n_nodes <= 0 || tex_slot >= MWB_MAX_TEX)
+        return set_err(MWB_EINVAL, "mwb_set_mesh: bad geometry id / sizes");
+    {   // the hierarchy is walked by a kernel: every link must stay inside the arrays and move forward (the walk terminates)
+        std::vector<char> seen((size_t)n_tris, 0);
+        for (int i = 0; i < n_nodes; i++) {
+            int32_t skip, fc;
+            memcpy(&skip, nodes + (size_t)i * 8 + 3, 4); memcpy(&fc, nodes + (size_t)i * 8 + 7, 4);
+            const int cnt = (int)((uint32_t)fc >> 24), first = (int)((uint32_t)fc & 0xFFFFFFu);
+            if (skip <= i || skip > n_nodes || first + cnt > n_tris || (cnt == 0 && i + 1 >= n_nodes))
+                return set_err(MWB_EINVAL, "mwb_set_mesh: malformed hierarchy");
+            for (int k = 0; k < cnt; k++) seen[(size_t)first + k] = 1;
+        }
+        for (int i = 0; i < n_tris; i++)
+            if (!seen[i] || perm[i] < 0 || perm[i] >= n_tris) return set_err(MWB_EINVAL, "mwb_set_mesh: the leaves must cover every triangle once");
+    }
+    mwb_handle::HostMesh &m = h->meshes[geom];
+    m.set = true; m.n_tris = n_tris; m.n_nodes = n_nodes; m.tex_id = tex_slot;
+    for (int k = 0; k < 3; k++) { m.min_c[k] = min_coords[k]; m.max_c[k] = max_coords[k]; }
+    m.nodes.assign(nodes, nodes + (size_t)n_nodes * 8);
+    auto rec = [&](int tri, float *o) {   // v0.xyz e1.x | e1.yz e2.xy | e2.z idx 0 0 with e1 = v1 - v0, e2 = v2 - v0 in float32
+        const float *v = verts + (size_t)tri * 9;
+        const float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = e1[0]; o[4] = e1[1]; o[5] = e1[2]; o[6] = e2[0]; o[7] = e2[1]; o[8] = e2[2];
+        int32_t idx = tri; memcpy(o + 9, &idx, 4); o[10] = 0; o[11] = 0;
+    };
+    m.tris.resize((size_t)n_tris * 12); m.tris2.resize((size_t)n_tris * 12); m.shade.assign((size_t)n_tris * 16, 0.0f);
+    for (int i = 0; i < n_tris; i++) {
+        rec(perm[i], &m.tris[(size_t)i * 12]);
+        rec(i, &m.tris2[(size_t)i * 12]);
+        float *o = &m.shade[(size_t)i * 16];
+        memcpy(o, norms + (size_t)i * 9, 36);
+        memcpy(o + 9, texcs + (size_t)i * 6, 24);
+    }
+    h->meshes_dirty = true;
+    return MWB_OK;
+}
+
+extern "C" int mwb_set_mesh_dims(mwb_handle *h, int geom, double height, double scale, double radius, int is_f32) {
+    if (!h) return set_err(MWB_EINVAL, "mwb_set_mesh_dims: null handle");
+    if (geom < 0 || geom >= MWB_NUM_MESHES || !(height > 0) || !(scale > 0) || !(radius > 0) || !std::isfinite(scale) || !std::isfinite(radius))
+        return set_err(MWB_EINVAL, "mwb_set_mesh_dims: bad argument");
+    MwbDev &d = h->dev;
+    int k = 0;
+    while (k < d.n_mesh_dims && !(d.mesh_dims[k].geom == geom && d.mesh_dims[k].height == height)) k++;
+    if (k == MWB_MAX_MESH_DIMS) return set_err(MWB_EINVAL, "mwb_set_mesh_dims: table full");
+    d.mesh_dims[k].geom = geom; d.mesh_dims[k].height = height; d.mesh_dims[k].scale = scale; d.mesh_dims[k].radius = radius; d.mesh_dims[k].is_f32 = is_f32 ? 1 : 0;
+    if (k == d.n_mesh_dims) d.n_mesh_dims++;
+    return MWB_OK;
+}
+
+// which geometries (and (geometry, height) pairs) the task builds
+static const int *task_meshes(int task, int *n) {
+    static const int pick[2] = {MWB_MESH_BALL, MWB_MESH_KEY}, health[1] = {MWB_MESH_MEDKIT}, three[3] = {MWB_MESH_DUCKIE, MWB_MESH_KEY, MWB_MESH_BALL},
+                     sign[1] = {MWB_MESH_KEY}, side[2] = {MWB_MESH_BUILDING, MWB_MESH_CONE}, gap[1] = {MWB_MESH_BUILDING};
+    switch (task) {
+    case MWB_TASK_PICKUPOBJS: case MWB_TASK_ROOMOBJS: *n = 2; return pick;
+    case MWB_TASK_COLLECTHEALTH: *n = 1; return health;
+    case MWB_TASK_THREEROOMS: *n = 3; return three;
+    case MWB_TASK_SIGN: *n = 1; return sign;
+    case MWB_TASK_SIDEWALK: *n = 2; return side;
+    case MWB_TASK_WALLGAP: *n = 1; return gap;
+    }
+    *n = 0; return nullptr;
+}
+
+static int upload_meshes(mwb_handle *h) {   // the caller holds the device guard
+    int n_need = 0;
+    const int *need = task_meshes(h->dev.task, &n_need);
+    for (int k = 0; k < n_need; k++) {
+        if (!h->meshes[need[k]].set) return set_err(MWB_ESTATE, "reset / render requested before the task's meshes were set (mwb_set_mesh)");
+        bool dims = false;
+        for (int q = 0; q < h->dev.n_mesh_dims; q++) dims = dims || h->dev.mesh_dims[q].geom == need[k];
+        if (!dims) return set_err(MWB_ESTATE, "reset requested before the task's mesh dimensions were set (mwb_set_mesh_dims)");
+    }
+    std::vector<float> all;
+    MwbMeshDesc desc[MWB_NUM_MESHES];
+    memset(desc, 0, sizeof(desc));
+    for (int g = 0; g < MWB_NUM_MESHES; g++) {
+        const mwb_handle::HostMesh &m = h->meshes[g];
+        if (!m.set) continue;
+        desc[g].n_tris = m.n_tris; desc[g].n_nodes = m.n_nodes; desc[g].tex_id = m.tex_id;
+        for (int k = 0; k < 3; k++) { desc[g].min_c[k] = m.min_c[k]; desc[g].max_c[k] = m.max_c[k]; }
+        desc[g].node_off = (uint32_t)(all.size() / 4); all.insert(all.end(), m.nodes.begin(), m.nodes.end());
+        desc[g].tri_off = (uint32_t)(all.size() / 4); all.insert(all.end(), m.tris.begin(), m.tris.end());
+        desc[g].tri2_off = (uint32_t)(all.size() / 4); all.insert(all.end(), m.tris2.begin(), m.tris2.end());
+        desc[g].shade_off = (uint32_t)(all.size() / 4); all.insert(all.end(), m.shade.begin(), m.shade.end());
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->mesh_data_dev) { hipFree(h->mesh_data_dev); h->mesh_data_dev = nullptr; }
+    HIP_TRY(hipMalloc((void **)&h->mesh_data_dev, (all.size() ? all.size() : 4) * sizeof(float)));
+    if (!all.empty()) HIP_TRY(hipMemcpy(h->mesh_data_dev, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->mesh_desc_dev, desc, sizeof(desc), hipMemcpyHostToDevice));
+    h->dev.mesh_data = h->mesh_data_dev;
+    h->meshes_dirty = false;
+    return MWB_OK;
+}
+
 // ---------------------------------------------------------------------------------- simulation
 extern "C" int mwb_seed(mwb_handle *h, const uint64_t *seeds) {
     if (!h || !seeds) return set_err(MWB_EINVAL, "mwb_seed: null argument");
@@ -498,6 +644,7 @@ static int stack_advance(mwb_handle *h, int after_reset, hipStream_t s) {
 static int ensure_ready(mwb_handle *h, bool renders = true) {   // the caller holds the device guard
     if (!h->seeded) return set_err(MWB_ESTATE, "mwb_seed must be called before reset/step (the reference seeds from entropy; this library refuses to)");
     if (h->textures_dirty || !h->have_textures) { int rc = upload_textures(h); if (rc) return rc; }
+    if (h->dev.ent_task && (h->meshes_dirty || !h->mesh_data_dev)) { int rc = upload_meshes(h); if (rc) return rc; }
     if (renders) h->have_obs = true;
     return MWB_OK;
 }
@@ -507,6 +654,7 @@ extern "C" int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream) {
     USE_DEVICE(h->cfg.device);
     int rc = ensure_ready(h); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    h->dev.step_pass = 0;
     rc = timing_begin(h, s); if (rc) return rc;
     rc = stack_advance(h, mask_dev == nullptr, s); if (rc) return rc;   // a full reset restarts the window; a partial one is a step for the others
     mwb_launch_mark_reset(h->dev, mask_dev, s);
@@ -539,6 +687,7 @@ static int step_impl(mwb_handle *h, const int32_t *actions_dev, const uint8_t *s
     int rc = ensure_ready(h); if (rc) return rc;
     if (!actions_dev) return set_err(MWB_EINVAL, "mwb_step: null actions");
     hipStream_t s = (hipStream_t)stream;
+    h->dev.step_pass = 1;   // the frames of this pass are the step's own (entity tasks: what a task rule removed is still drawn)
     rc = timing_begin(h, s); if (rc) return rc;
     rc = stack_advance(h, 0, s); if (rc) return rc;
     mwb_launch_step(h->dev, actions_dev, skip_mask_dev, s);
@@ -579,6 +728,7 @@ extern "C" int mwb_render(mwb_handle *h, void *stream) {
     USE_DEVICE(h->cfg.device);
     int rc = ensure_ready(h); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    h->dev.step_pass = 0;   // the current state (render_obs() called again shows what the task rule left)
     rc = timing_begin(h, s); if (rc) return rc;
     TMARK(1); TMARK(5); TMARK(6); TMARK(2);
     return render_tail(h, 0, s);
@@ -587,6 +737,7 @@ extern "C" int mwb_render(mwb_handle *h, void *stream) {
 extern "C" int mwb_render_top_view(mwb_handle *h, uint8_t *out_dev, int width, int height, void *stream) {
     if (!h || !out_dev) return set_err(MWB_EINVAL, "mwb_render_top_view: null argument");
     if (width < 1 || height < 1 || width > 4096 || height > 4096) return set_err(MWB_EINVAL, "mwb_render_top_view: bad frame size");
+    if (h->dev.ent_task) return set_err(MWB_EINVAL, "mwb_render_top_view: not available for the tasks with mesh entities");
     USE_DEVICE(h->cfg.device);
     int rc = ensure_ready(h, false); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -598,6 +749,7 @@ extern "C" int mwb_render_top_view(mwb_handle *h, uint8_t *out_dev, int width, i
 
 extern "C" int mwb_visible_ents(mwb_handle *h, uint32_t *mask_dev, void *stream) {
     if (!h || !mask_dev) return set_err(MWB_EINVAL, "mwb_visible_ents: null argument");
+    if (h->dev.ent_task) return set_err(MWB_EINVAL, "mwb_visible_ents: not available for the tasks with mesh entities");
     USE_DEVICE(h->cfg.device);
     int rc = ensure_ready(h, false); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -751,6 +903,33 @@ extern "C" int mwb_get_state(mwb_handle *h, int first, int count, mwb_state *o) 
     if ((rc = fetch_boxes(o->box_size, d.box_size, N, B, first, count, 1))) return rc;
     if ((rc = fetch(o->goal_dist, d.goal_dist, first, count, 1))) return rc;
     if ((rc = fetch(o->carrying, d.carrying, first, count, 1))) return rc;
+    if (o->ent_meta || o->ent_radius || o->ent_height || o->ent_scale || o->ent_order || o->task_f || o->task_i || o->text_tex) {
+        if (!d.ent_task) return set_err(MWB_EINVAL, "mwb_get_state: entity-list fields exist for the tasks >= MWB_TASK_PICKUPOBJS only");
+        if (o->ent_meta) {
+            std::vector<int32_t> plane(count);
+            for (int b = 0; b < B; b++) {
+                HIP_TRY(hipMemcpy(plane.data(), d.ent_meta + (size_t)b * N + first, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+                for (int i = 0; i < count; i++) o->ent_meta[(size_t)i * B + b] = plane[i];
+            }
+        }
+        if ((rc = fetch_boxes(o->ent_radius, d.ent_radius, N, B, first, count, 1))) return rc;
+        if ((rc = fetch_boxes(o->ent_height, d.ent_height, N, B, first, count, 1))) return rc;
+        if ((rc = fetch_boxes(o->ent_scale, d.ent_scale, N, B, first, count, 1))) return rc;
+        if (o->ent_order) {
+            std::vector<uint8_t> ord((size_t)count * MWB_ORDER_STRIDE);
+            std::vector<int32_t> no(count);
+            HIP_TRY(hipMemcpy(ord.data(), d.ent_order + (size_t)first * MWB_ORDER_STRIDE, ord.size(), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(no.data(), d.n_order + first, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (int i = 0; i < count; i++)
+                for (int k = 0; k <= B; k++) {
+                    const int v = ord[(size_t)i * MWB_ORDER_STRIDE + k];
+                    o->ent_order[(size_t)i * (B + 1) + k] = k >= no[i] ? -1 : (v == MWB_ENT_AGENT ? -2 : v);
+                }
+        }
+        if ((rc = fetch(o->task_f, d.task_f, first, count, 1))) return rc;
+        if ((rc = fetch(o->task_i, d.task_i, first, count, 1))) return rc;
+        if ((rc = fetch(o->text_tex, d.text_tex, first, count, 8))) return rc;
+    }
     if ((rc = fetch(o->goal_idx, d.goal_idx, first, count, 1))) return rc;
     if ((rc = fetch(o->episode_count, d.episode_count, first, count, 1))) return rc;
     if ((rc = fetch(o->task_step_count, d.task_step_count, first, count, 1))) return rc;
@@ -824,6 +1003,44 @@ extern "C" int mwb_set_state(mwb_handle *h, int first, int count, const mwb_stat
     if ((rc = store_boxes(in->box_size, d.box_size, N, B, first, count, 1))) return rc;
     if ((rc = store(in->goal_dist, d.goal_dist, first, count, 1))) return rc;
     if ((rc = store(in->carrying, d.carrying, first, count, 1))) return rc;
+    if (in->ent_meta || in->ent_radius || in->ent_height || in->ent_scale || in->ent_order || in->task_f || in->task_i || in->text_tex) {
+        if (!d.ent_task) return set_err(MWB_EINVAL, "mwb_set_state: entity-list fields exist for the tasks >= MWB_TASK_PICKUPOBJS only");
+        if (in->ent_radius || in->ent_height || in->ent_scale || in->text_tex) return set_err(MWB_EINVAL, "mwb_set_state: ent_radius / ent_height / ent_scale / text_tex are read-only");
+        if (in->ent_meta) {   // only the `alive` bit may differ (an entity PickupObjs removed): kinds and dimensions belong to the episode
+            std::vector<int32_t> plane(count);
+            for (int b = 0; b < B; b++) {
+                HIP_TRY(hipMemcpy(plane.data(), d.ent_meta + (size_t)b * N + first, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+                for (int i = 0; i < count; i++) {
+                    const int32_t v = in->ent_meta[(size_t)i * B + b];
+                    if ((v & ~(1 << 9)) != (plane[i] & ~(1 << 9))) return set_err(MWB_EINVAL, "mwb_set_state: ent_meta may only change an entity's alive bit");
+                    plane[i] = v;
+                }
+                HIP_TRY(hipMemcpy(d.ent_meta + (size_t)b * N + first, plane.data(), count * sizeof(int32_t), hipMemcpyHostToDevice));
+            }
+        }
+        if (in->ent_order) {
+            std::vector<uint8_t> ord((size_t)count * MWB_ORDER_STRIDE, (uint8_t)MWB_ENT_AGENT);
+            std::vector<int32_t> no(count);
+            for (int i = 0; i < count; i++) {
+                int n = 0;
+                uint32_t seen = 0;
+                for (int k = 0; k <= B; k++) {
+                    const int v = in->ent_order[(size_t)i * (B + 1) + k];
+                    if (v == -1) break;
+                    if (v != -2 && (v < 0 || v >= B)) return set_err(MWB_EINVAL, "mwb_set_state: ent_order entries are slots, -2 (the agent) or -1 (end)");
+                    const uint32_t bit = 1u << (v == -2 ? 31 : v);
+                    if (seen & bit) return set_err(MWB_EINVAL, "mwb_set_state: ent_order lists an entity twice");
+                    seen |= bit;
+                    ord[(size_t)i * MWB_ORDER_STRIDE + n++] = (uint8_t)(v == -2 ? MWB_ENT_AGENT : v);
+                }
+                no[i] = n;
+            }
+            HIP_TRY(hipMemcpy(d.ent_order + (size_t)first * MWB_ORDER_STRIDE, ord.data(), ord.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d.n_order + first, no.data(), count * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        if ((rc = store(in->task_f, d.task_f, first, count, 1))) return rc;
+        if ((rc = store(in->task_i, d.task_i, first, count, 1))) return rc;
+    }
     if ((rc = store(in->goal_idx, d.goal_idx, first, count, 1))) return rc;
     if ((rc = store(in->episode_count, d.episode_count, first, count, 1))) return rc;
     if ((rc = store(in->task_step_count, d.task_step_count, first, count, 1))) return rc;

@@ -18,7 +18,9 @@
 #define MWB_MT_WORDS 625   // 624 key words + pos
 #define MWB_MAX_TEX MWB_NUM_TEXTURES
 #define MWB_MAX_LEVELS 12
-#define MWB_MAX_BOXES 6
+#define MWB_MAX_BOXES 6   // box-only tasks (templated step / render kernels); entity tasks: MWB_MAX_ENTS slots
+#define MWB_ENT_AGENT 255 // the agent's entry in an env's entity order list
+#define MWB_ORDER_STRIDE 24   // bytes per env of d.ent_order (MWB_MAX_ENTS + 1 entries, padded)
 // frame constants: 36 fixed words, then one block of FC_BOX_STRIDE words per box; d.frame_words = that, rounded up to 4
 
 // room table: 24 f32 words (96 B) per room; ints stored as bit patterns
@@ -84,6 +86,38 @@
 #define FC_CULL_CC 68    // |oc|^2 - R^2
 #define FC_CULL_CC_PIXEL 69   // same with R grown by a pixel footprint
 #define MWB_FRAME_WORDS_FOR(n_boxes) ((36 + FC_BOX_STRIDE * (n_boxes) + 3) & ~3)
+// Entity tasks: the same FC_BOX_STRIDE-word block per entity slot, read by kind.  FC_BOX_HX >= 0: a box (as above); -1: a mesh;
+// -2: an image / text frame; an entity that has left the list has FC_CULL_CC = FC_CULL_CC_PIXEL = +inf (no ray ever passes its gate).
+//   mesh  (offsets from the block's start = FC_LIT_BOX - 36): 0-2 light direction in the mesh's frame / scale, 3-5 Kd,
+//         6-8 0.2 Kd + ambient Kd, 9-11 diffuse, 12 1 / scale, 13 geometry (int), 14 texture slot (int, -1 none);
+//         FC_BOX_POS, FC_BOX_C, FC_BOX_S as for a box; FC_BOX_LO = the eye in the mesh's frame (rotated, / scale)
+//   frame: 0-2 lit colour of the front, 3 depth, 4 half height, 5 half width, 6 character width, 7 characters (int),
+//         8-15 texture slot per character (int, -1 = blank); FC_BOX_POS, C, S; FC_BOX_LO = the eye in the frame's axes
+#define FE_MESH_LL 0
+#define FE_MESH_KD 3
+#define FE_MESH_AMB 6
+#define FE_MESH_DIF 9
+#define FE_MESH_INVS 12
+#define FE_MESH_GEOM 13
+#define FE_MESH_TEX 14
+#define FE_FRAME_LIT 0
+#define FE_FRAME_SX 3
+#define FE_FRAME_HY 4
+#define FE_FRAME_HZ 5
+#define FE_FRAME_CW 6
+#define FE_FRAME_NCH 7
+#define FE_FRAME_TEX 8
+
+// one mesh geometry in HBM (shared by all envs; L2 resident): BVH nodes (2 float4 each), triangle records in LEAF order
+// (3 float4: v0.xyz e1.x | e1.yz e2.xy | e2.z, original index (int bits), 0, 0) and shading records by ORIGINAL index
+// (4 float4: n0.xyz n1.x | n1.yz n2.xy | n2.z tc0.st tc1.s | tc1.t tc2.st 0)
+struct MwbMeshDesc {
+    int n_tris, n_nodes, tex_id, pad;
+    uint32_t node_off, tri_off, shade_off, tri2_off;   // float4 offsets into d.mesh_data; tri2 = the triangle records by ORIGINAL index (shading)
+    float min_c[4], max_c[4];
+};
+struct MwbMeshDims { int geom, is_f32; double height, scale, radius; };
+#define MWB_MAX_MESH_DIMS 16
 
 struct MwbTexDesc {
     int w, h, n_levels;
@@ -152,10 +186,27 @@ struct MwbDev {
     unsigned long long *wg_ts;   // [2 * (N + split_envs)] start / end s_memrealtime of every bulk render workgroup, or null (MWB_DEBUG bit 4)
     float *feature;         // [N][2]
     double *goal_pos;       // [N][3]
+    // ---- entity tasks (task >= MWB_TASK_PICKUPOBJS): the general entity list.  Slot arrays are [n_boxes][N] like the box arrays
+    // (box_x/y/z/dir = position and heading of any entity, box_size = Box edge / MeshEnt height, box_color = Box colour / mesh Kd)
+    int ent_task;           // 1 for those tasks: step_ents_kernel, kind-aware prep, the ENT render kernels
+    int step_pass;          // the frame being prepared is a step's own (an entity the task rule removed / respawned is still drawn)
+    int32_t *ent_meta;      // [n_boxes][N] MWB_META_* word
+    double *ent_radius, *ent_height, *ent_scale;   // [n_boxes][N]
+    uint8_t *ent_order;     // [N][MWB_ORDER_STRIDE] self.entities as slots (MWB_ENT_AGENT = the agent), n_order entries
+    int32_t *n_order;       // [N]
+    double *task_f;         // [N] CollectHealth.health
+    int32_t *task_i;        // [N] PickupObjs.num_picked_up
+    int32_t *text_tex;      // [N][8] texture slot per character of the TextFrame
+    int32_t *ovr_slot;      // [N] slot whose pose the step's frame takes from ovr_pose (-1 none): the entity as the frame saw it
+    double *ovr_pose;       // [N][4] x y z dir
+    const MwbMeshDesc *mesh_desc;   // [MWB_NUM_MESHES] in device memory
+    const float4 *mesh_data;
+    MwbMeshDims mesh_dims[MWB_MAX_MESH_DIMS];
+    int n_mesh_dims;
 };
 
 // launch wrappers implemented in mwb_kernels.hip
-void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *skip_mask, hipStream_t s);
+void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *skip_mask, hipStream_t s);   // entity tasks: step_ents_kernel
 void mwb_launch_clear_list(const MwbDev &d, hipStream_t s);
 void mwb_launch_order(const MwbDev &d, hipStream_t s);   // envs by decreasing measured frame cost -> the map not in use
 void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s);

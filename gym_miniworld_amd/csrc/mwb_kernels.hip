@@ -113,6 +113,14 @@ __device__ __forceinline__ bool seg_hit(const double *sg, double px, double pz, 
 }
 
 
+// a + b as the reference's interpreter evaluates it when either may be a numpy float32 SCALAR (a MeshEnt's radius under
+// NumPy >= 2, entity.py:118-127) and the other a Python float: the Python float is cast to float32, the sum is a float32
+__device__ __forceinline__ double tagged_add(double a, bool a_f32, double b, bool b_f32, bool &res_f32) {
+    res_f32 = a_f32 || b_f32;
+    return res_f32 ? (double)((float)a + (float)b) : a + b;
+}
+__device__ __forceinline__ double tagged_add(double a, bool a_f32, double b, bool b_f32) { bool f; return tagged_add(a, a_f32, b, b_f32, f); }
+
 __device__ __forceinline__ double box_radius(double size) {
     double sx = size, sz = size;   // entity.py:367-378, Box(size=s): radius = sqrt(sx^2 + sz^2) / 2
     return sqrt(sx * sx + sz * sz) / 2;
@@ -399,6 +407,212 @@ __global__ void __launch_bounds__(64 * STEP_PARTS) step_kernel(MwbDev d, const i
     if (regen) d.reset_list[atomicAdd(d.reset_count, 1)] = e;
 }
 
+// ---- MiniWorldEnv.step for the tasks with a general entity list (PickupObjs, RoomObjs, CollectHealth, ThreeRooms, Sign, Sidewalk,
+// WallGap): one lane per env, everything serial - these worlds have a handful of wall segments and at most 20 entities, and the
+// step is ~2 % of a pass.  Entities live in the [slot][N] arrays (coalesced across lanes); the entity LIST - which PickupObjs
+// shortens and CollectHealth re-orders - is the env's row of d.ent_order.  Sums with a mesh's float32 radius follow NumPy >= 2
+// (tagged_add).  What a task rule changes after the reference has rendered the step's frame (pickupobjs.py:56-69,
+// collecthealth.py:51-64) is recorded as a render override for this pass (d.ovr_slot / d.ovr_pose).
+__global__ void __launch_bounds__(64) step_ents_kernel(MwbDev d, const int32_t *__restrict__ actions, const uint8_t *__restrict__ skip) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && d.order_state[1]) { d.order_state[0] ^= 1; d.order_state[1] = 0; }
+    if (e >= d.N) return;
+    const size_t N = (size_t)d.N;
+    const int E = d.n_boxes;
+    if (skip && skip[e]) {   // the fork's 'dummy' command, vec_env/subproc_vec_env.py:26-31
+        d.reward[e] = -99.0f; d.reward64[e] = -99.0; d.done[e] = 0; d.ep_steps[e] = d.step_count[e];
+        d.reset_set[e] = 0; d.ovr_slot[e] = -1;
+        d.feature[e * 2] = 0.0f; d.feature[e * 2 + 1] = 0.0f;
+        return;
+    }
+    int a = actions[(size_t)e * d.act_stride];
+    if (d.act_stride == 2 && actions[(size_t)e * 2 + 1] != (a >> 31)) a = -1;   // an int64 outside int32 is no action
+    double ax = d.agent_x[e], az = d.agent_z[e], adir = d.agent_dir[e];
+    const double arad = d.agent_radius;
+    uint8_t *ord = d.ent_order + (size_t)e * MWB_ORDER_STRIDE;
+    int n_ord = d.n_order[e];
+    int carried = d.carrying[e];
+    const double max_fwd = d.params[MWB_P_FORWARD_STEP].hi[0];   // self.max_forward_step
+    const double cam_height = d.cam[e * 4 + 0];
+    const int ns = d.n_segs[e];
+    d.ovr_slot[e] = -1;
+    MtSerial g;
+    const bool use_rng = d.domain_rand || d.task == MWB_TASK_COLLECTHEALTH;
+    if (use_rng) g.load(d.rng + (size_t)e * MWB_MT_WORDS);
+    const int sc = d.step_count[e] + 1;   // miniworld.py:663
+    d.step_count[e] = sc;
+    double fwd_step = d.params[MWB_P_FORWARD_STEP].def[0], fwd_drift = d.params[MWB_P_FORWARD_DRIFT].def[0], turn_step = d.params[MWB_P_TURN_STEP].def[0];
+    if (d.domain_rand) {
+        fwd_step = g.uniform(d.params[MWB_P_FORWARD_STEP].lo[0], d.params[MWB_P_FORWARD_STEP].hi[0]);
+        fwd_drift = g.uniform(d.params[MWB_P_FORWARD_DRIFT].lo[0], d.params[MWB_P_FORWARD_DRIFT].hi[0]);
+        turn_step = g.uniform(d.params[MWB_P_TURN_STEP].lo[0], d.params[MWB_P_TURN_STEP].hi[0]);
+    }
+    auto walls_hit = [&](double px, double pz, double radius) {
+        for (int i = 0; i < ns; i++) {
+            double q[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) q[c] = d.segs[(size_t)(i * 4 + c) * N + e];
+            if (seg_hit(q, px, pz, radius)) return true;
+        }
+        return false;
+    };
+    // MiniWorldEnv.intersect(ent, pos, radius), miniworld.py:933-959: 0 none, 1 wall, 2 + slot entity, 2 + E the agent
+    auto intersect = [&](int self_slot, double px, double pz, double radius, bool rf32) {
+        if (walls_hit(px, pz, radius)) return 1;
+        for (int k = 0; k < n_ord; k++) {
+            const int slot = ord[k];
+            if (slot == self_slot) continue;
+            double ox, oz, orad; bool of32 = false;
+            if (slot == MWB_ENT_AGENT) { ox = ax; oz = az; orad = arad; }
+            else { const size_t be = (size_t)slot * N + e; ox = d.box_x[be]; oz = d.box_z[be]; orad = d.ent_radius[be]; of32 = MWB_META_RADF32(d.ent_meta[be]) != 0; }
+            const double ddx = ox - px, ddz = oz - pz;
+            if (sqrt(ddx * ddx + 0.0 + ddz * ddz) < tagged_add(radius, rf32, orad, of32)) return 2 + (slot == MWB_ENT_AGENT ? E : slot);
+        }
+        return 0;
+    };
+    auto carry_pos = [&](int slot, double agx, double agz, double dir, double &cx, double &cy, double &cz) {   // _get_carry_pos, miniworld.py:594-606
+        const size_t be = (size_t)slot * N + e;
+        bool f32;
+        double dist = tagged_add(arad, false, d.ent_radius[be], MWB_META_RADF32(d.ent_meta[be]) != 0, f32);
+        dist = tagged_add(dist, f32, max_fwd, false);
+        const double c = ref_cos(dir), s_ = ref_sin(dir);
+        cx = agx + (c * 1.05) * dist; cz = agz + ((-s_) * 1.05) * dist;
+        double yp = (cam_height - d.ent_height[be]) - 0.3;
+        yp = yp > 0 ? yp : 0;
+        cy = (0.0 + (0.0 * 1.05) * dist) + 1.0 * yp;
+        cx = cx + 0.0 * yp; cz = cz + 0.0 * yp;
+    };
+    auto ent_rad = [&](int slot, bool &f32) { const size_t be = (size_t)slot * N + e; f32 = MWB_META_RADF32(d.ent_meta[be]) != 0; return d.ent_radius[be]; };
+    auto set_pose = [&](int slot, double cx, double cy, double cz, bool set_dir) {
+        const size_t be = (size_t)slot * N + e;
+        d.box_x[be] = cx; d.box_y[be] = cy; d.box_z[be] = cz;
+        if (set_dir) d.box_dir[be] = adir;
+    };
+    if (a == 2 || a == 3) {   // move_agent, miniworld.py:608-633
+        const double fd = (a == 2) ? fwd_step : -fwd_step;
+        const double c = ref_cos(adir), s_ = ref_sin(adir);
+        const double nx = (ax + c * fd) + s_ * fwd_drift, nz = (az + (-s_) * fd) + c * fwd_drift;
+        bool hit = intersect(MWB_ENT_AGENT, nx, nz, arad, false) != 0;
+        if (!hit && carried >= 0) {
+            double cx, cy, cz; bool f32;
+            carry_pos(carried, nx, nz, adir, cx, cy, cz);
+            const double cr = ent_rad(carried, f32);
+            if (intersect(carried, cx, cz, cr, f32)) hit = true;
+            else set_pose(carried, cx, cy, cz, false);
+        }
+        if (!hit) { ax = nx; az = nz; d.agent_x[e] = ax; d.agent_z[e] = az; }
+    } else if (a == 0 || a == 1) {   // turn_agent, miniworld.py:635-656
+        double ta = (a == 0) ? turn_step : -turn_step;
+        ta *= (3.141592653589793 / 180);
+        const double orig = adir;
+        adir += ta;
+        if (carried >= 0) {
+            double cx, cy, cz; bool f32;
+            carry_pos(carried, ax, az, adir, cx, cy, cz);
+            const double cr = ent_rad(carried, f32);
+            if (intersect(carried, cx, cz, cr, f32)) adir = orig;
+            else set_pose(carried, cx, cy, cz, true);
+        }
+        d.agent_dir[e] = adir;
+    } else if (a == 4) {   // pickup, miniworld.py:682-689
+        const double c = ref_cos(adir), s_ = ref_sin(adir);
+        const double tx = ax + (c * 1.5) * arad, tz = az + ((-s_) * 1.5) * arad;
+        const int hit = intersect(MWB_ENT_AGENT, tx, tz, 1.2 * arad, false);
+        if (carried < 0 && hit >= 2 && hit - 2 < E && !MWB_META_STATIC(d.ent_meta[(size_t)(hit - 2) * N + e])) carried = hit - 2;
+    } else if (a == 5) {   // drop, miniworld.py:692-695
+        if (carried >= 0) { d.box_y[(size_t)carried * N + e] = 0.0; carried = -1; }
+    }
+    if (carried >= 0) {   // miniworld.py:698-701
+        double cx, cy, cz;
+        carry_pos(carried, ax, az, adir, cx, cy, cz);
+        set_pose(carried, cx, cy, cz, true);
+    }
+    // ---- obs = self.render_obs() happens here in the reference; the task rules follow
+    double r = 0.0;
+    int done = 0;
+    if (sc >= d.max_episode_steps) { done = 1; r = 0.0; }   // miniworld.py:708-711
+    auto near = [&](int slot) {   // MiniWorldEnv.near(ent), miniworld.py:961-971
+        const size_t be = (size_t)slot * N + e;
+        const double ddx = d.box_x[be] - ax, ddy = d.box_y[be] - 0.0, ddz = d.box_z[be] - az;
+        const double dist = sqrt((ddx * ddx + ddy * ddy) + ddz * ddz);
+        bool f32;
+        double thr = tagged_add(d.ent_radius[be], MWB_META_RADF32(d.ent_meta[be]) != 0, arad, false, f32);
+        thr = tagged_add(thr, f32, 1.1 * max_fwd, false);
+        return dist < thr;
+    };
+    auto remove_from_order = [&](int slot) {   // self.entities.remove(ent)
+        int k = 0;
+        while (k < n_ord && ord[k] != slot) k++;
+        for (; k + 1 < n_ord; k++) ord[k] = ord[k + 1];
+        n_ord--;
+    };
+    auto frame_keeps = [&](int slot) {   // the step's frame saw the entity where it is now
+        const size_t be = (size_t)slot * N + e;
+        d.ovr_slot[e] = slot;
+        d.ovr_pose[e * 4 + 0] = d.box_x[be]; d.ovr_pose[e * 4 + 1] = d.box_y[be]; d.ovr_pose[e * 4 + 2] = d.box_z[be]; d.ovr_pose[e * 4 + 3] = d.box_dir[be];
+    };
+    const double rw = 1.0 - 0.2 * ((double)sc / d.max_episode_steps);   // _reward, miniworld.py:1012
+    float feat0 = 0.0f;
+    if (d.task == MWB_TASK_PICKUPOBJS) {   // pickupobjs.py:56-69
+        if (carried >= 0) {
+            frame_keeps(carried);
+            remove_from_order(carried);
+            d.ent_meta[(size_t)carried * N + e] &= ~(1 << 9);   // no longer in the list
+            carried = -1;
+            const int np_ = d.task_i[e] + 1;
+            d.task_i[e] = np_;
+            r = 1.0;
+            if (np_ == E) done = 1;
+        }
+    } else if (d.task == MWB_TASK_COLLECTHEALTH) {   // collecthealth.py:51-77
+        double health = d.task_f[e] - 2;
+        if (a == 4 && carried >= 0) {   // respawn the kit: entities.remove(kit); place_entity(kit) appends it to the END of the list
+            frame_keeps(carried);
+            remove_from_order(carried);
+            const size_t be = (size_t)carried * N + e;
+            const double kr = d.ent_radius[be];
+            const bool kf32 = MWB_META_RADF32(d.ent_meta[be]) != 0;
+            const double size = d.task_args[0];
+            for (int attempt = 0; attempt < 100000; attempt++) {   // place_entity, miniworld.py:876-903, one room
+                (void)g.next_double();                                 // choice(rooms, p=room_probs): one double even for a single room
+                const double px = g.uniform(0.0 + kr, size - kr);
+                (void)g.uniform(0.0, 0.0);
+                const double pz = g.uniform(0.0 + kr, size - kr);
+                if (!(px > 0.0 && px < size && pz > 0.0 && pz < size)) continue;   // Room.point_inside of the square room
+                if (intersect(carried, px, pz, kr, kf32)) continue;
+                d.box_x[be] = px; d.box_y[be] = 0.0; d.box_z[be] = pz;
+                d.box_dir[be] = g.uniform(-3.141592653589793, 3.141592653589793);
+                break;
+            }
+            ord[n_ord++] = (uint8_t)carried;
+            carried = -1;
+            health = 100;
+        }
+        d.task_f[e] = health;
+        if (health > 0) r = 2.0;
+        else { r = -100.0; done = 1; }
+        feat0 = (float)health;   // info['health']
+    } else if (d.task == MWB_TASK_SIGN) {   // sign.py:115-128
+        if (a == 3) done = 1;   // move_forward + 1: "custom end episode action" (the base step has moved the agent back)
+        for (int obj = 0; obj < 2; obj++)
+            for (int ci = 0; ci < 3; ci++)
+                if (near(obj * 3 + ci)) { done = 1; r = (double)(ci == (int)d.task_args[1] && obj == (int)d.task_args[2]) * 2 - 1; }
+    } else if (d.task == MWB_TASK_SIDEWALK) {   // sidewalk.py:74-87: street = the room (0, 6) x (-80, 80)
+        if (ax > 0.0 && ax < 6.0 && az > -80.0 && az < 80.0) { r = 0.0; done = 1; }
+        if (near(6)) { r += rw; done = 1; }
+    } else if (d.task == MWB_TASK_WALLGAP) {   // wallgap.py:54-61
+        if (near(0)) { r += rw; done = 1; }
+    }   // RoomObjs, ThreeRooms: no rule
+    if (use_rng) g.store();
+    d.carrying[e] = carried;
+    d.n_order[e] = n_ord;
+    d.feature[e * 2] = feat0; d.feature[e * 2 + 1] = 0.0f;
+    d.reward64[e] = r; d.reward[e] = (float)r; d.done[e] = (uint8_t)done; d.ep_steps[e] = sc;
+    const bool regen = done && d.auto_reset;
+    d.reset_set[e] = (uint8_t)regen;
+    if (regen) d.reset_list[atomicAdd(d.reset_count, 1)] = e;
+}
+
 __global__ void mark_reset_kernel(MwbDev d, const uint8_t *__restrict__ mask) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= d.N) return;
@@ -439,9 +653,11 @@ struct alignas(16) WRoom {
 };
 
 enum { TEXF_FLOOR_TILES_BW = 0, TEXF_CONCRETE, TEXF_CONCRETE_TILES, TEXF_BRICK_WALL,
-       TEXF_CARDBOARD, TEXF_WOOD, TEXF_WOOD_PLANKS, TEXF_DRYWALL, TEXF_STUCCO, TEXF_CEILING_TILES };
-__constant__ int c_texf_first[10] = {0, 1, 5, 6, 7, 11, 13, 14, 15, 16};
-__constant__ int c_texf_count[10] = {1, 4, 1, 1, 4, 2, 1, 1, 1, 1};   // <name>_<i>.png variants, opengl.py:50-58
+       TEXF_CARDBOARD, TEXF_WOOD, TEXF_WOOD_PLANKS, TEXF_DRYWALL, TEXF_STUCCO, TEXF_CEILING_TILES,
+       TEXF_ASPHALT, TEXF_SLIME, TEXF_CINDER_BLOCKS, TEXF_LOGO_MILA };
+__constant__ int c_texf_first[14] = {0, 1, 5, 6, 7, 11, 13, 14, 15, 16, 17, 18, 19, 20};
+__constant__ int c_texf_count[14] = {1, 4, 1, 1, 4, 2, 1, 1, 1, 1, 1, 1, 1, 1};   // <name>_<i>.png variants, opengl.py:50-58
+
 
 struct WorldGen {
     WRoom *rooms;
@@ -453,6 +669,10 @@ struct WorldGen {
     MtWave rng;
     int lane;
     bool fail;
+    // entity tasks: the entities placed so far (slot order = list order while the world is built), in LDS
+    double *ent_x, *ent_z, *ent_r;
+    int *ent_f32;
+    int n_placed;
 
     // Room.__init__, miniworld.py:75-138
     __device__ int add_room(const double *ox, const double *oz, double height, int wall_fam, int floor_fam, int ceil_fam, int ne = 4) {
@@ -482,6 +702,10 @@ struct WorldGen {
     __device__ int add_rect_room(double min_x, double max_x, double min_z, double max_z, int wall_fam) {
         double ox[4] = {max_x, max_x, min_x, min_x}, oz[4] = {max_z, min_z, min_z, max_z};
         return add_room(ox, oz, 2.74, wall_fam, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES);
+    }
+    __device__ int add_rect_room_ex(double min_x, double max_x, double min_z, double max_z, int wall_fam, int floor_fam, int ceil_fam) {
+        double ox[4] = {max_x, max_x, min_x, min_x}, oz[4] = {max_z, min_z, min_z, max_z};
+        return add_room(ox, oz, 2.74, wall_fam, floor_fam, ceil_fam);
     }
     // edge direction as Room.__init__ / add_portal compute it: (p1 - p0) / norm
     __device__ __forceinline__ void edge(const WRoom &r, int e, double &dx, double &dz, double &len) const {
@@ -677,6 +901,7 @@ struct WorldGen {
         double other_x[MWB_MAX_BOXES] = {0, 0, 0, 0, 0, 0}, other_z[MWB_MAX_BOXES] = {0, 0, 0, 0, 0, 0}, other_radius = 0;
         double other_radius2 = -1;   // radius of the second other entity when it differs (sim-to-real boxes)
         double other_r[MWB_MAX_BOXES] = {-1, -1, -1, -1, -1, -1};   // per-entity radii where given (>= 0), else the two above
+        bool lds_ents = false, self_f32 = false;   // entity tasks: the others are WorldGen::ent_* [0, n_placed); radius is a float32 scalar
     };
     __device__ void place_entity(double radius, bool has_other, double other_x, double other_z, double other_radius,
                                  bool has_dir, double dir_in, bool has_min_x, double min_x, bool has_max_x, double max_x,
@@ -720,6 +945,12 @@ struct WorldGen {
                 const double orad = opt.other_r[k] >= 0 ? opt.other_r[k] : ((k == 1 && opt.other_radius2 >= 0) ? opt.other_radius2 : opt.other_radius);
                 if (dist < radius + orad) blocked = true;
             }
+            if (opt.lds_ents)
+                for (int k = 0; k < n_placed; k++) {
+                    double ddx = ent_x[k] - px, ddz = ent_z[k] - pz;
+                    double dist = sqrt(ddx * ddx + 0.0 + ddz * ddz);
+                    if (dist < tagged_add(radius, opt.self_f32, ent_r[k], ent_f32[k] != 0)) blocked = true;
+                }
             if (blocked) continue;
             out_dir = has_dir ? dir_in : rng.uniform(-3.141592653589793, 3.141592653589793);
             out_x = px; out_z = pz;
@@ -748,7 +979,12 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     double *segs = (double *)(smem + off); off += (size_t)d.S_max * 4 * sizeof(double);
     double *cdf = (double *)(smem + off); off += (size_t)d.R_max * sizeof(double);
     int *seg_off = (int *)(smem + off); off += (size_t)((d.R_max + 3) & ~3) * sizeof(int);
-    uint32_t *key = (uint32_t *)(smem + off);
+    uint32_t *key = (uint32_t *)(smem + off); off += 624 * sizeof(uint32_t);
+    // entity tasks: per slot x y z dir size radius height scale bias[3] (f64) and meta, radius-is-float32, colour index (i32); text textures
+    double *E_x = (double *)(smem + off), *E_y = E_x + MWB_MAX_ENTS, *E_z = E_y + MWB_MAX_ENTS, *E_dir = E_z + MWB_MAX_ENTS,
+           *E_size = E_dir + MWB_MAX_ENTS, *E_rad = E_size + MWB_MAX_ENTS, *E_hgt = E_rad + MWB_MAX_ENTS, *E_scale = E_hgt + MWB_MAX_ENTS,
+           *E_bias = E_scale + MWB_MAX_ENTS;
+    int *E_meta = (int *)(E_bias + 3 * MWB_MAX_ENTS), *E_f32 = E_meta + MWB_MAX_ENTS, *E_col = E_f32 + MWB_MAX_ENTS, *E_text = E_col + MWB_MAX_ENTS;
 
     uint32_t *st = d.rng + (size_t)e * MWB_MT_WORDS;
     for (int i = lane; i < 624; i += WAVE) key[i] = st[i];
@@ -757,7 +993,9 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     WorldGen w;
     w.rooms = rooms; w.n_rooms = 0; w.cdf = cdf; w.segs = segs; w.n_segs = 0; w.seg_off = seg_off;
     w.rng.key = key; w.rng.pos = (int)st[624]; w.rng.lane = lane; w.lane = lane; w.fail = false;
+    w.ent_x = E_x; w.ent_z = E_z; w.ent_r = E_rad; w.ent_f32 = E_f32; w.n_placed = 0;
     bool dr = d.domain_rand != 0;
+    double task_f0 = 0.0;   // CollectHealth.health after the reset
 
     double box_x = 0, box_z = 0, box_dir = 0, ag_x = 0, ag_z = 0, ag_dir = 0;
     double box2_x = 0, box2_z = 0, box2_dir = 0;
@@ -908,6 +1146,157 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         a.dir = w.rng.uniform(-3.141592653589793 / 4, 3.141592653589793 / 4);
         a.n_others = 1; a.other_radius = brad; a.other_x[0] = box_x; a.other_z[0] = box_z;
         w.place_entity_ex(arad, a, ag_x, ag_z, ag_dir);
+    } else if (d.ent_task) {
+        // ---- tasks with a general entity list.  Every lane runs the same serial logic; lane 0 records the entities in LDS.
+        auto put = [&](int b, int kind, int geom, bool is_static, int color, double size, double radius, bool f32, double height, double scale) {
+            __syncthreads();
+            if (lane == 0) {
+                E_meta[b] = kind | (geom << 4) | ((is_static ? 1 : 0) << 8) | (1 << 9) | ((f32 ? 1 : 0) << 10) | ((color + 1) << 12);
+                E_size[b] = size; E_rad[b] = radius; E_f32[b] = f32 ? 1 : 0; E_hgt[b] = height; E_scale[b] = scale; E_col[b] = color; E_y[b] = 0.0;
+            }
+            __syncthreads();
+        };
+        auto put_box = [&](int b, double size, int color) { put(b, MWB_ENT_BOX, 0, false, color, size, box_radius(size), false, size, 0.0); };
+        auto put_mesh = [&](int b, int geom, double height, bool is_static, int color) {   // MeshEnt.__init__, dimensions from the host's table
+            double sc = 0, rad = 0; bool f32 = false, found = false;
+            for (int k = 0; k < d.n_mesh_dims; k++)
+                if (d.mesh_dims[k].geom == geom && d.mesh_dims[k].height == height) { sc = d.mesh_dims[k].scale; rad = d.mesh_dims[k].radius; f32 = d.mesh_dims[k].is_f32 != 0; found = true; }
+            if (!found) w.fail = true;
+            put(b, MWB_ENT_MESH, geom, is_static, color, height, rad, f32, height, sc);
+        };
+        auto pose = [&](int b, double x, double y, double z, double dir) {
+            __syncthreads();
+            if (lane == 0) { E_x[b] = x; E_y[b] = y; E_z[b] = z; E_dir[b] = dir; }
+            __syncthreads();
+            w.n_placed = b + 1;
+        };
+        auto place = [&](int b, WorldGen::PlaceOpt &o) {   // place_entity(ent): among everything placed so far
+            o.lds_ents = true; o.self_f32 = E_f32[b] != 0;
+            double x, z, dir;
+            w.place_entity_ex(E_rad[b], o, x, z, dir);
+            pose(b, x, 0.0, z, dir);
+        };
+        auto place_at = [&](int b, double x, double y, double z, bool has_dir, double dir) {   // place_entity(ent, pos=...), miniworld.py:869-873
+            const double dd = has_dir ? dir : w.rng.uniform(-3.141592653589793, 3.141592653589793);
+            pose(b, x, y, z, dd);
+        };
+        auto place_agent = [&](WorldGen::PlaceOpt &o, double radius) {
+            o.lds_ents = true; o.self_f32 = false;
+            w.place_entity_ex(radius, o, ag_x, ag_z, ag_dir);
+        };
+        const int E = d.n_boxes;
+        if (d.task == MWB_TASK_PICKUPOBJS) {   // envs/pickupobjs.py:28-54
+            const double size = d.task_args[0];
+            w.add_rect_room_ex(0, size, 0, size, TEXF_BRICK_WALL, TEXF_ASPHALT, TEXF_CONCRETE_TILES);
+            for (int b = 0; b < E; b++) {
+                const int type = w.rng.randint(0, 3);    // self.rand.choice([Ball, Box, Key])
+                const int color = w.rng.randint(0, 6);   // self.rand.color()
+                if (type == 1) put_box(b, 0.9, color);
+                else if (type == 0) put_mesh(b, MWB_MESH_BALL, 0.9, false, color);
+                else put_mesh(b, MWB_MESH_KEY, 0.35, false, color);
+                if (b == 0) w.gen_static_data(dr, d.S_max);   // the first place_entity (after the constructor's draws)
+                WorldGen::PlaceOpt o;
+                place(b, o);
+            }
+            WorldGen::PlaceOpt a;
+            place_agent(a, arad);
+        } else if (d.task == MWB_TASK_ROOMOBJS) {   // envs/roomobjs.py:24-47 (agent.radius = 1.5: d.agent_radius)
+            const double size = d.task_args[0];
+            w.add_rect_room_ex(0, size, 0, size, TEXF_BRICK_WALL, TEXF_ASPHALT, TEXF_CONCRETE_TILES);
+            for (int b = 0; b < 3; b++) {
+                const int color = w.rng.randint(0, 6);   // an argument of the entity's constructor: drawn before the placement
+                if (b == 0) put_box(b, 0.9, color);
+                else if (b == 1) put_mesh(b, MWB_MESH_BALL, 0.9, false, color);
+                else put_mesh(b, MWB_MESH_KEY, 0.35, false, color);
+                if (b == 0) w.gen_static_data(dr, d.S_max);
+                WorldGen::PlaceOpt o;
+                place(b, o);
+            }
+            WorldGen::PlaceOpt a;
+            place_agent(a, arad);
+        } else if (d.task == MWB_TASK_COLLECTHEALTH) {   // envs/collecthealth.py:28-49
+            const double size = d.task_args[0];
+            w.add_rect_room_ex(0, size, 0, size, TEXF_CINDER_BLOCKS, TEXF_SLIME, TEXF_CONCRETE_TILES);
+            w.gen_static_data(dr, d.S_max);
+            for (int b = 0; b < 18; b++) {
+                put_mesh(b, MWB_MESH_MEDKIT, 0.40, false, -1);
+                WorldGen::PlaceOpt o;
+                place(b, o);
+            }
+            WorldGen::PlaceOpt a;
+            place_agent(a, arad);
+            task_f0 = 100.0;
+        } else if (d.task == MWB_TASK_THREEROOMS) {   // envs/threerooms.py:22-69
+            w.add_rect_room(-7, 7, 0.5, 7, TEXF_CONCRETE);
+            w.add_rect_room(-7, -1, -7, -0.5, TEXF_CONCRETE);
+            w.add_rect_room(1, 7, -7, -0.5, TEXF_CONCRETE);
+            w.connect_rooms(0, 1, 1, -5.25, -2.75, false, 0);
+            w.connect_rooms(0, 2, 1, 2.75, 5.25, false, 0);
+            w.gen_static_data(dr, d.S_max);
+            WorldGen::PlaceOpt o;
+            put_box(0, 0.8, 4); place(0, o);
+            put_box(1, 0.6, 1); place(1, o);
+            {   // ImageFrame(pos=[0, 1.35, 7], dir=pi/2, width=1.8, tex_name='logo_mila') appended: radius 0; size = its height
+                const MwbTexDesc &T = d.tex_desc[c_texf_first[TEXF_LOGO_MILA]];
+                const double fh = ((double)T.h / T.w) * 1.8;
+                put(2, MWB_ENT_IMAGE, 0, true, -1, 1.8, 0.0, false, fh, 0.0);
+                pose(2, 0.0, 1.35, 7.0, 3.141592653589793 / 2);
+            }
+            put_mesh(3, MWB_MESH_DUCKIE, 0.25, false, -1); place(3, o);
+            put_mesh(4, MWB_MESH_KEY, 0.35, false, 0); place(4, o);
+            put_mesh(5, MWB_MESH_BALL, 0.6, false, 1); place(5, o);
+            WorldGen::PlaceOpt a;
+            place_agent(a, arad);
+        } else if (d.task == MWB_TASK_SIGN) {   // envs/sign.py:75-113
+            const double size = d.task_args[0], gap = 0.25;
+            w.add_rect_room(0, size, 0, size * 0.65, TEXF_CONCRETE);
+            w.add_rect_room(0, size * 3 / 5, size * 0.65 + gap, size * 1.3, TEXF_CONCRETE);
+            w.add_rect_room(size * 3 / 5, size, size * 0.65 + gap, size * 1.3, TEXF_CONCRETE);
+            w.connect_rooms(0, 1, 1, 0, size * 3 / 5, false, 0);
+            w.connect_rooms(1, 2, 2, size * 0.65 + gap, size * 1.3, false, 0);
+            w.gen_static_data(dr, d.S_max);
+            const int box_col[3] = {0, 4, 1};   // blue, red, green
+            const double box_at[3][2] = {{1, 1}, {9, 1}, {9, 5}}, key_at[3][2] = {{5, 1}, {1, 5}, {1, 9}};
+            for (int i = 0; i < 3; i++) { put_box(i, 0.8, box_col[i]); place_at(i, box_at[i][0], 0.0, box_at[i][1], false, 0); }
+            for (int i = 0; i < 3; i++) { put_mesh(3 + i, MWB_MESH_KEY, 0.6, false, box_col[i]); place_at(3 + i, key_at[i][0], 0.0, key_at[i][1], false, 0); }   // BigKey
+            {   // TextFrame(pos=[size, 1.35, size + gap], dir=pi, str, height=1): width = len(str) * height
+                const int ci = (int)d.task_args[1];
+                const int n_ch = ci == 0 ? 4 : ci == 1 ? 3 : 5;   // "BLUE" "RED" "GREEN"
+                put(6, MWB_ENT_TEXT, 0, true, -1, (double)n_ch * 1.0, 0.0, false, 1.0, 0.0);
+                pose(6, size, 1.35, size + gap, 3.141592653589793);
+            }
+            WorldGen::PlaceOpt a;
+            a.has_min_x = a.has_max_x = a.has_min_z = a.has_max_z = true;
+            a.min_x = 4; a.max_x = 5; a.min_z = 4; a.max_z = 6;
+            place_agent(a, arad);
+        } else if (d.task == MWB_TASK_SIDEWALK) {   // envs/sidewalk.py:22-72
+            w.add_rect_room_ex(-3, 0, 0, 12, TEXF_BRICK_WALL, TEXF_CONCRETE_TILES, TEXF_CONCRETE_TILES);
+            w.add_rect_room_ex(0, 6, -80, 80, TEXF_CONCRETE, TEXF_ASPHALT, TEXF_CONCRETE_TILES);
+            w.connect_rooms(0, 1, 2, 0, 12, false, 0);
+            w.gen_static_data(dr, d.S_max);
+            put_mesh(0, MWB_MESH_BUILDING, 30, true, -1); place_at(0, 30, 0.0, 30, true, -3.141592653589793);
+            for (int i = 1; i < 6; i++) { put_mesh(i, MWB_MESH_CONE, 0.75, true, -1); place_at(i, 1, 0.0, 2 * i, false, 0); }
+            put_box(6, 0.8, 4);
+            WorldGen::PlaceOpt o;
+            o.room = 0; o.has_min_z = o.has_max_z = true; o.min_z = rooms[0].max_z - 2; o.max_z = rooms[0].max_z;
+            place(6, o);
+            WorldGen::PlaceOpt a;
+            a.room = 0; a.has_min_z = a.has_max_z = true; a.min_z = 0; a.max_z = 1.5;
+            place_agent(a, arad);
+        } else {   // MWB_TASK_WALLGAP, envs/wallgap.py:21-52
+            w.add_rect_room_ex(-7, 7, 0.5, 8, TEXF_BRICK_WALL, TEXF_ASPHALT, TEXF_CONCRETE_TILES);
+            w.add_rect_room_ex(-7, 7, -8, -0.5, TEXF_BRICK_WALL, TEXF_ASPHALT, TEXF_CONCRETE_TILES);
+            w.connect_rooms(0, 1, 1, -1.5, 1.5, false, 0);
+            w.gen_static_data(dr, d.S_max);
+            put_box(0, 0.8, 4);
+            WorldGen::PlaceOpt o;
+            o.room = 1;
+            place(0, o);
+            put_mesh(1, MWB_MESH_BUILDING, 30, true, -1); place_at(1, 30, 0.0, 30, true, -3.141592653589793);
+            WorldGen::PlaceOpt a;
+            a.room = 0;
+            place_agent(a, arad);
+        }
     } else if (d.task == MWB_TASK_HALLWAY) {   // envs/hallway.py:25-42
         double length = d.task_args[0];
         int r = w.add_rect_room(-1, -1 + length, -2, 2, TEXF_CONCRETE);
@@ -994,7 +1383,32 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     sample_param(w.rng, d.params[MWB_P_LIGHT_POS], 3, dr, lpos);
     sample_param(w.rng, d.params[MWB_P_LIGHT_COLOR], 3, dr, lcol);
     sample_param(w.rng, d.params[MWB_P_LIGHT_AMBIENT], 3, dr, lamb);
-    for (int b = 0; b < d.n_boxes; b++) sample_param(w.rng, d.params[MWB_P_OBJ_COLOR_BIAS], 3, dr, biases[b]);   // entities randomize in list order
+    if (!d.ent_task) {
+        for (int b = 0; b < d.n_boxes; b++) sample_param(w.rng, d.params[MWB_P_OBJ_COLOR_BIAS], 3, dr, biases[b]);   // entities randomize in list order
+    } else {
+        for (int b = 0; b < d.n_boxes; b++) {   // Box.randomize draws its colour bias, MeshEnt / ImageFrame draw nothing, TextFrame a texture per character
+            const int kind = E_meta[b] & 15;
+            if (kind == MWB_ENT_BOX) {
+                double bias[3];
+                sample_param(w.rng, d.params[MWB_P_OBJ_COLOR_BIAS], 3, dr, bias);
+                __syncthreads();
+                if (lane == 0) { E_bias[b * 3] = bias[0]; E_bias[b * 3 + 1] = bias[1]; E_bias[b * 3 + 2] = bias[2]; }
+                __syncthreads();
+            } else if (kind == MWB_ENT_TEXT) {   // TextFrame.randomize, entity.py:268-278: Texture.get('chars/ch_0x<ord>', rng) -> rng.int(0, 9)
+                const int ci = (int)d.task_args[1];
+                const int n_ch = ci == 0 ? 4 : ci == 1 ? 3 : 5;
+                for (int c = 0; c < 8; c++) {
+                    // index into "BLUERDGN" of character c of "BLUE" / "RED" / "GREEN"
+                    const int ch = ci == 0 ? (c == 0 ? 0 : c == 1 ? 1 : c == 2 ? 2 : 3) : ci == 1 ? (c == 0 ? 4 : c == 1 ? 3 : 5) : (c == 0 ? 6 : c == 1 ? 4 : c == 2 ? 3 : c == 3 ? 3 : 7);
+                    int t = -1;
+                    if (c < n_ch) t = MWB_TEX_CHAR0 + 9 * ch + (dr ? w.rng.randint(0, 9) : 0);
+                    __syncthreads();
+                    if (lane == 0) E_text[c] = t;
+                    __syncthreads();
+                }
+            }
+        }
+    }
     sample_param(w.rng, d.params[MWB_P_CAM_HEIGHT], 1, dr, &cam[0]);
     sample_param(w.rng, d.params[MWB_P_CAM_FWD_DISP], 1, dr, &cam[1]);
     sample_param(w.rng, d.params[MWB_P_CAM_PITCH], 1, dr, &cam[2]);
@@ -1009,7 +1423,25 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         // COLORS in COLOR_NAMES order (entity.py:8-18): blue green grey purple red yellow; Box.randomize adds the bias and clips
         const double COLORS[6][3] = {{0.0, 0.0, 1.0}, {0.0, 1.0, 0.0}, {0.39, 0.39, 0.39}, {0.44, 0.15, 0.76}, {1.0, 0.0, 0.0}, {1.00, 1.00, 0.00}};
         const size_t N = (size_t)d.N;
-        for (int b = 0; b < d.n_boxes; b++) {
+        for (int b = 0; b < d.n_boxes && d.ent_task; b++) {   // entity tasks: the slots as recorded in LDS
+            const size_t be = (size_t)b * N + e;
+            const int kind = E_meta[b] & 15, ci = E_col[b];
+            d.box_x[be] = E_x[b]; d.box_y[be] = E_y[b]; d.box_z[be] = E_z[b]; d.box_dir[be] = E_dir[b]; d.box_size[be] = E_size[b];
+            d.ent_meta[be] = E_meta[b]; d.ent_radius[be] = E_rad[b]; d.ent_height[be] = E_hgt[b]; d.ent_scale[be] = E_scale[b];
+            for (int k = 0; k < 3; k++) {   // Box: COLORS[c] + bias, clipped; mesh: the material's Kd = COLORS[c], white without one
+                double v = ci >= 0 ? COLORS[ci][k] : 1.0;
+                if (kind == MWB_ENT_BOX) { v = v + E_bias[b * 3 + k]; v = v < 0 ? 0 : (v > 1 ? 1 : v); }
+                d.box_color[be * 3 + k] = v;
+            }
+        }
+        if (d.ent_task) {
+            uint8_t *ord = d.ent_order + (size_t)e * MWB_ORDER_STRIDE;
+            for (int k = 0; k < MWB_ORDER_STRIDE; k++) ord[k] = k < d.n_boxes ? (uint8_t)k : (uint8_t)MWB_ENT_AGENT;   // [0 .. E-1, agent]
+            d.n_order[e] = d.n_boxes + 1;
+            d.task_f[e] = task_f0; d.task_i[e] = 0; d.ovr_slot[e] = -1;
+            for (int c = 0; c < 8; c++) d.text_tex[e * 8 + c] = d.task == MWB_TASK_SIGN ? E_text[c] : -1;
+        }
+        for (int b = 0; b < d.n_boxes && !d.ent_task; b++) {
             int base = 4;   // red
             double x = box_x, z = box_z, dir = box_dir, sz = box_s;
             if (d.task == MWB_TASK_PUTNEXT) { base = b; x = pn_x[b]; z = pn_z[b]; dir = pn_dir[b]; sz = pn_s[b]; }
@@ -1189,17 +1621,93 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
     // meet the cone around the view direction that contains the whole image (half angle atan |(TW, TH)|)?  Conservative
     // (2 % + 0.01 rad slack); in a maze the box is out of view in most frames and the tests are skipped wholesale.
     float any_in_view = 0.0f;
-    for (int bi = 0; bi < d.n_boxes; bi++) {   // one block of FC_BOX_STRIDE words per box
-    const size_t be = (size_t)bi * d.N + e;
+    for (int bi = 0; bi < (d.ent_task ? MWB_MAX_ENTS : d.n_boxes); bi++) {   // one block of FC_BOX_STRIDE words per box / entity slot
     fc = d.frame + (size_t)e * d.frame_words + bi * FC_BOX_STRIDE;
+    if (bi >= d.n_boxes) {   // entity tasks: the render kernel is compiled for MWB_MAX_ENTS slots; the unused ones meet no ray
+        fc[FC_BOX_HX] = -3.0f;
+        fc[FC_CULL_OC] = 0.0f; fc[FC_CULL_OC + 1] = 0.0f; fc[FC_CULL_OC + 2] = 0.0f;
+        fc[FC_CULL_CC] = INFINITY; fc[FC_CULL_CC_PIXEL] = INFINITY;
+        continue;
+    }
+    const size_t be = (size_t)bi * d.N + e;
     float bcol[3];
     for (int k = 0; k < 3; k++) bcol[k] = (float)d.box_color[be * 3 + k];
     double bdir = d.box_dir[be];
+    double px = d.box_x[be], py = d.box_y[be], pz = d.box_z[be];
+    if (d.ent_task) {   // entity tasks: the block is read by kind (mwb_internal.h); an entity that left the list is never met by a ray
+        const int meta = d.ent_meta[be];
+        const int kind = MWB_META_KIND(meta);
+        bool alive = MWB_META_ALIVE(meta) != 0;
+        if (d.step_pass && d.ovr_slot[e] == bi) {   // the step's own frame: as the entity was before the task rule removed / respawned it
+            px = d.ovr_pose[e * 4 + 0]; py = d.ovr_pose[e * 4 + 1]; pz = d.ovr_pose[e * 4 + 2]; bdir = d.ovr_pose[e * 4 + 3];
+            alive = true;
+        }
+        float *blk = fc + FC_LIT_BOX;
+        const float bpos[3] = {(float)px, (float)py, (float)pz};
+        const float c_ = (float)ref_cos(bdir), s_ = (float)ref_sin(bdir);
+        fc[FC_BOX_POS] = bpos[0]; fc[FC_BOX_POS + 1] = bpos[1]; fc[FC_BOX_POS + 2] = bpos[2];
+        fc[FC_BOX_C] = c_; fc[FC_BOX_S] = s_;
+        const float ro[3] = {eye[0] - bpos[0], eye[1] - bpos[1], eye[2] - bpos[2]};
+        float sph_c[3] = {0, 0, 0}, R = 0.0f;   // bounding sphere (world), 2 % larger
+        if (!alive) {
+            fc[FC_BOX_HX] = -3.0f;
+            fc[FC_CULL_OC] = 0.0f; fc[FC_CULL_OC + 1] = 0.0f; fc[FC_CULL_OC + 2] = 0.0f;
+            fc[FC_CULL_CC] = INFINITY; fc[FC_CULL_CC_PIXEL] = INFINITY;
+            continue;
+        }
+        if (kind == MWB_ENT_MESH) {
+            const MwbMeshDesc &md = d.mesh_desc[MWB_META_GEOM(meta)];
+            const double scale = d.ent_scale[be];
+            const float inv_s = (float)(1.0 / scale);
+            fc[FC_BOX_HX] = -1.0f; fc[FC_BOX_HZ] = 0.0f; fc[FC_BOX_SY] = 0.0f;
+            blk[FE_MESH_LL] = (L[0] * c_ - L[2] * s_) * inv_s; blk[FE_MESH_LL + 1] = L[1] * inv_s; blk[FE_MESH_LL + 2] = (L[0] * s_ + L[2] * c_) * inv_s;
+            for (int k = 0; k < 3; k++) { blk[FE_MESH_KD + k] = bcol[k]; blk[FE_MESH_AMB + k] = 0.2f * bcol[k] + amb[k] * bcol[k]; blk[FE_MESH_DIF + k] = dif[k]; }
+            blk[FE_MESH_INVS] = inv_s; blk[FE_MESH_GEOM] = __int_as_float(MWB_META_GEOM(meta)); blk[FE_MESH_TEX] = __int_as_float(md.tex_id);
+            fc[FC_BOX_LO] = (ro[0] * c_ - ro[2] * s_) * inv_s; fc[FC_BOX_LO + 1] = ro[1] * inv_s; fc[FC_BOX_LO + 2] = (ro[0] * s_ + ro[2] * c_) * inv_s;
+            float lc[3], ext2 = 0.0f;
+            for (int k = 0; k < 3; k++) { lc[k] = 0.5f * (md.min_c[k] + md.max_c[k]); const float h = 0.5f * (md.max_c[k] - md.min_c[k]); ext2 += h * h; }
+            const float sc = (float)scale;
+            sph_c[0] = bpos[0] + sc * (lc[0] * c_ + lc[2] * s_); sph_c[1] = bpos[1] + sc * lc[1]; sph_c[2] = bpos[2] + sc * (-lc[0] * s_ + lc[2] * c_);
+            R = 1.02f * sc * sqrtf(ext2);
+        } else if (kind == MWB_ENT_IMAGE || kind == MWB_ENT_TEXT) {
+            const float sx = 0.05f, hy = (float)(d.ent_height[be] / 2), hz = (float)(d.box_size[be] / 2);   // depth, height / 2, width / 2
+            fc[FC_BOX_HX] = -2.0f; fc[FC_BOX_HZ] = 0.0f; fc[FC_BOX_SY] = 0.0f;
+            lit_color(L, amb, dif, c_, 0.0f, -s_, white, blk + FE_FRAME_LIT);   // the front's normal (1, 0, 0) turned by the heading
+            blk[FE_FRAME_SX] = sx; blk[FE_FRAME_HY] = hy; blk[FE_FRAME_HZ] = hz;
+            blk[FE_FRAME_CW] = kind == MWB_ENT_TEXT ? (float)d.ent_height[be] : (float)d.box_size[be];
+            int n_ch = 1;
+            if (kind == MWB_ENT_TEXT) { n_ch = 0; for (int c = 0; c < 8; c++) if (d.text_tex[e * 8 + c] >= 0) n_ch = c + 1; }
+            blk[FE_FRAME_NCH] = __int_as_float(n_ch);
+            for (int c = 0; c < 8; c++) blk[FE_FRAME_TEX + c] = __int_as_float(kind == MWB_ENT_TEXT ? d.text_tex[e * 8 + c] : (c == 0 ? 20 : -1));   // 20: logo_mila_1
+            fc[FC_BOX_LO] = ro[0] * c_ - ro[2] * s_; fc[FC_BOX_LO + 1] = ro[1]; fc[FC_BOX_LO + 2] = ro[0] * s_ + ro[2] * c_;
+            sph_c[0] = bpos[0] + 0.5f * sx * c_; sph_c[1] = bpos[1]; sph_c[2] = bpos[2] - 0.5f * sx * s_;
+            R = 1.02f * sqrtf(0.25f * sx * sx + hy * hy + hz * hz);
+        }
+        if (kind != MWB_ENT_BOX) {   // cull sphere, its pixel-inflated twin and the frame-level gate, as for a box below
+            const float oc[3] = {sph_c[0] - eye[0], sph_c[1] - eye[1], sph_c[2] - eye[2]};
+            fc[FC_CULL_OC] = oc[0]; fc[FC_CULL_OC + 1] = oc[1]; fc[FC_CULL_OC + 2] = oc[2];
+            const float oc2 = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2];
+            fc[FC_CULL_CC] = oc2 - R * R;
+            const float tw = (float)(th * ((double)d.W / (double)d.H)) / (float)d.W, thh = (float)th / (float)d.H;
+            const float rho = 1.5f * 2.0f * sqrtf(tw * tw + thh * thh);
+            const float Rp = R + rho * (sqrtf(oc2) + R);
+            fc[FC_CULL_CC_PIXEL] = oc2 - Rp * Rp;
+            const double dist = sqrt((double)oc2), Rg = 1.02 * (double)Rp;
+            if (dist <= Rg) any_in_view = 1.0f;
+            else {
+                const double cosang = ((double)oc[0] * f[0] + (double)oc[1] * f[1] + (double)oc[2] * f[2]) / dist;
+                const double ang = acos(cosang < -1 ? -1 : (cosang > 1 ? 1 : cosang));
+                const double half = atan(sqrt(th * th * ((double)d.W / d.H) * ((double)d.W / d.H) + th * th));
+                if (ang <= half + asin(Rg / dist) + 0.01) any_in_view = 1.0f;
+            }
+            continue;
+        }
+    }
     float bc = (float)ref_cos(bdir), bs = (float)ref_sin(bdir);
     const float ln[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
     for (int k = 0; k < 6; k++)   // world normal = R_y(dir) n_local (glRotatef about +Y)
         lit_color(L, amb, dif, ln[k][0] * bc + ln[k][2] * bs, ln[k][1], -ln[k][0] * bs + ln[k][2] * bc, bcol, fc + FC_LIT_BOX + 3 * k);
-    float bpos[3] = {(float)d.box_x[be], (float)d.box_y[be], (float)d.box_z[be]};   // y > 0 while the box is carried
+    float bpos[3] = {(float)px, (float)py, (float)pz};   // y > 0 while the box is carried
     const double bsz = d.box_size[be];   // Box.render: extents +-sx/2, 0..sy, +-sz/2 (entity.py:385-408)
     float hx = (float)(bsz / 2), hz = (float)(bsz / 2), sy = (float)bsz;
     fc[FC_BOX_POS] = bpos[0]; fc[FC_BOX_POS + 1] = bpos[1]; fc[FC_BOX_POS + 2] = bpos[2];
@@ -1518,6 +2026,114 @@ __device__ __forceinline__ int trace_box(const float *fc, const float *dv, float
     return face;
 }
 
+// ---- mesh entities and frames (entity tasks; oracle/mw_oracle.c trace_mesh / trace_frame state the same arithmetic) ---------------
+#define KIND_MESH 5u
+#define KIND_FRAME 6u
+__device__ __forceinline__ float dot3f(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+__device__ __forceinline__ void cross3f(const float *a, const float *b, float *o) {
+    o[0] = fmaf(a[1], b[2], -(a[2] * b[1])); o[1] = fmaf(a[2], b[0], -(a[0] * b[2])); o[2] = fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+// the ray direction in the mesh's frame: R^T d / scale (the ray parameter stays the world's)
+__device__ __forceinline__ void mesh_local_dir(const float *blk, const float *dv, float *ld) {
+    const float c = blk[FC_BOX_C], s = blk[FC_BOX_S], inv_s = blk[FC_LIT_BOX + FE_MESH_INVS];
+    ld[0] = fmaf(dv[0], c, -(dv[2] * s)) * inv_s; ld[1] = dv[1] * inv_s; ld[2] = fmaf(dv[0], s, dv[2] * c) * inv_s;
+}
+// Moeller-Trumbore against one triangle record (v0, e1, e2): u, v (not divided), det; front faces only (det > 0)
+__device__ __forceinline__ bool mesh_tri(const float *lo, const float *ld, const float4 r0, const float4 r1, const float4 r2, bool need_inside,
+                                         float &t, float &u, float &v, float &det) {
+    const float v0[3] = {r0.x, r0.y, r0.z}, e1[3] = {r0.w, r1.x, r1.y}, e2[3] = {r1.z, r1.w, r2.x};
+    float pv[3], qv[3];
+    cross3f(ld, e2, pv);
+    det = dot3f(e1, pv);
+    if (!(det > 0.0f)) return false;
+    const float tv[3] = {lo[0] - v0[0], lo[1] - v0[1], lo[2] - v0[2]};
+    u = dot3f(tv, pv);
+    cross3f(tv, e1, qv);
+    v = dot3f(ld, qv);
+    if (need_inside && (u < 0.0f || u > det || v < 0.0f || u + v > det)) return false;
+    t = dot3f(e2, qv) / det;
+    return need_inside ? t > 0.0f : true;
+}
+// nearest front-facing triangle of the entity's mesh along (eye, dv) that is strictly nearer than t_max: its index in draw order
+// or -1.  Threaded BVH (host-built, gym_miniworld_amd/meshes.py): depth-first node order, `skip` links, no stack.
+__device__ __forceinline__ int trace_mesh_bvh(const float *blk, const MwbMeshDesc *__restrict__ descs, const float4 *__restrict__ data,
+                                              const float *dv, float t_max, float &t_out) {
+    float ld[3];
+    mesh_local_dir(blk, dv, ld);
+    const float lo[3] = {blk[FC_BOX_LO], blk[FC_BOX_LO + 1], blk[FC_BOX_LO + 2]};
+    const int geom = __builtin_amdgcn_readfirstlane(__float_as_int(blk[FC_LIT_BOX + FE_MESH_GEOM]));
+    const MwbMeshDesc &md = descs[geom];
+    const float4 *nodes = data + md.node_off, *tris = data + md.tri_off;
+    const int n_nodes = md.n_nodes;
+    const float ix = 1.0f / ld[0], iy = 1.0f / ld[1], iz = 1.0f / ld[2];
+    int node = 0, best = -1;
+    float bt = t_max;
+    while (node < n_nodes) {
+        const float4 a = nodes[2 * node], b = nodes[2 * node + 1];
+        float t0 = (a.x - lo[0]) * ix, t1 = (b.x - lo[0]) * ix;
+        float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+        t0 = (a.y - lo[1]) * iy; t1 = (b.y - lo[1]) * iy;
+        tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+        t0 = (a.z - lo[2]) * iz; t1 = (b.z - lo[2]) * iz;
+        tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+        const uint32_t fcnt = (uint32_t)__float_as_int(b.w);
+        if (!(tn <= tf && tf > 0.0f && tn <= bt)) { node = __float_as_int(a.w); continue; }   // boxes are padded: never rejects a real hit
+        const int cnt = (int)(fcnt >> 24);
+        if (cnt == 0) { node++; continue; }
+        const int first = (int)(fcnt & 0xFFFFFFu);
+        for (int k = 0; k < cnt; k++) {
+            const float4 r0 = tris[3 * (first + k)], r1 = tris[3 * (first + k) + 1], r2 = tris[3 * (first + k) + 2];
+            float t, u, v, det;
+            if (mesh_tri(lo, ld, r0, r1, r2, true, t, u, v, det)) {
+                const int idx = __float_as_int(r2.y);
+                if (t < bt || (t == bt && best >= 0 && idx < best)) { bt = t; best = idx; }   // ties: the first triangle drawn
+            }
+        }
+        node = __float_as_int(a.w);
+    }
+    t_out = bt;
+    return best;
+}
+// ImageFrame / TextFrame: slab [0, depth] x [-h/2, h/2] x [-w/2, w/2] in the frame's axes; returns the character cell of the
+// front (+x) face, 100 for a black side, -1 for a miss or the missing back
+__device__ __forceinline__ int trace_frame(const float *blk, const float *dv, float &t_out) {
+    const float c = blk[FC_BOX_C], s = blk[FC_BOX_S];
+    const float *fe = blk + FC_LIT_BOX;
+    const float ld[3] = {fmaf(dv[0], c, -(dv[2] * s)), dv[1], fmaf(dv[0], s, dv[2] * c)};
+    const float lo_[3] = {blk[FC_BOX_LO], blk[FC_BOX_LO + 1], blk[FC_BOX_LO + 2]};
+    const float lo[3] = {0.0f, -fe[FE_FRAME_HY], -fe[FE_FRAME_HZ]}, hi[3] = {fe[FE_FRAME_SX], fe[FE_FRAME_HY], fe[FE_FRAME_HZ]};
+    float tn = -INFINITY, tf = INFINITY;
+    int face = -1;
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        if (ld[a] == 0) { miss = miss || lo_[a] < lo[a] || lo_[a] > hi[a]; continue; }
+        const float inv = 1.0f / ld[a];
+        const float t1 = (lo[a] - lo_[a]) * inv, t2 = (hi[a] - lo_[a]) * inv;
+        const float tmin = t1 < t2 ? t1 : t2, tmax = t1 < t2 ? t2 : t1;
+        if (tmin > tn) { tn = tmin; face = a * 2 + (ld[a] > 0 ? 0 : 1); }
+        if (tmax < tf) tf = tmax;
+    }
+    if (miss || face <= 0 || !(tn <= tf) || !(tn > 0)) return -1;   // face 0 = the -x side: not drawn
+    t_out = tn;
+    if (face != 1) return 100;
+    const float z = fmaf(tn, ld[2], lo_[2]);
+    const int n_ch = __float_as_int(fe[FE_FRAME_NCH]);
+    int i = (int)floorf((fe[FE_FRAME_HZ] - z) / fe[FE_FRAME_CW]);
+    return i < 0 ? 0 : (i >= n_ch ? n_ch - 1 : i);
+}
+__device__ __forceinline__ bool frame_front_tc(const float *blk, int cell, const float *dv, float &s_, float &t_) {
+    const float c = blk[FC_BOX_C], s = blk[FC_BOX_S];
+    const float *fe = blk + FC_LIT_BOX;
+    const float ld[3] = {fmaf(dv[0], c, -(dv[2] * s)), dv[1], fmaf(dv[0], s, dv[2] * c)};
+    const float lo_[3] = {blk[FC_BOX_LO], blk[FC_BOX_LO + 1], blk[FC_BOX_LO + 2]};
+    const float tt = (fe[FE_FRAME_SX] - lo_[0]) / ld[0];
+    const float y = fmaf(tt, ld[1], lo_[1]), z = fmaf(tt, ld[2], lo_[2]);
+    const float z1 = fe[FE_FRAME_HZ] - fe[FE_FRAME_CW] * (float)cell;
+    s_ = (z1 - z) / fe[FE_FRAME_CW]; t_ = (y + fe[FE_FRAME_HY]) / (2.0f * fe[FE_FRAME_HY]);
+    return ld[0] != 0.0f && tt > 0.0f;
+}
+
 // ---- shading: continuous in its inputs, so fused / approximate arithmetic is within the +-1 LSB bar
 struct TexLds { int w, h, n_levels; float sc_s, sc_t; int pad[3]; uint32_t off[MWB_MAX_LEVELS]; };
 static_assert(sizeof(TexLds) == sizeof(MwbTexDesc), "TexLds mirrors MwbTexDesc");
@@ -1608,6 +2224,8 @@ struct RenderCtx {
     int n_rooms, cam_room, W, H, layout;
     float cull_cc[1], cull_oc[1][3], zA, zB;   // the box's cull constants (NBOX == 1 only: scalar registers)
     bool boxes_in_view;   // workgroup-uniform (scalar): false = no ray of this frame can touch a box
+    const MwbMeshDesc *mesh_desc;   // entity tasks: mesh geometries in HBM (L2 resident), or null
+    const float4 *mesh_data;
     // per work item (15 x 15 pixels), which boxes can touch any of its rays at all (frame-level pre-test pass; null = unknown)
     const uint4 *item_res;
     int part_h_inv;       // ceil(65536 / rows per item): row -> quarter without a division
@@ -1702,10 +2320,102 @@ struct RenderCtx {
 
     // INTERIOR: the caller guarantees a room surface (floor / ceiling / wall) whose plane the pixel's centre ray meets
     // in front of the eye (the four corner rays of the pixel do): no sky / box cases, no fallback to a sample's ray.
+    // One shade per (pixel, triangle) with the attributes evaluated at the PIXEL CENTRE (extrapolated, as a multisampling
+    // rasteriser without centroid sampling does): per-vertex fixed-function lighting with the normal R n / scale (not
+    // renormalised: GL_NORMALIZE is off), clamped to 1, interpolated with the centre ray's barycentrics; where the centre ray sees
+    // the triangle's back or edge, the covering sample's ray instead; a textured mesh modulates by its image.
+    __device__ __noinline__ void shade_mesh(uint32_t key, int first_k, float cx, float cy, float *col) const {
+        const int bi = (int)((key >> 3) & 31u), tri = (int)(key >> 8);
+        const float *blk = fc + bi * FC_BOX_STRIDE;
+        const float *me = blk + FC_LIT_BOX;
+        const MwbMeshDesc &md = mesh_desc[__float_as_int(me[FE_MESH_GEOM])];
+        const float4 *rec = mesh_data + md.tri2_off + 3 * tri, *sh = mesh_data + md.shade_off + 4 * tri;
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3];
+        const float nrm[3][3] = {{s0.x, s0.y, s0.z}, {s0.w, s1.x, s1.y}, {s1.z, s1.w, s2.x}};
+        const float tc[6] = {s2.y, s2.z, s2.w, s3.x, s3.y, s3.z};
+        float vc[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float ndl = nrm[k][0] * me[FE_MESH_LL] + nrm[k][1] * me[FE_MESH_LL + 1] + nrm[k][2] * me[FE_MESH_LL + 2];
+            ndl = ndl < 0.0f ? 0.0f : ndl;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const float v = me[FE_MESH_AMB + q] + ndl * me[FE_MESH_DIF + q] * me[FE_MESH_KD + q];
+                vc[k][q] = v > 1.0f ? 1.0f : v;
+            }
+        }
+        const float lo[3] = {blk[FC_BOX_LO], blk[FC_BOX_LO + 1], blk[FC_BOX_LO + 2]};
+        float dc[3], ld[3], t, u, v, det;
+        make_ray(cam, cx, cy, dc);
+        mesh_local_dir(blk, dc, ld);
+        const bool centre_ok = mesh_tri(lo, ld, r0, r1, r2, false, t, u, v, det);
+        if (!centre_ok) {
+            float ds[3];
+            make_ray(cam, cx + c_sample_x[first_k], cy + c_sample_y[first_k], ds);
+            mesh_local_dir(blk, ds, ld);
+            mesh_tri(lo, ld, r0, r1, r2, false, t, u, v, det);
+        }
+        const float ub = u / det, vb = v / det;
+#pragma unroll
+        for (int q = 0; q < 3; q++) col[q] = fmaf(vb, vc[2][q] - vc[0][q], fmaf(ub, vc[1][q] - vc[0][q], vc[0][q]));
+        const int tex_id = __float_as_int(me[FE_MESH_TEX]);
+        if (tex_id >= 0) {
+            const float s_0 = fmaf(vb, tc[4] - tc[0], fmaf(ub, tc[2] - tc[0], tc[0])), t_0 = fmaf(vb, tc[5] - tc[1], fmaf(ub, tc[3] - tc[1], tc[1]));
+            float s_1 = s_0, t_1 = t_0, s_2 = s_0, t_2 = t_0;
+            bool valid = false;
+            if (centre_ok) {
+                float dx[3], dy[3], l1[3], l2[3], tt, u1, v1, d1, u2, v2, d2;
+                neighbour_rays(dc, dx, dy);
+                mesh_local_dir(blk, dx, l1); mesh_local_dir(blk, dy, l2);
+                const bool ok1 = mesh_tri(lo, l1, r0, r1, r2, false, tt, u1, v1, d1), ok2 = mesh_tri(lo, l2, r0, r1, r2, false, tt, u2, v2, d2);
+                valid = ok1 && ok2;
+                if (valid) {
+                    u1 /= d1; v1 /= d1; u2 /= d2; v2 /= d2;
+                    s_1 = fmaf(v1, tc[4] - tc[0], fmaf(u1, tc[2] - tc[0], tc[0])); t_1 = fmaf(v1, tc[5] - tc[1], fmaf(u1, tc[3] - tc[1], tc[1]));
+                    s_2 = fmaf(v2, tc[4] - tc[0], fmaf(u2, tc[2] - tc[0], tc[0])); t_2 = fmaf(v2, tc[5] - tc[1], fmaf(u2, tc[3] - tc[1], tc[1]));
+                }
+            }
+            float texel[3];
+            sample_texture(texels, tex[tex_id], s_0, t_0, s_1, t_1, s_2, t_2, valid, texel);
+#pragma unroll
+            for (int q = 0; q < 3; q++) col[q] = col[q] * (texel[q] * (1.0f / 255.0f));
+        }
+    }
+    // the front of an ImageFrame / TextFrame (its picture, or one texture per character; a blank cell is plain lit white) or a black side
+    __device__ __noinline__ void shade_frame(uint32_t key, int first_k, float cx, float cy, float *col) const {
+        const int bi = (int)((key >> 3) & 31u), code = (int)(key >> 8);
+        const float *blk = fc + bi * FC_BOX_STRIDE;
+        const float *fe = blk + FC_LIT_BOX;
+        if (code >= 100) { col[0] = 0.0f; col[1] = 0.0f; col[2] = 0.0f; return; }
+        const int tex_id = __float_as_int(fe[FE_FRAME_TEX + code]);
+        if (tex_id < 0) { col[0] = fe[FE_FRAME_LIT]; col[1] = fe[FE_FRAME_LIT + 1]; col[2] = fe[FE_FRAME_LIT + 2]; return; }
+        float dc[3], dx[3], dy[3], s0, t0, s1, t1, s2, t2;
+        make_ray(cam, cx, cy, dc);
+        neighbour_rays(dc, dx, dy);
+        bool valid;
+        if (!frame_front_tc(blk, code, dc, s0, t0)) {
+            float ds[3];
+            make_ray(cam, cx + c_sample_x[first_k], cy + c_sample_y[first_k], ds);
+            frame_front_tc(blk, code, ds, s0, t0);
+            valid = false; s1 = s2 = s0; t1 = t2 = t0;
+        } else {
+            const bool v1 = frame_front_tc(blk, code, dx, s1, t1), v2 = frame_front_tc(blk, code, dy, s2, t2);
+            valid = v1 && v2;
+        }
+        float texel[3];
+        sample_texture(texels, tex[tex_id], s0, t0, s1, t1, s2, t2, valid, texel);
+#pragma unroll
+        for (int q = 0; q < 3; q++) col[q] = fe[FE_FRAME_LIT + q] * (texel[q] * (1.0f / 255.0f));
+    }
+
     template <bool INTERIOR>
     __device__ __forceinline__ void shade(uint32_t key, int first_k, float cx, float cy, float *col) const {
         if constexpr (POLY) { shade_poly<INTERIOR>(key, first_k, cx, cy, col); return; }
         const uint32_t kind = key & 7u, side = (key >> 3) & 3u;
+        if constexpr (!INTERIOR && NBOX > MWB_MAX_BOXES) {   // entity tasks
+            if (kind == KIND_MESH) { shade_mesh(key, first_k, cx, cy, col); return; }
+            if (kind == KIND_FRAME) { shade_frame(key, first_k, cx, cy, col); return; }
+        }
         if (!INTERIOR) {
             if (kind == KIND_SKY) { col[0] = fc[FC_SKY]; col[1] = fc[FC_SKY + 1]; col[2] = fc[FC_SKY + 2]; return; }
             if (kind == KIND_BOX) {   // the key's room field holds the box index
@@ -1850,8 +2560,21 @@ struct RenderCtx {
                     const float b = dv[0] * fb_[FC_CULL_OC] + dv[1] * fb_[FC_CULL_OC + 1] + dv[2] * fb_[FC_CULL_OC + 2];
                     if (((my_boxes >> bi) & 1u) && (cc <= 0.0f || (b > 0.0f && b * b >= dd * cc))) {
                         float tb;
-                        int face = trace_box(fb_, dv, tb);
-                        if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, bi); th = tb; }
+                        int ekind = 0;   // 0 box, 1 mesh, 2 frame (entity tasks; workgroup-uniform per slot)
+                        if constexpr (NBOX > MWB_MAX_BOXES) {
+                            const float hxk = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb_[FC_BOX_HX])));
+                            ekind = hxk == -1.0f ? 1 : hxk == -2.0f ? 2 : 0;
+                        }
+                        if (ekind == 1) {
+                            const int tri = trace_mesh_bvh(fb_, mesh_desc, mesh_data, dv, th, tb);
+                            if (tri >= 0) { key = KIND_MESH | ((uint32_t)bi << 3) | ((uint32_t)tri << 8); th = tb; }
+                        } else if (ekind == 2) {
+                            const int code = trace_frame(fb_, dv, tb);
+                            if (code >= 0 && tb < th) { key = KIND_FRAME | ((uint32_t)bi << 3) | ((uint32_t)code << 8); th = tb; }
+                        } else {
+                            int face = trace_box(fb_, dv, tb);
+                            if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, bi); th = tb; }
+                        }
                     }
                 }
             }
@@ -1978,6 +2701,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     __syncthreads();
     RenderCtx<NBOX, POLY> ctx;
     ctx.rooms = rooms; ctx.fc = fc; ctx.tex = tex; ctx.texels = d.texels; ctx.fb = fb;
+    ctx.mesh_desc = d.mesh_desc; ctx.mesh_data = d.mesh_data;
     ctx.depth = d.want_depth ? d.depth + (size_t)e * W * H : nullptr;
     ctx.n_rooms = n_rooms; ctx.W = W; ctx.H = H; ctx.layout = d.layout;
     Cam &cam = ctx.cam;
@@ -2357,8 +3081,9 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
 // MODE 0: every env; 1: only the envs regenerated this step (side stream, through the compact list);
 // 2: all the others (bulk).  A template parameter so that the three launches carry distinct kernel names
 // in profiles.
+// NBOX = MWB_MAX_ENTS: the entity tasks' instantiation (mesh BVH walks, frames): 4 workgroups per CU (128 VGPRs) instead of 5
 template <int THREADS, int MODE, int NBOX, bool POLY = false>
-__global__ void __launch_bounds__(THREADS, 5) render_kernel(MwbDev d) {
+__global__ void __launch_bounds__(THREADS, NBOX > MWB_MAX_BOXES ? 4 : 5) render_kernel(MwbDev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (MODE == 1) {
         __builtin_amdgcn_s_setprio(3);   // the few regenerated envs, beside the bulk render (see reset_kernel)
@@ -2485,6 +3210,21 @@ __global__ void intersect_kernel(MwbDev d, int e, int ent, double x, double z, d
         for (int c = 0; c < 4; c++) q[c] = d.segs[(size_t)(i * 4 + c) * d.N + e];
         if (seg_hit(q, x, z, radius)) res = 1;
     }
+    if (d.ent_task) {   // the entity list in its current order, radii from the entities (tagged sums: the query radius is a Python float)
+        const uint8_t *ord = d.ent_order + (size_t)e * MWB_ORDER_STRIDE;
+        const int n_ord = d.n_order[e];
+        for (int k = 0; k < n_ord && !res; k++) {
+            const int slot = ord[k];
+            if (slot == (ent == d.n_boxes ? MWB_ENT_AGENT : ent)) continue;
+            double ox, oz, orad; bool of32 = false;
+            if (slot == MWB_ENT_AGENT) { ox = d.agent_x[e]; oz = d.agent_z[e]; orad = d.agent_radius; }
+            else { const size_t be = (size_t)slot * d.N + e; ox = d.box_x[be]; oz = d.box_z[be]; orad = d.ent_radius[be]; of32 = MWB_META_RADF32(d.ent_meta[be]) != 0; }
+            const double ddx = ox - x, ddz = oz - z;
+            if (sqrt(ddx * ddx + 0.0 + ddz * ddz) < tagged_add(radius, false, orad, of32)) res = 2 + (slot == MWB_ENT_AGENT ? d.n_boxes : slot);
+        }
+        *result = res;
+        return;
+    }
     for (int b = 0; b < d.n_boxes && !res; b++) {
         if (b == ent) continue;
         double ddx = d.box_x[(size_t)b * d.N + e] - x, ddz = d.box_z[(size_t)b * d.N + e] - z;
@@ -2501,7 +3241,8 @@ __global__ void intersect_kernel(MwbDev d, int e, int ent, double x, double z, d
 #define RENDER_THREADS 256
 size_t mwb_reset_lds_bytes(const MwbDev &d) {
     size_t b = (size_t)d.R_max * sizeof(WRoom) + (size_t)d.S_max * 4 * sizeof(double) + (size_t)d.R_max * sizeof(double) +
-               (size_t)((d.R_max + 3) & ~3) * sizeof(int) + 624 * sizeof(uint32_t);
+               (size_t)((d.R_max + 3) & ~3) * sizeof(int) + 624 * sizeof(uint32_t) +
+               (size_t)MWB_MAX_ENTS * (11 * sizeof(double) + 3 * sizeof(int)) + 8 * sizeof(int);   // the entity tasks' slot records
     return (b + 15) & ~(size_t)15;
 }
 size_t mwb_render_lds_bytes(const MwbDev &d) {
@@ -2512,6 +3253,7 @@ size_t mwb_render_lds_bytes(const MwbDev &d) {
 }
 
 void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *skip, hipStream_t s) {
+    if (d.ent_task) { hipLaunchKernelGGL(step_ents_kernel, dim3((d.N + 63) / 64), dim3(64), 0, s, d, actions, skip); return; }
     const dim3 g((d.N + 63) / 64), b(64 * STEP_PARTS);
     if (d.n_boxes == 1) hipLaunchKernelGGL(step_kernel<1>, g, b, 0, s, d, actions, skip);
     else if (d.n_boxes == 2) hipLaunchKernelGGL(step_kernel<2>, g, b, 0, s, d, actions, skip);
@@ -2538,8 +3280,9 @@ int mwb_prepare_kernels(const MwbDev &d) {
                                  {(const void *)render_kernel<RENDER_THREADS, 0, 2>, (const void *)render_kernel<RENDER_THREADS, 1, 2>, (const void *)render_kernel<RENDER_THREADS, 2, 2>},
                                  {(const void *)render_kernel<RENDER_THREADS, 0, 6>, (const void *)render_kernel<RENDER_THREADS, 1, 6>, (const void *)render_kernel<RENDER_THREADS, 2, 6>}};
         const void *pfns[3] = {(const void *)render_kernel<RENDER_THREADS, 0, 1, true>, (const void *)render_kernel<RENDER_THREADS, 1, 1, true>, (const void *)render_kernel<RENDER_THREADS, 2, 1, true>};
+        const void *efns[3] = {(const void *)render_kernel<RENDER_THREADS, 0, MWB_MAX_ENTS>, (const void *)render_kernel<RENDER_THREADS, 1, MWB_MAX_ENTS>, (const void *)render_kernel<RENDER_THREADS, 2, MWB_MAX_ENTS>};
         for (int m = 0; m < 3; m++)
-            if (hipFuncSetAttribute(d.poly ? pfns[m] : fns[d.n_boxes == 6 ? 2 : d.n_boxes == 2 ? 1 : 0][m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess) return -2;
+            if (hipFuncSetAttribute(d.ent_task ? efns[m] : d.poly ? pfns[m] : fns[d.n_boxes == 6 ? 2 : d.n_boxes == 2 ? 1 : 0][m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)q) != hipSuccess) return -2;
     }
     return 0;
 }
@@ -2557,6 +3300,12 @@ void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
     const dim3 g(d.N + d.split_envs), b(RENDER_THREADS);
     const size_t lds = mwb_render_lds_bytes(d);
     const dim3 gl(d.N < LIST_GRID ? d.N : LIST_GRID);
+    if (d.ent_task) {   // the general entity list: boxes, meshes, frames in up to MWB_MAX_ENTS slots
+        if (mode == 1) render_kernel<RENDER_THREADS, 1, MWB_MAX_ENTS><<<gl, b, lds, s>>>(d);
+        else if (mode == 2) render_kernel<RENDER_THREADS, 2, MWB_MAX_ENTS><<<g, b, lds, s>>>(d);
+        else render_kernel<RENDER_THREADS, 0, MWB_MAX_ENTS><<<g, b, lds, s>>>(d);
+        return;
+    }
     if (d.poly) {   // YMaze: polygon rooms (one box)
         if (mode == 1) render_kernel<RENDER_THREADS, 1, 1, true><<<gl, b, lds, s>>>(d);
         else if (mode == 2) render_kernel<RENDER_THREADS, 2, 1, true><<<g, b, lds, s>>>(d);

@@ -159,7 +159,7 @@ def build_bvh(verts, leaf_size=4):
     def rec(idx):
         me = len(nodes)
         lo, hi = tlo[idx].min(axis=0) - pad, thi[idx].max(axis=0) + pad
-        nodes.append([lo, hi, -1, -1, 0])
+        nodes.append([lo, hi, -1, 0, 0])
         if len(idx) <= leaf_size:
             nodes[me][3], nodes[me][4] = len(order), len(idx)
             order.extend(int(i) for i in idx)

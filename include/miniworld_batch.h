@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MWB_ABI_VERSION 4
+#define MWB_ABI_VERSION 5
 
 enum { MWB_OK = 0, MWB_EINVAL = -1, MWB_EHIP = -2, MWB_ENOMEM = -3, MWB_ESTATE = -4 };
 
@@ -59,7 +59,44 @@ enum { MWB_TASK_HALLWAY = 0,   /* envs/hallway.py   task_args = {length}        
        /* envs/ymaze.py:8-103 (YMaze, YMazeLeft, YMazeRight): a corridor, a triangular hub and two arms rotated by -+120
         * degrees - rooms are convex polygons with 3 or 4 arbitrary edges (the polygon room table below); reward + done
         * near the box, info['goal_pos'] = box position; Discrete(3).  task_args = {goal given (0 = random arm), goal x, goal z} */
-       MWB_TASK_YMAZE = 9 };
+       MWB_TASK_YMAZE = 9,
+       /* ---- tasks with a general entity list: mesh entities (MeshEnt / Key / Ball, entity.py:100-146,410-434),
+        * image and text frames (entity.py:148-360), entities that leave the list or re-enter it at its end.  Meshes must be
+        * registered with mwb_set_mesh / mwb_set_mesh_dims before the first reset. */
+       /* envs/pickupobjs.py: num_objs objects (Ball 0.9, Box 0.9 or Key of a random colour each) in a size x size yard without
+        * ceiling; Discrete(5); picking an object up removes it (after the step's frame was rendered) for reward 1; done when
+        * all are gone.  task_args = {size, num_objs} */
+       MWB_TASK_PICKUPOBJS = 10,
+       /* envs/roomobjs.py: a box, a ball and a key of random colours, agent radius 1.5, no reward, no time limit
+        * (max_episode_steps = INT32_MAX); the base class' Discrete(8).  task_args = {size} */
+       MWB_TASK_ROOMOBJS = 11,
+       /* envs/collecthealth.py: 18 medkits; health -= 2 per step, a pickup respawns the kit at a random place (it moves to the
+        * END of the entity list) and restores health to 100; reward 2 per step alive, -100 and done at health <= 0;
+        * info['health'] is delivered in mwb_outputs.feature[0].  task_args = {size} */
+       MWB_TASK_COLLECTHEALTH = 12,
+       /* envs/threerooms.py: three rooms, two boxes, the Mila logo as an ImageFrame, a duckie, a key, a ball; no reward */
+       MWB_TASK_THREEROOMS = 13,
+       /* envs/sign.py: three rooms in a U, (blue, red, green) x (box, big key) at fixed places, a TextFrame naming a colour;
+        * Discrete(4) where action 3 moves back AND ends the episode; touching an object ends it with +1 (the named colour and the
+        * goal's shape) or -1.  task_args = {size, color_index, goal}; pass Sign's parameter table (forward_step 0.7, turn_step 45) */
+       MWB_TASK_SIGN = 14,
+       /* envs/sidewalk.py: a sidewalk beside a long street (no ceilings), a far building and five cones (static meshes), a red
+        * box; stepping into the street ends the episode with reward 0 */
+       MWB_TASK_SIDEWALK = 15,
+       /* envs/wallgap.py: two yards (no ceilings) joined by a gap in a wall, a red box, the far building */
+       MWB_TASK_WALLGAP = 16,
+       MWB_NUM_TASKS };
+
+/* entity kinds and mesh geometries of the general entity list */
+enum { MWB_ENT_BOX = 0, MWB_ENT_MESH = 1, MWB_ENT_IMAGE = 2, MWB_ENT_TEXT = 3 };
+enum { MWB_MESH_BALL = 0, MWB_MESH_KEY, MWB_MESH_MEDKIT, MWB_MESH_DUCKIE, MWB_MESH_BUILDING, MWB_MESH_CONE, MWB_NUM_MESHES };
+/* mwb_state.ent_meta word: kind | geometry << 4 | static << 8 | alive << 9 | radius is a float32 scalar << 10 | (colour index + 1) << 12 */
+#define MWB_META_KIND(m) ((m) & 15)
+#define MWB_META_GEOM(m) (((m) >> 4) & 15)
+#define MWB_META_STATIC(m) (((m) >> 8) & 1)
+#define MWB_META_ALIVE(m) (((m) >> 9) & 1)
+#define MWB_META_RADF32(m) (((m) >> 10) & 1)
+#define MWB_MAX_ENTS 20   /* entity slots besides the agent (CollectHealth: 18) */
 
 /* observation layouts */
 enum { MWB_LAYOUT_HWC = 0,  /* [N,H,W,3]  MiniWorldEnv.observation_space, miniworld.py:473-478 */
@@ -136,6 +173,15 @@ typedef struct mwb_state {
     double *goal_dist;      /* [count] simtorealpush.py:84 */
     uint32_t *rng_state;    /* [count][625] RandomState.get_state(): the 624 key words, then the position */
     int32_t *carrying;      /* [count] agent.carrying as an index into the boxes, or -1 (miniworld.py:682-702) */
+    /* general entity list (tasks >= MWB_TASK_PICKUPOBJS; B = mwb_num_boxes(h) slots = the episode's first list, agent excluded) */
+    int32_t *ent_meta;      /* [count][B] see MWB_META_*; read-only */
+    double *ent_radius;     /* [count][B] Entity.radius (a float32 value for meshes under NumPy >= 2); read-only */
+    double *ent_height;     /* [count][B] Entity.height; read-only */
+    double *ent_scale;      /* [count][B] MeshEnt.scale (0 for other kinds); read-only */
+    int32_t *ent_order;     /* [count][B + 1] self.entities now, as slots: -2 = the agent, -1 = past the end (entities removed) */
+    double *task_f;         /* [count] CollectHealth.health */
+    int32_t *task_i;        /* [count] PickupObjs.num_picked_up */
+    int32_t *text_tex;      /* [count][8] texture slot per character of the task's TextFrame (-1 = none / space); read-only */
 } mwb_state;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
@@ -153,8 +199,25 @@ int mwb_abi_version(void);
  * 6 brick_wall_1; the sim-to-real rinks also use 7-10 cardboard_1..4, 11-12 wood_1..2, 13 wood_planks_1,
  * 14 drywall_1, 15 stucco_1, 16 ceiling_tiles_1); the library builds the mip chain.  Every slot the task can
  * draw must be set before the first render. Synchronous. */
-#define MWB_NUM_TEXTURES 17
-int mwb_num_textures(mwb_handle *h);   /* how many leading slots the handle's task uses (7 or 17) */
+/* entity tasks: 17 asphalt_1, 18 slime_1, 19 cinder_blocks_1, 20 logo_mila_1, 21-24 the images of the textured meshes (medkit,
+ * duckie, building, cone), 25 + 9 c + v: variant v + 1 of chars/ch_0x<ord>_*.png for the c-th character of "BLUERDGN" (Sign) */
+#define MWB_NUM_TEXTURES 97
+#define MWB_TEX_MESH0 21
+#define MWB_TEX_CHAR0 25
+int mwb_num_textures(mwb_handle *h);   /* how many leading slots the handle's task uses (7, 17, 25 or 97) */
+/* replaces: ObjMesh.get / ObjMesh.__init__ (objmesh.py:16-216) for one mesh geometry, shared by all envs of the handle: the
+ * triangle soup as the reference hands it to OpenGL - verts / norms float32 [n_tris][3][3], texcs [n_tris][3][2], in draw order -
+ * its extents (ObjMesh.min_coords / max_coords), the texture slot of its image (-1 none) and a threaded bounding-volume
+ * hierarchy over the triangles for the render kernel: nodes float32 [n_nodes][8] = lo.xyz, skip (int bits) | hi.xyz,
+ * first | count << 24 (int bits) in depth-first order (an inner node's first child follows it; `skip` = next node when the box
+ * is missed or the leaf is done); perm int32 [n_tris] = triangle indices in leaf order.  Host pointers; synchronous.
+ * The vertex colour is the material's Kd, which the entity carries (ball_<c> / key_<c> share their geometry). */
+int mwb_set_mesh(mwb_handle *h, int geom, int n_tris, const float *verts, const float *norms, const float *texcs, int tex_slot,
+                 const float *min_coords, const float *max_coords, int n_nodes, const float *nodes, const int32_t *perm);
+/* replaces: MeshEnt.__init__'s arithmetic (entity.py:118-127) - `scale = height / sy`, `radius = sqrt(sx^2 + sz^2) * scale` -
+ * evaluated by the host with the reference's expressions, because their scalar type follows the installed NumPy (float32 under
+ * NumPy >= 2, where sums with Python floats are then float32 too): one call per (geometry, height) the task builds. */
+int mwb_set_mesh_dims(mwb_handle *h, int geom, double height, double scale, double radius, int is_float32);
 /* debugging aid (MWB_DEBUG bit 4 at mwb_create): start / end s_memrealtime ticks (100 MHz) of every workgroup of the
  * last bulk render launch, [2 * n] u64; returns n or a negative code */
 int mwb_debug_wg_times(mwb_handle *h, unsigned long long *out, int max_wgs);

@@ -97,6 +97,7 @@ def lib():
         L.mwo_set_box.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         L.mwo_set_box_y.argtypes = [vp, ctypes.c_int, ctypes.c_double]
         L.mwo_set_carrying.argtypes = [vp, ctypes.c_int]
+        L.mwo_render_step_frame.argtypes = [vp, ctypes.c_int]
         L.mwo_intersect_ent.argtypes = [vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         L.mwo_set_counters.argtypes = [vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int]
         L.mwo_get_geometry.argtypes = [vp] + [vp] * 13
@@ -346,7 +347,9 @@ class OracleEnv:
     def intersect_agent(self, x, z, radius=0.4):
         return self.L.mwo_intersect(self.h, 1, x, z, radius)
 
-    def render_obs(self, depth=False):
+    def render_obs(self, depth=False, step_frame=False):
+        """step_frame: the entities as the last step's own frame saw them (before PickupObjs removed / CollectHealth respawned one)"""
+        self.L.mwo_render_step_frame(self.h, int(bool(step_frame)))
         rgb = np.zeros((self.H, self.W, 3), np.uint8)
         dep = np.zeros((self.H, self.W), np.float32) if depth else None
         self.L.mwo_render(self.h, self.W, self.H, rgb.ctypes.data_as(ctypes.c_void_p),
