@@ -21,7 +21,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# name -> (env id, envs per GPU, depth, domain_rand, SURVEY.md 8(d) algorithmic bytes per env-step)
+# name -> (env id, envs per GPU, depth, domain_rand, SURVEY.md 8(d) algorithmic bytes per env-step[, actions drawn from range(n)])
 WORKLOADS = {
     "maze8192": ("MiniWorld-Maze-v0", 8192, False, False, 25600),             # north_star target / configs[4] per-GPU shape
     "oneroom4096": ("MiniWorld-OneRoom-v0", 4096, False, False, 14700),       # configs[1]
@@ -38,12 +38,19 @@ WORKLOADS = {
     "putnext8192": ("MiniWorld-PutNext-v0", 8192, False, False, 16000),
     # polygon rooms; 14 400 B obs + ~0.2 KB state + 6 rooms x 208 B + 288 B frame constants
     "ymaze8192": ("MiniWorld-YMaze-v0", 8192, False, False, 16200),
+    # SURVEY.md 8f.2 (round 3): mesh entities.  14 400 B obs + 2 864 B frame constants (20 entity slots x 34 words + 36) + entity
+    # state read / written (~0.1 KB per entity) + 96 B per room.  Actions over the task's whole action space, so that objects
+    # ARE picked up (PickupObjs: Discrete(5); CollectHealth: the base class' Discrete(8))
+    "pickupobjs8192": ("MiniWorld-PickupObjs-v0", 8192, False, False, 17900, 5),
+    "collecthealth8192": ("MiniWorld-CollectHealth-v0", 8192, False, False, 19200, 8),
+    "sidewalk8192": ("MiniWorld-Sidewalk-v0", 8192, False, True, 18300, 3),
 }
 ORACLE_TASK = {"MiniWorld-Maze-v0": ("Maze", None), "MiniWorld-OneRoom-v0": ("OneRoom", None),
                "MiniWorld-FourRooms-v0": ("FourRooms", None), "MiniWorld-Hallway-v0": ("Hallway", None),
                "MiniWorld-TMazeTwoBoxDynamicFeatures100K-v0": ("TMazeTwoBox", [1, 0, 0, 100000]),
                "MiniWorld-SimToRealPush-v0": ("SimToRealPush", None), "MiniWorld-PutNext-v0": ("PutNext", None),
-               "MiniWorld-YMaze-v0": ("YMaze", [0, 0, 0, 0])}
+               "MiniWorld-YMaze-v0": ("YMaze", [0, 0, 0, 0]), "MiniWorld-PickupObjs-v0": ("PickupObjs", [12, 5, 0, 0]),
+               "MiniWorld-CollectHealth-v0": ("CollectHealth", [16, 0, 0, 0]), "MiniWorld-Sidewalk-v0": ("Sidewalk", None)}
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ACTION_SEED = 12345
 
@@ -59,14 +66,14 @@ def splitmix64(x):
     return x ^ lsr(x, 31)
 
 
-def make_actions(steps, first_env, n_envs, device):
-    """[steps, n_envs] int32 actions in {0,1,2}: counter-based in (step, global env index)."""
+def make_actions(steps, first_env, n_envs, device, n_actions=3):
+    """[steps, n_envs] int32 actions in range(n_actions) (default {0,1,2}): counter-based in (step, global env index)."""
     import torch
     t = torch.arange(steps, dtype=torch.int64, device=device)[:, None]
     e = torch.arange(first_env, first_env + n_envs, dtype=torch.int64, device=device)[None, :]
     inner = splitmix64(t * 0x100000001B3 + e)
     v = splitmix64(inner ^ ACTION_SEED)
-    return (((v >> 33) & ((1 << 31) - 1)) % 3).to(torch.int32).contiguous()
+    return (((v >> 33) & ((1 << 31) - 1)) % n_actions).to(torch.int32).contiguous()
 
 
 def host_cores(cap=64):
@@ -91,7 +98,7 @@ def host_cores(cap=64):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(env_id, depth, dr, budget_s=10.0):
+def cpu_baseline(env_id, depth, dr, budget_s=10.0, n_actions=3):
     """Oracle (CPU restatement, scalar C) timed on this host on a bounded sample of the same workload:
     one env per thread on every host core (the reference's own parallelism is one process per env,
     vec_env/subproc_vec_env.py:36-56), plus the single-thread rate."""
@@ -109,9 +116,9 @@ def cpu_baseline(env_id, depth, dr, budget_s=10.0):
         e.reset(render=False)
         return e
     env0 = make(0)
-    dt = env0.bench_loop(200, ACTION_SEED, 0, want_depth=depth)   # calibrate
+    dt = env0.bench_loop(200, ACTION_SEED, 0, want_depth=depth, n_actions=n_actions)   # calibrate
     n1 = max(200, min(6000, int(200 * 4.0 / max(dt, 1e-6))))
-    dt1 = env0.bench_loop(n1, ACTION_SEED, 0, want_depth=depth)
+    dt1 = env0.bench_loop(n1, ACTION_SEED, 0, want_depth=depth, n_actions=n_actions)
     single = n1 / dt1
     cores = host_cores()
     envs = [make(i) for i in range(cores)]
@@ -119,7 +126,7 @@ def cpu_baseline(env_id, depth, dr, budget_s=10.0):
     times = [0.0] * cores
 
     def run(i):   # ctypes releases the GIL inside the C loop
-        times[i] = envs[i].bench_loop(n, ACTION_SEED, i, want_depth=depth)
+        times[i] = envs[i].bench_loop(n, ACTION_SEED, i, want_depth=depth, n_actions=n_actions)
     th = [threading.Thread(target=run, args=(i,)) for i in range(cores)]
     t0 = time.perf_counter()
     for t in th:
@@ -133,7 +140,7 @@ def cpu_baseline(env_id, depth, dr, budget_s=10.0):
                       "step+auto-reset+render, one env per thread on %d host cores" % (cores, n, env_id, cores)}
 
 
-def vecenv_rates(env_id, per_gpu, dr, device, K, Wm):
+def vecenv_rates(env_id, per_gpu, dr, device, K, Wm, n_actions=3):
     """The same workload through the boundary the reference's trainer calls (pytorch-a2c-ppo-acktr/main.py:610:
     `obs, reward, done, infos = envs.step(action, env_mask)`): actions as LongTensor [N,1] on the device, numpy dones,
     CPU float rewards, info dicts.  Two views: the bare VecEnv (uint8 [N,3,80,60] observations: what the Python layer
@@ -147,7 +154,7 @@ def vecenv_rates(env_id, per_gpu, dr, device, K, Wm):
             v = MiniWorldVecEnv(env_id, per_gpu, seed=1, device=device.index, domain_rand=dr, to_float=False, feature_info=True)
         else:
             v = make_vec_envs(env_id, 1, per_gpu, device=str(device), domain_rand=dr)
-        acts = make_actions(K + Wm, 0, per_gpu, device).to(torch.int64).unsqueeze(2)   # [T, N, 1] LongTensor
+        acts = make_actions(K + Wm, 0, per_gpu, device, n_actions).to(torch.int64).unsqueeze(2)   # [T, N, 1] LongTensor
         v.reset()
         n_done = 0
         for t in range(Wm):
@@ -207,7 +214,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
-    env_id, per_gpu, depth, dr, alg_bytes = WORKLOADS[args.workload]
+    env_id, per_gpu, depth, dr, alg_bytes = WORKLOADS[args.workload][:5]
+    n_actions = WORKLOADS[args.workload][5] if len(WORKLOADS[args.workload]) > 5 else 3
     if args.envs_per_gpu:
         per_gpu = args.envs_per_gpu
     total = per_gpu * world
@@ -226,13 +234,13 @@ def main():
     env = BatchedMiniWorld(env_id, num_envs=count, seed=1, domain_rand=dr, want_depth=depth, device=dev_index,
                            first_env_index=first)
     K, Wm = args.steps, args.warmup
-    actions = make_actions(K + Wm, first, count, device)
+    actions = make_actions(K + Wm, first, count, device, n_actions)
     gather = None
     actions_all = None
     if (world > 1 and not args.no_gather) or args.force_gather:
         gather = ShardExchange(tuple(env.obs.shape), env.obs.dtype, device, world, rank=rank, method=args.gather)
         if rank == 0:   # the learner's action table for ALL envs (identical values to every rank's own `actions`)
-            actions_all = make_actions(K + Wm, 0, total, device)
+            actions_all = make_actions(K + Wm, 0, total, device, n_actions)
     env.reset()
     consumed = torch.zeros((), dtype=torch.float64, device=device)
 
@@ -284,7 +292,7 @@ def main():
             "vs_baseline": None, "dtype": "f64 sim / f32 render / u8 obs", "data": "synthetic",
             "config": {"workload": args.workload, "env_id": env_id, "envs_per_gpu": per_gpu, "global_envs": total,
                        "obs": "80x60 RGB" + (" + f32 depth" if depth else ""), "domain_rand": bool(dr),
-                       "actions": "uniform random over {turn_left, turn_right, move_forward}, counter-based",
+                       "actions": "uniform random over %s, counter-based" % ("{turn_left, turn_right, move_forward}" if n_actions == 3 else "the %d actions of the task" % n_actions),
                        "auto_reset": True, "parallelism": "env-sharded x%d%s" % (world, "" if gather is None else " + per-step exchange(obs u8 + aux f64[8], %s) + action scatter" % gather.method),
                        "gather_tuning_s": None if gather is None else gather.tuned},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -298,13 +306,13 @@ def main():
         if world == 1 and not args.no_vecenv:
             env.close()
             try:
-                out["vecenv"] = vecenv_rates(env_id, per_gpu, dr, device, K, Wm)
+                out["vecenv"] = vecenv_rates(env_id, per_gpu, dr, device, K, Wm, n_actions)
                 out["vecenv"]["vs_c_abi"] = out["vecenv"]["vecenv_u8"]["value"] / value
             except Exception as ex:
                 out["vecenv"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(env_id, depth, dr)
+                out["cpu_baseline"] = cpu_baseline(env_id, depth, dr, n_actions=n_actions)
             except Exception as ex:   # the oracle is only a reported baseline; never fail the GPU number on it
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
         print(json.dumps(out))

@@ -120,6 +120,7 @@ class BatchedMiniWorld:
             if spec_dr is not None:
                 domain_rand = spec_dr
         self.env_id, self.task = env_id, task
+        self.task_args = list(task_args or []) + [0, 0, 0, 0]
         self.num_envs = int(num_envs)
         self.W, self.H = int(obs_width), int(obs_height)
         self.want_depth = bool(want_depth)

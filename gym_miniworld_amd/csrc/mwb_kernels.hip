@@ -964,6 +964,9 @@ __device__ __forceinline__ void sample_param(MtWave &g, const MwbParam &p, int n
     for (int k = 0; k < n; k++) out[k] = use_rng ? g.uniform(p.lo[k], p.hi[k]) : p.def[k];   // params.py:81-99
 }
 
+// One instantiation per task: the task is a compile-time constant, so every other task's world generation - and the registers /
+// scratch its locals would claim - is gone from the kernel (one kernel with every branch: 256 VGPRs + 256 AGPRs + 2.3 KB/lane of scratch).
+template <int TASK_>
 __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     // The regenerated envs' chain (this kernel, then their render) runs beside the bulk render, whose five waves per SIMD
     // would otherwise leave a lone latency-bound wave one issue slot in six: raise the wave's priority at the arbiter
@@ -1006,10 +1009,10 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     // reset() overrides of the T-maze family run before MiniWorldEnv.reset (every lane computes the same)
     int goal_idx = d.goal_idx[e];
     long long episode_count = d.episode_count[e];
-    if (d.task == MWB_TASK_TMAZE && d.task_args[3] > 0) {   // TMazeDynamic.reset, tmaze.py:98-105
+    if (TASK_ == MWB_TASK_TMAZE && d.task_args[3] > 0) {   // TMazeDynamic.reset, tmaze.py:98-105
         episode_count += 1;
         if (episode_count % (long long)d.task_args[3] == 0) goal_idx = (goal_idx + 1) % 2;
-    } else if (d.task == MWB_TASK_TMAZE_TWOBOX) {
+    } else if (TASK_ == MWB_TASK_TMAZE_TWOBOX) {
         if (d.task_args[0] == 0) {   // TMazeTwoBoxDynamic.reset, tmaze.py:210-217
             episode_count += 1;
             if (episode_count % (long long)d.task_args[3] == 0) goal_idx = (goal_idx + 1) % 2;
@@ -1017,8 +1020,8 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             goal_idx = (goal_idx + 1) % 2;                               // never cleared (the reference assigns a misspelt name)
         }
     }
-    if (d.task == MWB_TASK_SIM2REAL_GOTO || d.task == MWB_TASK_SIM2REAL_PUSH) {   // envs/simtorealgoto.py:40-82, simtorealpush.py:39-107
-        const bool push = d.task == MWB_TASK_SIM2REAL_PUSH;
+    if (TASK_ == MWB_TASK_SIM2REAL_GOTO || TASK_ == MWB_TASK_SIM2REAL_PUSH) {   // envs/simtorealgoto.py:40-82, simtorealpush.py:39-107
+        const bool push = TASK_ == MWB_TASK_SIM2REAL_PUSH;
         const double size = push ? w.rng.uniform(1.6, 1.7) : w.rng.uniform(1, 2);
         const double wall_height = push ? w.rng.uniform(0.42, 0.50) : w.rng.uniform(0.20, 0.50);
         box_s = push ? w.rng.uniform(0.075, 0.090) : w.rng.uniform(0.07, 0.12);
@@ -1060,18 +1063,18 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         a.n_others = d.n_boxes; a.other_radius = brad; a.other_radius2 = brad2;
         a.other_x[0] = box_x; a.other_z[0] = box_z; a.other_x[1] = box2_x; a.other_z[1] = box2_z;
         w.place_entity_ex(arad, a, ag_x, ag_z, ag_dir);
-    } else if (d.task == MWB_TASK_TMAZE || d.task == MWB_TASK_TMAZE_TWOBOX) {   // envs/tmaze.py:27-61, 151-194
+    } else if (TASK_ == MWB_TASK_TMAZE || TASK_ == MWB_TASK_TMAZE_TWOBOX) {   // envs/tmaze.py:27-61, 151-194
         w.add_rect_room(-1, 8, -2, 2, TEXF_CONCRETE);
         int r2 = w.add_rect_room(8, 12, -8, 8, TEXF_CONCRETE);
         const double r2min = rooms[r2].min_z, r2max = rooms[r2].max_z;
         w.connect_rooms(0, 1, 2, -2, 2, false, 0);
         // `if self.rand.bool():` (tmaze.py:53) is evaluated before the first place_entity, i.e. before the
         // texture draws of _gen_static_data (miniworld.py:865-866)
-        const bool random_arm = d.task == MWB_TASK_TMAZE && d.task_args[0] == 0;
+        const bool random_arm = TASK_ == MWB_TASK_TMAZE && d.task_args[0] == 0;
         const bool left_arm = random_arm && w.rng.randint(0, 2) == 0;   // RandGen.bool, random.py:26-31
         w.gen_static_data(dr, d.S_max);
         WorldGen::PlaceOpt o;
-        if (d.task == MWB_TASK_TMAZE_TWOBOX) {   // red box at (10, -6), blue box at (10, 6): min == max
+        if (TASK_ == MWB_TASK_TMAZE_TWOBOX) {   // red box at (10, -6), blue box at (10, 6): min == max
             o.has_min_x = o.has_max_x = o.has_min_z = o.has_max_z = true;
             o.min_x = o.max_x = 10; o.min_z = o.max_z = -6;
             w.place_entity_ex(brad, o, box_x, box_z, box_dir);
@@ -1096,7 +1099,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         a.n_others = d.n_boxes; a.other_radius = brad;
         a.other_x[0] = box_x; a.other_z[0] = box_z; a.other_x[1] = box2_x; a.other_z[1] = box2_z;
         w.place_entity_ex(arad, a, ag_x, ag_z, ag_dir);
-    } else if (d.task == MWB_TASK_PUTNEXT) {   // envs/putnext.py:22-43
+    } else if (TASK_ == MWB_TASK_PUTNEXT) {   // envs/putnext.py:22-43
         const double size = d.task_args[0];
         w.add_rect_room(0, size, 0, size, TEXF_CONCRETE);
         WorldGen::PlaceOpt o;
@@ -1110,7 +1113,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         }
         o.n_others = 6;
         w.place_entity_ex(arad, o, ag_x, ag_z, ag_dir);
-    } else if (d.task == MWB_TASK_YMAZE) {   // envs/ymaze.py:28-83
+    } else if (TASK_ == MWB_TASK_YMAZE) {   // envs/ymaze.py:28-83
         const double mox[4] = {-9.15, -9.15, -1.15, -1.15}, moz[4] = {-2, 2, 2, -2};
         w.add_room(mox, moz, 2.74, TEXF_CONCRETE, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES);
         const double hox[4] = {-1.15, -1.15, 2.31, 0}, hoz[4] = {-2, 2, 0, 0};   // the hub: a triangle
@@ -1146,7 +1149,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         a.dir = w.rng.uniform(-3.141592653589793 / 4, 3.141592653589793 / 4);
         a.n_others = 1; a.other_radius = brad; a.other_x[0] = box_x; a.other_z[0] = box_z;
         w.place_entity_ex(arad, a, ag_x, ag_z, ag_dir);
-    } else if (d.ent_task) {
+    } else if ((TASK_ >= MWB_TASK_PICKUPOBJS)) {
         // ---- tasks with a general entity list.  Every lane runs the same serial logic; lane 0 records the entities in LDS.
         auto put = [&](int b, int kind, int geom, bool is_static, int color, double size, double radius, bool f32, double height, double scale) {
             __syncthreads();
@@ -1185,7 +1188,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             w.place_entity_ex(radius, o, ag_x, ag_z, ag_dir);
         };
         const int E = d.n_boxes;
-        if (d.task == MWB_TASK_PICKUPOBJS) {   // envs/pickupobjs.py:28-54
+        if (TASK_ == MWB_TASK_PICKUPOBJS) {   // envs/pickupobjs.py:28-54
             const double size = d.task_args[0];
             w.add_rect_room_ex(0, size, 0, size, TEXF_BRICK_WALL, TEXF_ASPHALT, TEXF_CONCRETE_TILES);
             for (int b = 0; b < E; b++) {
@@ -1200,7 +1203,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             }
             WorldGen::PlaceOpt a;
             place_agent(a, arad);
-        } else if (d.task == MWB_TASK_ROOMOBJS) {   // envs/roomobjs.py:24-47 (agent.radius = 1.5: d.agent_radius)
+        } else if (TASK_ == MWB_TASK_ROOMOBJS) {   // envs/roomobjs.py:24-47 (agent.radius = 1.5: d.agent_radius)
             const double size = d.task_args[0];
             w.add_rect_room_ex(0, size, 0, size, TEXF_BRICK_WALL, TEXF_ASPHALT, TEXF_CONCRETE_TILES);
             for (int b = 0; b < 3; b++) {
@@ -1214,7 +1217,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             }
             WorldGen::PlaceOpt a;
             place_agent(a, arad);
-        } else if (d.task == MWB_TASK_COLLECTHEALTH) {   // envs/collecthealth.py:28-49
+        } else if (TASK_ == MWB_TASK_COLLECTHEALTH) {   // envs/collecthealth.py:28-49
             const double size = d.task_args[0];
             w.add_rect_room_ex(0, size, 0, size, TEXF_CINDER_BLOCKS, TEXF_SLIME, TEXF_CONCRETE_TILES);
             w.gen_static_data(dr, d.S_max);
@@ -1226,7 +1229,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             WorldGen::PlaceOpt a;
             place_agent(a, arad);
             task_f0 = 100.0;
-        } else if (d.task == MWB_TASK_THREEROOMS) {   // envs/threerooms.py:22-69
+        } else if (TASK_ == MWB_TASK_THREEROOMS) {   // envs/threerooms.py:22-69
             w.add_rect_room(-7, 7, 0.5, 7, TEXF_CONCRETE);
             w.add_rect_room(-7, -1, -7, -0.5, TEXF_CONCRETE);
             w.add_rect_room(1, 7, -7, -0.5, TEXF_CONCRETE);
@@ -1247,7 +1250,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             put_mesh(5, MWB_MESH_BALL, 0.6, false, 1); place(5, o);
             WorldGen::PlaceOpt a;
             place_agent(a, arad);
-        } else if (d.task == MWB_TASK_SIGN) {   // envs/sign.py:75-113
+        } else if (TASK_ == MWB_TASK_SIGN) {   // envs/sign.py:75-113
             const double size = d.task_args[0], gap = 0.25;
             w.add_rect_room(0, size, 0, size * 0.65, TEXF_CONCRETE);
             w.add_rect_room(0, size * 3 / 5, size * 0.65 + gap, size * 1.3, TEXF_CONCRETE);
@@ -1269,7 +1272,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             a.has_min_x = a.has_max_x = a.has_min_z = a.has_max_z = true;
             a.min_x = 4; a.max_x = 5; a.min_z = 4; a.max_z = 6;
             place_agent(a, arad);
-        } else if (d.task == MWB_TASK_SIDEWALK) {   // envs/sidewalk.py:22-72
+        } else if (TASK_ == MWB_TASK_SIDEWALK) {   // envs/sidewalk.py:22-72
             w.add_rect_room_ex(-3, 0, 0, 12, TEXF_BRICK_WALL, TEXF_CONCRETE_TILES, TEXF_CONCRETE_TILES);
             w.add_rect_room_ex(0, 6, -80, 80, TEXF_CONCRETE, TEXF_ASPHALT, TEXF_CONCRETE_TILES);
             w.connect_rooms(0, 1, 2, 0, 12, false, 0);
@@ -1297,7 +1300,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             a.room = 0;
             place_agent(a, arad);
         }
-    } else if (d.task == MWB_TASK_HALLWAY) {   // envs/hallway.py:25-42
+    } else if (TASK_ == MWB_TASK_HALLWAY) {   // envs/hallway.py:25-42
         double length = d.task_args[0];
         int r = w.add_rect_room(-1, -1 + length, -2, 2, TEXF_CONCRETE);
         double rmax = rooms[r].max_x;
@@ -1305,13 +1308,13 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         w.place_entity(brad, false, 0, 0, 0, false, 0, true, rmax - 2, false, 0, box_x, box_z, box_dir);
         double adir = w.rng.uniform(-3.141592653589793 / 4, 3.141592653589793 / 4);
         w.place_entity(arad, true, box_x, box_z, brad, true, adir, false, 0, true, rmax - 2, ag_x, ag_z, ag_dir);
-    } else if (d.task == MWB_TASK_ONEROOM) {   // envs/oneroom.py:26-35
+    } else if (TASK_ == MWB_TASK_ONEROOM) {   // envs/oneroom.py:26-35
         double size = d.task_args[0];
         w.add_rect_room(0, size, 0, size, TEXF_CONCRETE);
         w.gen_static_data(dr, d.S_max);
         w.place_entity(brad, false, 0, 0, 0, false, 0, false, 0, false, 0, box_x, box_z, box_dir);
         w.place_entity(arad, true, box_x, box_z, brad, false, 0, false, 0, false, 0, ag_x, ag_z, ag_dir);
-    } else if (d.task == MWB_TASK_FOURROOMS) {   // envs/fourrooms.py:22-52
+    } else if (TASK_ == MWB_TASK_FOURROOMS) {   // envs/fourrooms.py:22-52
         w.add_rect_room(-7, -1, 1, 7, TEXF_CONCRETE);
         w.add_rect_room(1, 7, 1, 7, TEXF_CONCRETE);
         w.add_rect_room(1, 7, -7, -1, TEXF_CONCRETE);
@@ -1383,7 +1386,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     sample_param(w.rng, d.params[MWB_P_LIGHT_POS], 3, dr, lpos);
     sample_param(w.rng, d.params[MWB_P_LIGHT_COLOR], 3, dr, lcol);
     sample_param(w.rng, d.params[MWB_P_LIGHT_AMBIENT], 3, dr, lamb);
-    if (!d.ent_task) {
+    if (!(TASK_ >= MWB_TASK_PICKUPOBJS)) {
         for (int b = 0; b < d.n_boxes; b++) sample_param(w.rng, d.params[MWB_P_OBJ_COLOR_BIAS], 3, dr, biases[b]);   // entities randomize in list order
     } else {
         for (int b = 0; b < d.n_boxes; b++) {   // Box.randomize draws its colour bias, MeshEnt / ImageFrame draw nothing, TextFrame a texture per character
@@ -1423,7 +1426,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         // COLORS in COLOR_NAMES order (entity.py:8-18): blue green grey purple red yellow; Box.randomize adds the bias and clips
         const double COLORS[6][3] = {{0.0, 0.0, 1.0}, {0.0, 1.0, 0.0}, {0.39, 0.39, 0.39}, {0.44, 0.15, 0.76}, {1.0, 0.0, 0.0}, {1.00, 1.00, 0.00}};
         const size_t N = (size_t)d.N;
-        for (int b = 0; b < d.n_boxes && d.ent_task; b++) {   // entity tasks: the slots as recorded in LDS
+        for (int b = 0; b < d.n_boxes && (TASK_ >= MWB_TASK_PICKUPOBJS); b++) {   // entity tasks: the slots as recorded in LDS
             const size_t be = (size_t)b * N + e;
             const int kind = E_meta[b] & 15, ci = E_col[b];
             d.box_x[be] = E_x[b]; d.box_y[be] = E_y[b]; d.box_z[be] = E_z[b]; d.box_dir[be] = E_dir[b]; d.box_size[be] = E_size[b];
@@ -1434,18 +1437,18 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
                 d.box_color[be * 3 + k] = v;
             }
         }
-        if (d.ent_task) {
+        if ((TASK_ >= MWB_TASK_PICKUPOBJS)) {
             uint8_t *ord = d.ent_order + (size_t)e * MWB_ORDER_STRIDE;
             for (int k = 0; k < MWB_ORDER_STRIDE; k++) ord[k] = k < d.n_boxes ? (uint8_t)k : (uint8_t)MWB_ENT_AGENT;   // [0 .. E-1, agent]
             d.n_order[e] = d.n_boxes + 1;
             d.task_f[e] = task_f0; d.task_i[e] = 0; d.ovr_slot[e] = -1;
-            for (int c = 0; c < 8; c++) d.text_tex[e * 8 + c] = d.task == MWB_TASK_SIGN ? E_text[c] : -1;
+            for (int c = 0; c < 8; c++) d.text_tex[e * 8 + c] = TASK_ == MWB_TASK_SIGN ? E_text[c] : -1;
         }
-        for (int b = 0; b < d.n_boxes && !d.ent_task; b++) {
+        for (int b = 0; b < d.n_boxes && !(TASK_ >= MWB_TASK_PICKUPOBJS); b++) {
             int base = 4;   // red
             double x = box_x, z = box_z, dir = box_dir, sz = box_s;
-            if (d.task == MWB_TASK_PUTNEXT) { base = b; x = pn_x[b]; z = pn_z[b]; dir = pn_dir[b]; sz = pn_s[b]; }
-            else if (b == 1) { base = d.task == MWB_TASK_SIM2REAL_PUSH ? 5 : 0; x = box2_x; z = box2_z; dir = box2_dir; sz = box2_s; }   // yellow / blue
+            if (TASK_ == MWB_TASK_PUTNEXT) { base = b; x = pn_x[b]; z = pn_z[b]; dir = pn_dir[b]; sz = pn_s[b]; }
+            else if (b == 1) { base = TASK_ == MWB_TASK_SIM2REAL_PUSH ? 5 : 0; x = box2_x; z = box2_z; dir = box2_dir; sz = box2_s; }   // yellow / blue
             const size_t be = (size_t)b * N + e;
             d.box_x[be] = x; d.box_z[be] = z; d.box_y[be] = 0.0; d.box_dir[be] = dir; d.box_size[be] = sz;
             for (int k = 0; k < 3; k++) {
@@ -2026,7 +2029,7 @@ __device__ __forceinline__ int trace_box(const float *fc, const float *dv, float
     return face;
 }
 
-// ---- mesh entities and frames (entity tasks; oracle/mw_oracle.c trace_mesh / trace_frame state the same arithmetic) ---------------
+// ---- mesh entities and frames (entity tasks; DESIGN.md 5, "meshes" / "frames": the written arithmetic) -------------------------
 #define KIND_MESH 5u
 #define KIND_FRAME 6u
 __device__ __forceinline__ float dot3f(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
@@ -3265,6 +3268,8 @@ void mwb_launch_clear_list(const MwbDev &d, hipStream_t s) { hipLaunchKernelGGL(
 void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s) {
     hipLaunchKernelGGL(mark_reset_kernel, dim3((d.N + 255) / 256), dim3(256), 0, s, d, mask);
 }
+typedef void (*reset_fn_t)(MwbDev);
+static reset_fn_t reset_fn(int task);
 int mwb_prepare_kernels(const MwbDev &d) {
     // opt in to more than the default 64 KB of dynamic LDS where a large world needs it (160 KB per CU)
     size_t r = mwb_reset_lds_bytes(d), q = mwb_render_lds_bytes(d);
@@ -3274,7 +3279,7 @@ int mwb_prepare_kernels(const MwbDev &d) {
         while ((1 << wshift) < d.W) wshift++;
         if (((size_t)d.H << wshift) > 65536) return -3;
     }
-    if (r > 64 * 1024 && hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r) != hipSuccess) return -2;
+    if (r > 64 * 1024 && hipFuncSetAttribute((const void *)reset_fn(d.task), hipFuncAttributeMaxDynamicSharedMemorySize, (int)r) != hipSuccess) return -2;
     if (q > 64 * 1024) {   // large mazes, or any task at a large observation size (the W*H*3 frame is in LDS too)
         const void *fns[3][3] = {{(const void *)render_kernel<RENDER_THREADS, 0, 1>, (const void *)render_kernel<RENDER_THREADS, 1, 1>, (const void *)render_kernel<RENDER_THREADS, 2, 1>},
                                  {(const void *)render_kernel<RENDER_THREADS, 0, 2>, (const void *)render_kernel<RENDER_THREADS, 1, 2>, (const void *)render_kernel<RENDER_THREADS, 2, 2>},
@@ -3289,8 +3294,18 @@ int mwb_prepare_kernels(const MwbDev &d) {
 
 #define LIST_GRID 1280   // blocks that walk the compact list of regenerated envs: a handful per step - but ALL of them in the step at
                         // which a whole batch hits the episode limit together (a block with nothing to do exits at once)
+static reset_fn_t reset_fn(int task) {
+    switch (task) {
+#define RK(t) case t: return reset_kernel<t>;
+    RK(MWB_TASK_HALLWAY) RK(MWB_TASK_ONEROOM) RK(MWB_TASK_FOURROOMS) RK(MWB_TASK_MAZE) RK(MWB_TASK_TMAZE) RK(MWB_TASK_TMAZE_TWOBOX)
+    RK(MWB_TASK_SIM2REAL_GOTO) RK(MWB_TASK_SIM2REAL_PUSH) RK(MWB_TASK_PUTNEXT) RK(MWB_TASK_YMAZE) RK(MWB_TASK_PICKUPOBJS)
+    RK(MWB_TASK_ROOMOBJS) RK(MWB_TASK_COLLECTHEALTH) RK(MWB_TASK_THREEROOMS) RK(MWB_TASK_SIGN) RK(MWB_TASK_SIDEWALK) RK(MWB_TASK_WALLGAP)
+#undef RK
+    }
+    return reset_kernel<MWB_TASK_MAZE>;
+}
 void mwb_launch_reset(const MwbDev &d, int max_blocks, hipStream_t s) {
-    hipLaunchKernelGGL(reset_kernel, dim3(d.N < max_blocks ? d.N : max_blocks), dim3(WAVE), mwb_reset_lds_bytes(d), s, d);
+    hipLaunchKernelGGL(reset_fn(d.task), dim3(d.N < max_blocks ? d.N : max_blocks), dim3(WAVE), mwb_reset_lds_bytes(d), s, d);
 }
 void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s) {
     const int blocks = mode == 1 ? 8 : (d.N + 255) / 256;

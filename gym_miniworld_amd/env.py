@@ -24,6 +24,10 @@ class _Ent:
         return np.array([np.sin(self.dir), 0, np.cos(self.dir)])
 
 
+COLOR_NAMES = ("blue", "green", "grey", "purple", "red", "yellow")   # sorted(COLORS), entity.py:18
+_KIND_NAMES = ("Box", "MeshEnt", "ImageFrame", "TextFrame")
+
+
 class _Room:
     def __init__(self, words):
         if len(words) == 24:
@@ -76,6 +80,9 @@ class MiniWorldEnv:
                 b.color = name
             self.red_box, self.yellow_box = self.boxes[4], self.boxes[5]
             self.entities = self.boxes + [self.agent]
+        if self._b.ent_task:   # a general entity list: rebuilt from the device state after every reset / step
+            self.entities, self._slots = [self.agent], []
+            del self.box
         self.rooms, self.step_count = [], 0
         self._seeded = False
         if seed is not None:
@@ -96,9 +103,56 @@ class MiniWorldEnv:
         self._seeded = True
         return [seed]
 
-    def _sync(self):
+    def _sync_entities(self, st, rebuild):
+        """the tasks with mesh entities / frames: one object per slot (kind, mesh_name, color, size ..., entity.py), self.entities in
+        the reference's current LIST order (PickupObjs removes entries, CollectHealth moves a respawned kit to the end)"""
+        from . import _lib
+        B = self._b.n_boxes
+        if rebuild or len(self._slots) != B:
+            self._slots = []
+            for k in range(B):
+                ent = _Ent(float(st["ent_radius"][0, k]), float(st["ent_height"][0, k]))
+                kind = int(st["ent_kind"][0, k])
+                ent.kind = _KIND_NAMES[kind]
+                ent.is_static = bool(st["ent_static"][0, k])
+                ci = int(st["ent_color"][0, k])
+                if kind == 0:
+                    s0 = float(st["boxes_size"][0, k])
+                    ent.color, ent.size = COLOR_NAMES[ci], np.array([s0, s0, s0])
+                elif kind == 1:
+                    geom = _lib.MESH_GEOMS[int(st["ent_geom"][0, k])]
+                    ent.mesh_name = geom + "_" + COLOR_NAMES[ci] if ci >= 0 else geom
+                    ent.scale = float(st["ent_scale"][0, k])
+                else:
+                    ent.width, ent.depth = float(st["boxes_size"][0, k]), 0.05
+                self._slots.append(ent)
+        for k, ent in enumerate(self._slots):
+            ent.pos, ent.dir = st["boxes_pos"][0, k].copy(), float(st["boxes_dir"][0, k])
+            if ent.kind == "Box":
+                ent.color_vec = st["boxes_color"][0, k].copy()
+        self.entities = [self.agent if v == -2 else self._slots[v] for v in st["ent_order"][0] if v != -1]
+        c = int(st["carrying"][0])
+        self.agent.carrying = None if c < 0 else self._slots[c]
+        task = self._b.task
+        if task in ("Sidewalk", "WallGap"):
+            self.box = self._slots[6 if task == "Sidewalk" else 0]
+        if task == "CollectHealth":
+            self.health = float(st["task_f"][0])
+        if task == "PickupObjs":
+            self.num_picked_up = int(st["task_i"][0])
+        if task == "Sign":   # sign.py:91-102: (boxes, keys) x (blue, red, green)
+            self._objects = [tuple(self._slots[0:3]), tuple(self._slots[3:6])]
+
+    def _sync(self, rebuild=False):
         st = self._b.get_state()
         self.agent.pos, self.agent.dir = st["agent_pos"][0].copy(), float(st["agent_dir"][0])
+        if self._b.ent_task:
+            self._sync_entities(st, rebuild)
+            (self.agent.cam_height, self.agent.cam_fwd_disp, self.agent.cam_pitch, self.agent.cam_fov_y) = st["cam"][0]
+            self.sky_color, self.light_pos = st["sky_color"][0], st["light_pos"][0]
+            self.light_color, self.light_ambient = st["light_color"][0], st["light_ambient"][0]
+            self.step_count = int(st["step_count"][0])
+            return
         self.box.pos, self.box.dir = st["box_pos"][0].copy(), float(st["box_dir"][0])
         self.box.color_vec = st["box_color"][0].copy()
         s0 = float(st["box_size"][0])
@@ -130,7 +184,9 @@ class MiniWorldEnv:
         obs = self._b.reset().cpu().numpy()[0]
         rooms, _ = self._b.get_geometry(0)
         self.rooms = [_Room(w) for w in rooms]
-        self._sync()
+        self._sync(rebuild=True)
+        if self._b.task == "Sign":   # sign.py:130-133: the observation is a dict
+            return {"obs": obs, "goal": int(self._b.task_args[2])}
         return obs
 
     def step(self, action):
@@ -144,6 +200,10 @@ class MiniWorldEnv:
             info["goal_pos"] = self._b.goal_pos.cpu().numpy()[0].copy()
         if self._b.has_features:   # tmaze.py:311-318
             info["feature"] = self._b.feature.cpu().numpy()[0].astype(np.float64)
+        if self._b.has_health:   # collecthealth.py:75
+            info["health"] = float(self._b.feature.cpu().numpy()[0, 0])
+        if self._b.task == "Sign":
+            obs = {"obs": obs, "goal": int(self._b.task_args[2])}
         return obs, reward, done, info
 
     def render_obs(self):
@@ -173,6 +233,10 @@ class MiniWorldEnv:
 
     def intersect(self, ent, pos, radius):
         """miniworld.py:933-959: True for a wall, the other entity for an entity hit, else None."""
+        if self._b.ent_task:   # results name slots (2 + slot; 2 + n_slots = the agent)
+            idx = self._b.n_boxes if ent is self.agent else next((i for i, e2 in enumerate(self._slots) if e2 is ent), -1)
+            r = self._b.intersect(0, pos[0], pos[2], radius, ent=idx)
+            return True if r == 1 else None if r < 2 else (self.agent if r - 2 == self._b.n_boxes else self._slots[r - 2])
         idx = next((i for i, e2 in enumerate(self.entities) if e2 is ent), -1)
         r = self._b.intersect(0, pos[0], pos[2], radius, ent=idx)
         if r == 1:

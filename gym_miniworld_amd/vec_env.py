@@ -76,8 +76,9 @@ class LazyInfos:
         for info in infos: _feature.append(info["feature"])          (pytorch-a2c-ppo-acktr/main.py:612-617)
     by `infos.feature`:  goal_pos [N,3] float64 or None, feature [N,2] float64 or None, skipped bool [N] or None."""
 
-    def __init__(self, n, goal_pos=None, feature=None, skipped=None, default_feature=False):
+    def __init__(self, n, goal_pos=None, feature=None, skipped=None, default_feature=False, health=None):
         self.n, self.goal_pos, self.skipped = n, goal_pos, skipped
+        self.health = health   # CollectHealth: info['health'] (collecthealth.py:75), float64 [N] or None
         self._task_feature = feature is not None
         self.feature = feature if feature is not None else (np.zeros((n, 2)) if default_feature else None)
 
@@ -96,6 +97,8 @@ class LazyInfos:
         info = {}
         if self.goal_pos is not None:
             info["goal_pos"] = self.goal_pos[i].copy()
+        if self.health is not None:
+            info["health"] = float(self.health[i])
         if self._task_feature:
             info["feature"] = self.feature[i].copy()
         elif self.feature is not None:
@@ -152,7 +155,7 @@ class MiniWorldVecEnv(VecEnv):
         # done | reward | feature | goal_pos | ep_steps | reward64 in one allocation: only the prefix this view returns is copied
         off_ = b.pack_offsets
         need = off_["feature"] if torch_api else int(b.pack.numel())   # done + float32 reward ...
-        if torch_api and b.has_features:
+        if torch_api and (b.has_features or b.has_health):
             need = off_["goal_pos"]
         if torch_api and b.has_goal_pos:
             need = off_["ep_steps"]
@@ -163,7 +166,7 @@ class MiniWorldVecEnv(VecEnv):
         self._h_done = part("done", np.uint8, n)
         self._h_rew = part("reward", np.float32, n) if torch_api else part("reward64", np.float64, n)
         self._h_goal = part("goal_pos", np.float64, 3 * n).reshape(n, 3) if b.has_goal_pos else None
-        self._h_feat = part("feature", np.float32, 2 * n).reshape(n, 2) if b.has_features else None
+        self._h_feat = part("feature", np.float32, 2 * n).reshape(n, 2) if (b.has_features or b.has_health) else None
         self._h_skip = pin((num_envs,), torch.uint8)
         self._ev = torch.cuda.Event()
         self._skip_host = None
@@ -250,7 +253,9 @@ class MiniWorldVecEnv(VecEnv):
         else:
             rews = self._h_rew.copy()
         sk = self._skip_host
-        if b.has_goal_pos:   # the T-maze family: info['goal_pos'] (tmaze.py:66,206) and, where produced, info['feature']
+        if b.has_health:   # CollectHealth: info['health'] (delivered in feature[:, 0])
+            infos = LazyInfos(self.num_envs, health=self._h_feat[:, 0].astype(np.float64), skipped=sk, default_feature=self.feature_info)
+        elif b.has_goal_pos:   # the T-maze family: info['goal_pos'] (tmaze.py:66,206) and, where produced, info['feature']
             infos = LazyInfos(self.num_envs, goal_pos=self._h_goal.copy(),
                               feature=self._h_feat.astype(np.float64) if self._h_feat is not None else None,
                               skipped=sk, default_feature=self.feature_info)

@@ -2304,17 +2304,19 @@ static uint64_t splitmix(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-double mwo_bench_loop(MwoEnv *e, int n_steps, uint64_t action_seed, uint64_t env_index, int W, int H, int want_depth, int constant_action) {
+double mwo_bench_loop(MwoEnv *e, int n_steps, uint64_t action_seed, uint64_t env_index, int W, int H, int want_depth, int constant_action, int n_actions) {
+    if (n_actions <= 0) n_actions = 3;
     uint8_t *rgb = malloc((size_t)W * H * 3);
     float *dep = want_depth ? malloc(sizeof(float) * W * H) : NULL;
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int t = 0; t < n_steps; t++) {
         int a = constant_action >= 0 ? constant_action
-                                     : (int)((splitmix(action_seed ^ splitmix((uint64_t)t * 0x100000001B3ull + env_index)) >> 33) % 3);
+                                     : (int)((splitmix(action_seed ^ splitmix((uint64_t)t * 0x100000001B3ull + env_index)) >> 33) % (uint64_t)n_actions);
         double r; int d;
         mwo_step(e, a, &r, &d);
         if (d) mwo_reset(e);
+        e->render_step_frame = !d;   /* the step's own frame (an object just picked up is still drawn), as the GPU path renders it */
         mwo_render(e, W, H, rgb, dep);
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);

@@ -140,7 +140,7 @@ void mwo_gen_rot_matrix(const double *axis3, double angle, double *out9);
 /* timed loop for bench.py's cpu_baseline: n_steps of step(+auto reset)+render with the
  * counter-based action stream; returns wall seconds */
 double mwo_bench_loop(MwoEnv *e, int n_steps, uint64_t action_seed, uint64_t env_index, int width,
-                      int height, int want_depth, int constant_action /* -1 = random */);
+                      int height, int want_depth, int constant_action /* -1 = random */, int n_actions /* random actions over range(n), 0 = 3 */);
 
 #ifdef __cplusplus
 }

@@ -113,7 +113,7 @@ def lib():
         L.mwo_gen_rot_matrix.argtypes = [dp, ctypes.c_double, dp]
         L.mwo_bench_loop.restype = ctypes.c_double
         L.mwo_bench_loop.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int,
-                                     ctypes.c_int, ctypes.c_int, ctypes.c_int]
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -384,9 +384,9 @@ class OracleEnv:
         self.L.mwo_get_geometry(self.h, *[g[k].ctypes.data_as(ctypes.c_void_p) for k in order])
         return g
 
-    def bench_loop(self, n_steps, action_seed=0, env_index=0, want_depth=False, constant_action=-1):
+    def bench_loop(self, n_steps, action_seed=0, env_index=0, want_depth=False, constant_action=-1, n_actions=3):
         return self.L.mwo_bench_loop(self.h, n_steps, action_seed, env_index, self.W, self.H,
-                                     int(want_depth), constant_action)
+                                     int(want_depth), constant_action, int(n_actions))
 
 
 def intersect_circle_segs(pt, radius, segs):

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_struct_layout_matches_header(built):
     # mwb_config: 10 int32, 4 doubles, 2 int32, 13*9 doubles
     assert ctypes.sizeof(built.MwbConfig) == 10 * 4 + 4 * 8 + 2 * 4 + 13 * 9 * 8
-    assert ctypes.sizeof(built.MwbOutputs) == 14 * 8 and ctypes.sizeof(built.MwbState) == 22 * 8
+    assert ctypes.sizeof(built.MwbOutputs) == 14 * 8 and ctypes.sizeof(built.MwbState) == 30 * 8
 
 
 def test_create_fails_loudly_without_gpu_or_with_bad_args(built):
@@ -91,7 +91,10 @@ def test_params_table_mirrors_reference_defaults():
 def test_env_registry_covers_the_configured_tasks():
     from gym_miniworld_amd.batch import ENV_SPECS
     for k in ("MiniWorld-Hallway-v0", "MiniWorld-OneRoom-v0", "MiniWorld-FourRooms-v0", "MiniWorld-Maze-v0",
-              "MiniWorld-MazeS2-v0", "MiniWorld-MazeS3-v0", "MiniWorld-OneRoomS6-v0"):
+              "MiniWorld-MazeS2-v0", "MiniWorld-MazeS3-v0", "MiniWorld-OneRoomS6-v0",
+              # round 3: the tasks with mesh entities / frames
+              "MiniWorld-PickupObjs-v0", "MiniWorld-RoomObjs-v0", "MiniWorld-CollectHealth-v0", "MiniWorld-Sign-v0",
+              "MiniWorld-Sidewalk-v0", "MiniWorld-WallGap-v0"):
         assert k in ENV_SPECS
 
 

@@ -17,8 +17,10 @@ pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/gym_miniworld
 def test_state_and_glstream_fixtures_round_trip(tmp_path):
     out = str(tmp_path)
     subprocess.check_call([sys.executable, os.path.join(GOLDEN, "gen_fixtures.py"), "--out", out], stdout=subprocess.DEVNULL)
+    # the tasks with a general entity list (meshes, frames) have their own generator; meshes.json = digests of the reference's vertex lists
+    subprocess.check_call([sys.executable, os.path.join(GOLDEN, "gen_fixtures_ents.py"), "--out", out], stdout=subprocess.DEVNULL)
     names = sorted(f for f in os.listdir(out) if f.endswith((".npz", ".json")))
-    committed = sorted(f for f in os.listdir(GOLDEN) if f.startswith(("state_", "glstream_", "gltop_", "math_kat", "seed_keys")))
+    committed = sorted(f for f in os.listdir(GOLDEN) if f.startswith(("state_", "glstream_", "gltop_", "math_kat", "seed_keys", "meshes.json")))
     assert names == committed
     n_arrays = 0
     for f in names:

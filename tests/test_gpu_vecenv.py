@@ -175,6 +175,8 @@ def test_every_covered_env_id_loads_and_steps_like_run_tests():
         env.domain_rand = True
         for _ in range(4):
             obs = env.reset()
+            if isinstance(obs, dict):   # Sign: {"obs": ..., "goal": ...} (sign.py:130-133)
+                obs = obs["obs"]
             assert obs.shape == env.observation_space.shape and 0 < obs.mean() < 255, env_id
             assert not env.intersect(env.agent, env.agent.pos, env.agent.radius), env_id
             for _ in range(20):
