@@ -306,6 +306,16 @@ class BatchedMiniWorld:
         _lib.check(self.L.mwb_render_top_view(self.h, out.data_ptr(), W, H, self._stream()))
         return out
 
+    def render_view(self, width, height, depth=False):
+        """MiniWorldEnv.render_obs(frame_buffer) with another frame buffer than the observation's (miniworld.py:1160-1205), e.g.
+        the 800 x 600 human view of render(mode='rgb_array'): uint8 [N, height, width, 3] (and float32 [N, height, width, 1]
+        metres with depth=True) on the device, any size (rendered in tiles)"""
+        W, H = int(width), int(height)
+        out = self.torch.empty((self.num_envs, H, W, 3), dtype=self.torch.uint8, device=self.device)
+        dep = self.torch.empty((self.num_envs, H, W, 1), dtype=self.torch.float32, device=self.device) if depth else None
+        _lib.check(self.L.mwb_render_view(self.h, out.data_ptr(), dep.data_ptr() if depth else None, W, H, self._stream()))
+        return (out, dep) if depth else out
+
     # ---------------------------------------------------------------------------- introspection
     def check(self):
         """Synchronous: raises if world generation ever flagged a failure (see mwb_check)."""

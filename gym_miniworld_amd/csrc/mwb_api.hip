@@ -75,6 +75,7 @@ struct mwb_handle {
     bool meshes_dirty;
     float4 *mesh_data_dev;
     MwbMeshDesc *mesh_desc_dev;
+    float *view_frame;   // frame constants of mwb_render_view's size (lazily allocated)
 };
 
 extern "C" const char *mwb_last_error(void) { return g_err.c_str(); }
@@ -361,6 +362,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     h->timing = false; h->timing_now = false; h->timing_period = 1; h->timing_tick = 0; h->ev_used = 0; h->ev = nullptr;
     { const char *no = getenv("MWB_NO_OVERLAP"); h->overlap_reset = !(no && atoi(no)); }
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
+    h->view_frame = nullptr; d.lds_geom = -1; d.lds_mesh_f4 = 0;
     h->meshes_dirty = false; h->mesh_data_dev = nullptr; d.mesh_desc = h->mesh_desc_dev; d.mesh_data = nullptr;
     h->stack = nullptr; h->stack_n = 0; h->stack_dtype = 0; h->stack_bytes = 0; h->stack_planes = 0; h->stack_pos = 0; h->stack_fused = 0;
     int prio_lo = 0, prio_hi = 0;
@@ -572,6 +574,16 @@ static int upload_meshes(mwb_handle *h) {   // the caller holds the device guard
     if (!all.empty()) HIP_TRY(hipMemcpy(h->mesh_data_dev, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->mesh_desc_dev, desc, sizeof(desc), hipMemcpyHostToDevice));
     h->dev.mesh_data = h->mesh_data_dev;
+    {   // the small mesh of the task (a key, a medkit, a cone: <= 25 KB of nodes + triangle records) is walked from LDS
+        static const int prefer[MWB_NUM_TASKS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, MWB_MESH_KEY, MWB_MESH_KEY, MWB_MESH_MEDKIT, MWB_MESH_KEY, MWB_MESH_KEY, MWB_MESH_CONE, -1};
+        const int g = prefer[h->dev.task];
+        h->dev.lds_geom = -1; h->dev.lds_mesh_f4 = 0;
+        if (g >= 0 && h->meshes[g].set) {
+            const int f4 = 2 * h->meshes[g].n_nodes + 3 * h->meshes[g].n_tris;
+            if (f4 <= 1600) { h->dev.lds_geom = g; h->dev.lds_mesh_f4 = f4; }
+        }
+        if (int prc = mwb_prepare_kernels(h->dev)) return set_err(prc == -2 ? MWB_EHIP : MWB_EINVAL, "mesh staging does not fit LDS");
+    }
     h->meshes_dirty = false;
     return MWB_OK;
 }
@@ -745,6 +757,26 @@ extern "C" int mwb_render_top_view(mwb_handle *h, uint8_t *out_dev, int width, i
     rc = check_launch("prep_kernel"); if (rc) return rc;
     mwb_launch_top_view(h->dev, out_dev, width, height, s);
     return check_launch("top_view_kernel");
+}
+
+extern "C" int mwb_render_view(mwb_handle *h, uint8_t *out_dev, float *depth_dev, int width, int height, void *stream) {
+    if (!h || !out_dev) return set_err(MWB_EINVAL, "mwb_render_view: null argument");
+    if (width < 1 || height < 1 || width > 4096 || height > 4096) return set_err(MWB_EINVAL, "mwb_render_view: bad frame size");
+    USE_DEVICE(h->cfg.device);
+    int rc = ensure_ready(h, false); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t words = (size_t)h->dev.N * h->dev.frame_words;
+    if (!h->view_frame) {   // frame constants of the other view size, kept apart from the observation's
+        rc = dev_alloc(h, &h->view_frame, words); if (rc) return rc;
+    }
+    MwbDev v = h->dev;
+    v.W = width; v.H = height; v.layout = MWB_LAYOUT_HWC; v.obs = out_dev; v.depth = depth_dev; v.want_depth = depth_dev ? 1 : 0;
+    v.frame = h->view_frame; v.stk = nullptr; v.step_pass = 0; v.wg_ts = nullptr;
+    mwb_launch_prep(v, 0, s);
+    rc = check_launch("prep_kernel"); if (rc) return rc;
+    const int lrc = mwb_launch_render_view(v, s);
+    if (lrc) return set_err(lrc == -1 ? MWB_EINVAL : MWB_EHIP, lrc == -1 ? "mwb_render_view: the world's room table does not fit LDS beside a tile" : "mwb_render_view: hipFuncSetAttribute failed");
+    return check_launch("render_view_kernel");
 }
 
 extern "C" int mwb_visible_ents(mwb_handle *h, uint32_t *mask_dev, void *stream) {

@@ -89,7 +89,7 @@
 // Entity tasks: the same FC_BOX_STRIDE-word block per entity slot, read by kind.  FC_BOX_HX >= 0: a box (as above); -1: a mesh;
 // -2: an image / text frame; an entity that has left the list has FC_CULL_CC = FC_CULL_CC_PIXEL = +inf (no ray ever passes its gate).
 //   mesh  (offsets from the block's start = FC_LIT_BOX - 36): 0-2 light direction in the mesh's frame / scale, 3-5 Kd,
-//         6-8 0.2 Kd + ambient Kd, 9-11 diffuse, 12 1 / scale, 13 geometry (int), 14 texture slot (int, -1 none);
+//         6-8 0.2 Kd + ambient Kd, 9-11 diffuse, 12 1 / scale, 13 geometry (int), 14 texture slot (int, -1 none), 15-17 + FC_BOX_SY: gate box;
 //         FC_BOX_POS, FC_BOX_C, FC_BOX_S as for a box; FC_BOX_LO = the eye in the mesh's frame (rotated, / scale)
 //   frame: 0-2 lit colour of the front, 3 depth, 4 half height, 5 half width, 6 character width, 7 characters (int),
 //         8-15 texture slot per character (int, -1 = blank); FC_BOX_POS, C, S; FC_BOX_LO = the eye in the frame's axes
@@ -100,6 +100,9 @@
 #define FE_MESH_INVS 12
 #define FE_MESH_GEOM 13
 #define FE_MESH_TEX 14
+#define FE_MESH_BPAD 15   // gate box (below) grown by a pixel's footprint at the mesh's far side, in mesh units
+#define FE_MESH_BHX 16    // a conservative box of the mesh in its own frame, for the interior-pixel gate: |x| <= BHX, |z| <= BHZ,
+#define FE_MESH_BHZ 17    //   0 <= y <= FC_BOX_SY (objmesh.py re-centres every mesh: base at y = 0, x and z about the middle)
 #define FE_FRAME_LIT 0
 #define FE_FRAME_SX 3
 #define FE_FRAME_HY 4
@@ -203,6 +206,7 @@ struct MwbDev {
     const float4 *mesh_data;
     MwbMeshDims mesh_dims[MWB_MAX_MESH_DIMS];
     int n_mesh_dims;
+    int lds_geom, lds_mesh_f4;   // the task's small mesh geometry the render kernel stages in LDS (-1 none) and its size in float4
 };
 
 // launch wrappers implemented in mwb_kernels.hip
@@ -218,6 +222,7 @@ void mwb_launch_stack(const MwbDev &d, void *stack, int nstack, int dtype, int a
 void mwb_launch_stack_slide(const MwbDev &d, void *stack, int nstack, int planes, int dtype, int pos, int from, int mode, hipStream_t s);
 void mwb_launch_intersect(const MwbDev &d, int env, int ent, double x, double z, double radius, int *result_dev, hipStream_t s);
 void mwb_launch_visible(const MwbDev &d, uint32_t *mask_out, hipStream_t s);   // get_visible_ents for every env
+int mwb_launch_render_view(const MwbDev &d, hipStream_t s);   // the agent's view at d.W x d.H in tiles; 0 ok, -1 LDS, -2 HIP
 void mwb_launch_top_view(const MwbDev &d, uint8_t *out, int W, int H, hipStream_t s);   // render_top_view for every env, [N][H][W][3]
 int mwb_prepare_kernels(const MwbDev &d);   // 0 ok, -1 world too large for LDS, -2 HIP error, -3 frame too large for the pixel queue
 size_t mwb_reset_lds_bytes(const MwbDev &d);

@@ -1662,10 +1662,12 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
             const MwbMeshDesc &md = d.mesh_desc[MWB_META_GEOM(meta)];
             const double scale = d.ent_scale[be];
             const float inv_s = (float)(1.0 / scale);
-            fc[FC_BOX_HX] = -1.0f; fc[FC_BOX_HZ] = 0.0f; fc[FC_BOX_SY] = 0.0f;
+            fc[FC_BOX_HX] = -1.0f; fc[FC_BOX_HZ] = 0.0f;
             blk[FE_MESH_LL] = (L[0] * c_ - L[2] * s_) * inv_s; blk[FE_MESH_LL + 1] = L[1] * inv_s; blk[FE_MESH_LL + 2] = (L[0] * s_ + L[2] * c_) * inv_s;
             for (int k = 0; k < 3; k++) { blk[FE_MESH_KD + k] = bcol[k]; blk[FE_MESH_AMB + k] = 0.2f * bcol[k] + amb[k] * bcol[k]; blk[FE_MESH_DIF + k] = dif[k]; }
             blk[FE_MESH_INVS] = inv_s; blk[FE_MESH_GEOM] = __int_as_float(MWB_META_GEOM(meta)); blk[FE_MESH_TEX] = __int_as_float(md.tex_id);
+            blk[FE_MESH_BHX] = fmaxf(fabsf(md.min_c[0]), fabsf(md.max_c[0])); blk[FE_MESH_BHZ] = fmaxf(fabsf(md.min_c[2]), fabsf(md.max_c[2]));
+            fc[FC_BOX_SY] = md.max_c[1];
             fc[FC_BOX_LO] = (ro[0] * c_ - ro[2] * s_) * inv_s; fc[FC_BOX_LO + 1] = ro[1] * inv_s; fc[FC_BOX_LO + 2] = (ro[0] * s_ + ro[2] * c_) * inv_s;
             float lc[3], ext2 = 0.0f;
             for (int k = 0; k < 3; k++) { lc[k] = 0.5f * (md.min_c[k] + md.max_c[k]); const float h = 0.5f * (md.max_c[k] - md.min_c[k]); ext2 += h * h; }
@@ -1695,14 +1697,18 @@ __device__ __forceinline__ void prep_env(const MwbDev &d, int e) {
             const float rho = 1.5f * 2.0f * sqrtf(tw * tw + thh * thh);
             const float Rp = R + rho * (sqrtf(oc2) + R);
             fc[FC_CULL_CC_PIXEL] = oc2 - Rp * Rp;
+            // a mesh's own box (a sphere is a poor bound of a 30 m building): grown by the same pixel footprint, in mesh units
+            if (kind == MWB_ENT_MESH) blk[FE_MESH_BPAD] = 1.02f * rho * (sqrtf(oc2) + R) * blk[FE_MESH_INVS] + 1e-3f * fc[FC_BOX_SY];
             const double dist = sqrt((double)oc2), Rg = 1.02 * (double)Rp;
-            if (dist <= Rg) any_in_view = 1.0f;
-            else {
+            bool in_view = dist <= Rg;
+            if (!in_view) {
                 const double cosang = ((double)oc[0] * f[0] + (double)oc[1] * f[1] + (double)oc[2] * f[2]) / dist;
                 const double ang = acos(cosang < -1 ? -1 : (cosang > 1 ? 1 : cosang));
                 const double half = atan(sqrt(th * th * ((double)d.W / d.H) * ((double)d.W / d.H) + th * th));
-                if (ang <= half + asin(Rg / dist) + 0.01) any_in_view = 1.0f;
+                in_view = ang <= half + asin(Rg / dist) + 0.01;
             }
+            if (in_view) any_in_view = 1.0f;
+            if (kind == MWB_ENT_MESH) fc[FC_BOX_HZ] = in_view ? 1.0f : 0.0f;   // read by the render kernel's decision to stage the mesh in LDS
             continue;
         }
     }
@@ -2059,20 +2065,15 @@ __device__ __forceinline__ bool mesh_tri(const float *lo, const float *ld, const
 }
 // nearest front-facing triangle of the entity's mesh along (eye, dv) that is strictly nearer than t_max: its index in draw order
 // or -1.  Threaded BVH (host-built, gym_miniworld_amd/meshes.py): depth-first node order, `skip` links, no stack.
-__device__ __forceinline__ int trace_mesh_bvh(const float *blk, const MwbMeshDesc *__restrict__ descs, const float4 *__restrict__ data,
-                                              const float *dv, float t_max, float &t_out) {
-    float ld[3];
-    mesh_local_dir(blk, dv, ld);
-    const float lo[3] = {blk[FC_BOX_LO], blk[FC_BOX_LO + 1], blk[FC_BOX_LO + 2]};
-    const int geom = __builtin_amdgcn_readfirstlane(__float_as_int(blk[FC_LIT_BOX + FE_MESH_GEOM]));
-    const MwbMeshDesc &md = descs[geom];
-    const float4 *nodes = data + md.node_off, *tris = data + md.tri_off;
-    const int n_nodes = md.n_nodes;
+typedef float f4n __attribute__((ext_vector_type(4)));   // a plain vector type: loadable through an address-space-qualified pointer
+typedef __attribute__((address_space(3))) const f4n lds_f4;
+template <typename P4>
+__device__ __forceinline__ int walk_mesh_bvh(P4 *nodes, P4 *tris, const int n_nodes, const float *lo, const float *ld, float t_max, float &t_out) {
     const float ix = 1.0f / ld[0], iy = 1.0f / ld[1], iz = 1.0f / ld[2];
     int node = 0, best = -1;
     float bt = t_max;
     while (node < n_nodes) {
-        const float4 a = nodes[2 * node], b = nodes[2 * node + 1];
+        const f4n a = nodes[2 * node], b = nodes[2 * node + 1];
         float t0 = (a.x - lo[0]) * ix, t1 = (b.x - lo[0]) * ix;
         float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
         t0 = (a.y - lo[1]) * iy; t1 = (b.y - lo[1]) * iy;
@@ -2085,7 +2086,8 @@ __device__ __forceinline__ int trace_mesh_bvh(const float *blk, const MwbMeshDes
         if (cnt == 0) { node++; continue; }
         const int first = (int)(fcnt & 0xFFFFFFu);
         for (int k = 0; k < cnt; k++) {
-            const float4 r0 = tris[3 * (first + k)], r1 = tris[3 * (first + k) + 1], r2 = tris[3 * (first + k) + 2];
+            const f4n q0 = tris[3 * (first + k)], q1 = tris[3 * (first + k) + 1], q2 = tris[3 * (first + k) + 2];
+            const float4 r0 = make_float4(q0.x, q0.y, q0.z, q0.w), r1 = make_float4(q1.x, q1.y, q1.z, q1.w), r2 = make_float4(q2.x, q2.y, q2.z, q2.w);
             float t, u, v, det;
             if (mesh_tri(lo, ld, r0, r1, r2, true, t, u, v, det)) {
                 const int idx = __float_as_int(r2.y);
@@ -2096,6 +2098,23 @@ __device__ __forceinline__ int trace_mesh_bvh(const float *blk, const MwbMeshDes
     }
     t_out = bt;
     return best;
+}
+// lds_geom: the geometry whose nodes + leaf-order triangle records this workgroup has staged in LDS at lds_mesh (-1 none): its walk
+// reads LDS (~100 cycles per dependent step instead of an L2 round trip)
+__device__ __forceinline__ int trace_mesh_bvh(const float *blk, const MwbMeshDesc *__restrict__ descs, const float4 *__restrict__ data,
+                                              const float *dv, float t_max, float &t_out, int lds_geom, const float4 *lds_mesh) {
+    float ld[3];
+    mesh_local_dir(blk, dv, ld);
+    const float lo[3] = {blk[FC_BOX_LO], blk[FC_BOX_LO + 1], blk[FC_BOX_LO + 2]};
+    const int geom = __builtin_amdgcn_readfirstlane(__float_as_int(blk[FC_LIT_BOX + FE_MESH_GEOM]));
+    const MwbMeshDesc &md = descs[geom];
+    const int n_nodes = md.n_nodes;
+    if (geom == lds_geom) {
+        lds_f4 *base = (lds_f4 *)lds_mesh;
+        return walk_mesh_bvh<lds_f4>(base, base + 2 * n_nodes, n_nodes, lo, ld, t_max, t_out);
+    }
+    const f4n *gd = (const f4n *)data;
+    return walk_mesh_bvh<const f4n>(gd + md.node_off, gd + md.tri_off, n_nodes, lo, ld, t_max, t_out);
 }
 // ImageFrame / TextFrame: slab [0, depth] x [-h/2, h/2] x [-w/2, w/2] in the frame's axes; returns the character cell of the
 // front (+x) face, 100 for a black side, -1 for a miss or the missing back
@@ -2225,10 +2244,13 @@ struct RenderCtx {
     float *depth;   // this env's depth map or null
     Cam cam;
     int n_rooms, cam_room, W, H, layout;
+    int depth_stride;   // floats between rows of the depth map: W, or the whole view's width when this workgroup renders a tile of it
     float cull_cc[1], cull_oc[1][3], zA, zB;   // the box's cull constants (NBOX == 1 only: scalar registers)
     bool boxes_in_view;   // workgroup-uniform (scalar): false = no ray of this frame can touch a box
     const MwbMeshDesc *mesh_desc;   // entity tasks: mesh geometries in HBM (L2 resident), or null
     const float4 *mesh_data;
+    int lds_geom;                   // geometry staged in LDS for this frame (-1 none) ...
+    const float4 *lds_mesh;         // ... its nodes, then its triangle records in leaf order
     // per work item (15 x 15 pixels), which boxes can touch any of its rays at all (frame-level pre-test pass; null = unknown)
     const uint4 *item_res;
     int part_h_inv;       // ceil(65536 / rows per item): row -> quarter without a division
@@ -2500,7 +2522,7 @@ struct RenderCtx {
             // get_depth_map, opengl.py:362-367 in float32
             float dm = (float)z16 / 65535.0f;
             float clip_z = (dm - 0.5f) * 2.0f;
-            depth[py * W + px] = (float)(-2.0 * 100.0 * 0.04) / (clip_z * (float)(100.0 - 0.04) - (float)(100.0 + 0.04));
+            depth[py * depth_stride + px] = (float)(-2.0 * 100.0 * 0.04) / (clip_z * (float)(100.0 - 0.04) - (float)(100.0 + 0.04));
         }
     }
 
@@ -2569,7 +2591,7 @@ struct RenderCtx {
                             ekind = hxk == -1.0f ? 1 : hxk == -2.0f ? 2 : 0;
                         }
                         if (ekind == 1) {
-                            const int tri = trace_mesh_bvh(fb_, mesh_desc, mesh_data, dv, th, tb);
+                            const int tri = trace_mesh_bvh(fb_, mesh_desc, mesh_data, dv, th, tb, lds_geom, lds_mesh);
                             if (tri >= 0) { key = KIND_MESH | ((uint32_t)bi << 3) | ((uint32_t)tri << 8); th = tb; }
                         } else if (ekind == 2) {
                             const int code = trace_frame(fb_, dv, tb);
@@ -2669,13 +2691,18 @@ __device__ __forceinline__ void copy_frame_range(uint8_t *__restrict__ dst, cons
 // part < 0: the whole frame; part 0 / 1: one half of it (the last envs of a bulk launch are cut in two so that the
 // launch drains in units of half a workgroup time) - the upper / lower rows for HWC frames, the left / right
 // strips for CWH ones, so that a half's bytes are one (three) contiguous run(s).
-template <int THREADS, int NBOX, bool LOOPED, bool POLY>
-__device__ __forceinline__ void render_env(const MwbDev &d, const int e, const int part, unsigned char *smem) {
+// TILED: the workgroup renders the tile [tx0, tx0 + tw) x [ty0, ty0 + th) of a larger view of d.W x d.H pixels (mwb_render_view: the
+// reference's 800 x 600 human view, or any observation size whose frame does not fit LDS): everything below works in tile-local
+// pixel coordinates; only the camera's window mapping carries the offset - (2 (wx + ox) - W) / W = (2 wx - (W - 2 ox)) / W, exact
+// in float32 - and the tile's rows go to their places in the big frame.
+template <int THREADS, int NBOX, bool LOOPED, bool POLY, bool TILED = false>
+__device__ __forceinline__ void render_env(const MwbDev &d, const int e, const int part, unsigned char *smem, const int tx0 = 0,
+                                           const int ty0 = 0, const int tw = 0, const int th = 0) {
     // LOOPED (the body sits in a loop over the regenerated-env list): make the lane id opaque to the optimiser so that
     // nothing derived from it is hoisted out of that loop and kept alive across whole frames (200 -> 76 B/lane of scratch)
     int tid = threadIdx.x;
     if (LOOPED) asm volatile("" : "+v"(tid));
-    const int W = d.W, H = d.H;
+    const int W = TILED ? tw : d.W, H = TILED ? th : d.H;
     int n_rooms = d.n_rooms[e];
     if (n_rooms < 0) n_rooms = 0;
     float *rooms = (float *)smem;
@@ -2688,6 +2715,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     uint16_t *ipix = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
     uint4 *item_res = (uint4 *)(smem + off); off += (size_t)ITEM_RES_BYTES(W);   // per work item: uniform rows + their key
     uint8_t *fb = smem + off;   // the frame is assembled in LDS and leaves as 16-byte coalesced stores
+    float4 *mesh_lds = (float4 *)(smem + ((off + (size_t)W * H * 3 + 15) & ~(size_t)15));   // entity tasks: a small mesh's BVH (d.lds_mesh_f4 float4)
 
     {   // stage the room table, the frame constants and the texture descriptors
         const int rw = POLY ? MWB_POLY_ROOM_WORDS : MWB_ROOM_WORDS;
@@ -2705,7 +2733,28 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     RenderCtx<NBOX, POLY> ctx;
     ctx.rooms = rooms; ctx.fc = fc; ctx.tex = tex; ctx.texels = d.texels; ctx.fb = fb;
     ctx.mesh_desc = d.mesh_desc; ctx.mesh_data = d.mesh_data;
-    ctx.depth = d.want_depth ? d.depth + (size_t)e * W * H : nullptr;
+    ctx.lds_geom = -1; ctx.lds_mesh = mesh_lds;
+    if constexpr (NBOX > MWB_MAX_BOXES) {
+        // the task's small mesh (key / medkit / cone: d.lds_geom) moves into LDS for this frame if an entity made of it can be seen at all
+        if (d.lds_geom >= 0) {
+            bool wanted = false;
+            for (int bi = 0; bi < d.n_boxes; bi++) {
+                const float *fb_ = fc + bi * FC_BOX_STRIDE;
+                wanted = wanted || (fb_[FC_BOX_HX] == -1.0f && __float_as_int(fb_[FC_LIT_BOX + FE_MESH_GEOM]) == d.lds_geom && fb_[FC_BOX_HZ] != 0.0f);
+            }
+            if (__builtin_amdgcn_readfirstlane((int)wanted)) {
+                const MwbMeshDesc &md = d.mesh_desc[d.lds_geom];
+                const float4 *srcn = d.mesh_data + md.node_off, *srct = d.mesh_data + md.tri_off;
+                const int nn = 2 * md.n_nodes, nt = 3 * md.n_tris;
+                for (int i = tid; i < nn; i += THREADS) mesh_lds[i] = srcn[i];
+                for (int i = tid; i < nt; i += THREADS) mesh_lds[nn + i] = srct[i];
+                ctx.lds_geom = d.lds_geom;
+                __syncthreads();
+            }
+        }
+    }
+    ctx.depth = d.want_depth ? d.depth + (size_t)e * d.W * d.H + (TILED ? (size_t)ty0 * d.W + tx0 : 0) : nullptr;
+    ctx.depth_stride = TILED ? d.W : W;
     ctx.n_rooms = n_rooms; ctx.W = W; ctx.H = H; ctx.layout = d.layout;
     Cam &cam = ctx.cam;
     // frame constants are workgroup-uniform: pin them to scalar registers
@@ -2714,6 +2763,10 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     for (int k = 0; k < 3; k++) { cam.eye[k] = uni(fc[FC_EYE + k]); cam.F[k] = uni(fc[FC_F + k]); cam.S[k] = uni(fc[FC_S + k]); cam.U[k] = uni(fc[FC_U + k]); }
     cam.TW = uni(fc[FC_TW]); cam.TH = uni(fc[FC_TH]);
     cam.Wf = (float)W; cam.Hf = (float)H; cam.invW = 1.0f / (float)W; cam.invH = 1.0f / (float)H;
+    if (TILED) {   // window x of tile column c = tx0 + c; window y (up) of tile row r (from the top) = (d.H - ty0 - th) + (th - r)
+        cam.Wf = (float)(d.W - 2 * tx0); cam.Hf = (float)(d.H - 2 * (d.H - ty0 - th));
+        cam.invW = 1.0f / (float)d.W; cam.invH = 1.0f / (float)d.H;
+    }
     // room containing the eye: first (lowest index) rectangle that holds it, bounds inclusive.  Every wave finds it for
     // itself (64 rooms per sweep, lowest set bit of the first non-empty ballot): no LDS atomic, no barrier
     ctx.cam_room = -1;
@@ -2824,7 +2877,25 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
                 const float *fb_ = fc + __builtin_ctz(bm) * FC_BOX_STRIDE;
                 const float ccp = fb_[FC_CULL_CC_PIXEL];
                 const float b = dc[0] * fb_[FC_CULL_OC] + dc[1] * fb_[FC_CULL_OC + 1] + dc[2] * fb_[FC_CULL_OC + 2];
-                touch = touch || ccp <= 0.0f || (b > 0.0f && b * b >= dd * ccp);
+                bool t_ = ccp <= 0.0f || (b > 0.0f && b * b >= dd * ccp);
+                if constexpr (NBOX > MWB_MAX_BOXES) {   // a mesh: its pixel-inflated sphere AND its own pixel-inflated bounding box
+                    if (__builtin_amdgcn_readfirstlane(__float_as_int(fb_[FC_BOX_HX])) == __float_as_int(-1.0f) && t_) {
+                        const float *me = fb_ + FC_LIT_BOX;
+                        float ld[3];
+                        mesh_local_dir(fb_, dc, ld);
+                        const float pad = me[FE_MESH_BPAD];
+                        const float blo[3] = {-me[FE_MESH_BHX] - pad, -pad, -me[FE_MESH_BHZ] - pad}, bhi[3] = {me[FE_MESH_BHX] + pad, fb_[FC_BOX_SY] + pad, me[FE_MESH_BHZ] + pad};
+                        float tn = -INFINITY, tf = INFINITY;
+#pragma unroll
+                        for (int a = 0; a < 3; a++) {
+                            const float inv = 1.0f / ld[a], o_ = fb_[FC_BOX_LO + a];
+                            const float t0 = (blo[a] - o_) * inv, t1 = (bhi[a] - o_) * inv;
+                            tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                        }
+                        t_ = tn <= tf && tf > 0.0f;
+                    }
+                }
+                touch = touch || t_;
             }
         }
         return touch;
@@ -3035,7 +3106,13 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     {   // framebuffer LDS -> HBM, 16 bytes per lane where the alignment allows
         const int nbytes = W * H * 3;
         uint8_t *dst = d.obs + (size_t)e * nbytes;
-        if (part < 0) {
+        if (TILED) {   // the tile's rows into the big HWC frame
+            uint8_t *big = d.obs + ((size_t)e * d.W * d.H + (size_t)ty0 * d.W + tx0) * 3;
+            for (int i = tid; i < H * W * 3; i += THREADS) {
+                const int row = i / (W * 3), col = i - row * (W * 3);
+                big[(size_t)row * d.W * 3 + col] = fb[i];
+            }
+        } else if (part < 0) {
             copy_frame_range<THREADS>(dst, fb, 0, nbytes, tid);
         } else if (!split_x) {   // HWC: rows [r0, r1)
             const int mid = 2 * part_h < H ? 2 * part_h : H;
@@ -3116,6 +3193,21 @@ __global__ void __launch_bounds__(THREADS, NBOX > MWB_MAX_BOXES ? 4 : 5) render_
             else d.cost[2 * e + part] = dt;
         }
     }
+}
+
+// The agent's view at any size (mwb_render_view): a grid of tiles per env, one workgroup each.  d.W x d.H is the view's size, d.obs /
+// d.depth / d.frame the caller's frame, the optional depth map and the frame constants prepared for that size.
+#define VIEW_TILE_W 75   // 5 strips of 15 pixels
+#define VIEW_TILE_H 60
+template <int THREADS, int NBOX, bool POLY>
+__global__ void __launch_bounds__(THREADS, NBOX > MWB_MAX_BOXES ? 4 : 5) render_view_kernel(MwbDev d, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int per_env = tiles_x * tiles_y;
+    const int e = blockIdx.x / per_env, t = blockIdx.x - e * per_env;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int tx0 = tx * VIEW_TILE_W, ty0 = ty * VIEW_TILE_H;
+    const int tw = d.W - tx0 < VIEW_TILE_W ? d.W - tx0 : VIEW_TILE_W, th = d.H - ty0 < VIEW_TILE_H ? d.H - ty0 : VIEW_TILE_H;
+    render_env<THREADS, NBOX, false, POLY, true>(d, e, -1, smem, tx0, ty0, tw, th);
 }
 
 // ================================================================================== frame stack
@@ -3248,7 +3340,35 @@ size_t mwb_reset_lds_bytes(const MwbDev &d) {
                (size_t)MWB_MAX_ENTS * (11 * sizeof(double) + 3 * sizeof(int)) + 8 * sizeof(int);   // the entity tasks' slot records
     return (b + 15) & ~(size_t)15;
 }
+static size_t render_lds_bytes_for(const MwbDev &d, int W, int H) {
+    size_t b = (((size_t)d.R_max * d.room_words * 4 + 15) & ~(size_t)15) + (size_t)d.frame_words * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
+               (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)ITEM_RES_BYTES(W) + (size_t)W * H * 3;
+    b = (b + 15) & ~(size_t)15;
+    if (d.ent_task) b += (size_t)d.lds_mesh_f4 * 16;   // a small mesh's BVH + triangle records, staged per frame
+    return (b + 15) & ~(size_t)15;
+}
+// d: the handle's MwbDev with W / H / obs / depth / frame / want_depth / layout set for the view
+int mwb_launch_render_view(const MwbDev &d, hipStream_t s) {
+    const int tiles_x = (d.W + VIEW_TILE_W - 1) / VIEW_TILE_W, tiles_y = (d.H + VIEW_TILE_H - 1) / VIEW_TILE_H;
+    const size_t lds = render_lds_bytes_for(d, VIEW_TILE_W, VIEW_TILE_H);
+    if (lds > 160 * 1024) return -1;
+    const dim3 g((unsigned)((size_t)d.N * tiles_x * tiles_y)), b(RENDER_THREADS);
+#define RV(NB, PL)                                                                                                                 \
+    do {                                                                                                                           \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)render_view_kernel<RENDER_THREADS, NB, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2; \
+        render_view_kernel<RENDER_THREADS, NB, PL><<<g, b, lds, s>>>(d, tiles_x, tiles_y);                                         \
+    } while (0)
+    if (d.ent_task) RV(MWB_MAX_ENTS, false);
+    else if (d.poly) RV(1, true);
+    else if (d.n_boxes == 6) RV(6, false);
+    else if (d.n_boxes == 2) RV(2, false);
+    else RV(1, false);
+#undef RV
+    return 0;
+}
+
 size_t mwb_render_lds_bytes(const MwbDev &d) {
+    if (d.ent_task) return render_lds_bytes_for(d, d.W, d.H);
     size_t b = (((size_t)d.R_max * d.room_words * 4 + 15) & ~(size_t)15) + (size_t)d.frame_words * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
                (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)ITEM_RES_BYTES(d.W) + (size_t)d.W * d.H * 3;
     b += (size_t)(d.debug_flags >> 8) * 128;   // MWB_DEBUG bits 8+: units of 128 B of LDS padding (occupancy experiments)

@@ -45,12 +45,16 @@ class ShardExchange:
       "direct" every rank sends its shard straight to each of its world-1 peers and receives theirs (one batched
                group of isend/irecv): xGMI is a full point-to-point mesh (7 links x ~153 GB/s per GPU), so the
                direct form moves shard/link_bw instead of the ring's 7 x shard/link_bw per-link bound.
-    "auto" times both on the first push (tune()) and keeps the faster; every rank takes the same decision (max
-    over ranks).  Whether the backend offers batched point-to-point is agreed on by all ranks BEFORE any transfer
+      "learner" only rank `learner` receives (every other rank sends its shard straight to it): a single learner process needs
+               1 / world of the bytes an all-gather moves; latest() / previous() return the full batch on the learner and the
+               rank's own shard elsewhere.
+    "auto" times ring and direct on the first push (tune()) and keeps the faster; every rank takes the same decision (max
+    over ranks).  verify() checks, outside any timed region, that the last round delivered every rank's shard (per-shard
+    checksums exchanged separately).  Whether the backend offers batched point-to-point is agreed on by all ranks BEFORE any transfer
     is posted, so a rank can never be left waiting for peers that fell back.  Gather uint8, convert on the learner side.
     """
 
-    def __init__(self, shard_shape, dtype, device, world_size, rank=0, group=None, method="auto", aux_words=AUX_WORDS):
+    def __init__(self, shard_shape, dtype, device, world_size, rank=0, group=None, method="auto", aux_words=AUX_WORDS, learner=0):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -66,8 +70,9 @@ class ShardExchange:
         self.aux_gathered = mk((self.n * self.world, self.aux_words), torch.float64)
         self.work = [None, None]
         self.cur = 0
-        if method not in ("auto", "ring", "direct"):
-            raise ValueError("method must be auto, ring or direct")
+        if method not in ("auto", "ring", "direct", "learner"):
+            raise ValueError("method must be auto, ring, direct or learner")
+        self.learner = int(learner)
         self.method = method if self.world > 1 else "ring"
         self.tuned = {}
         self._direct_ok = None
@@ -94,6 +99,18 @@ class ShardExchange:
         if method == "ring":
             return [dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True) for src, dst in pairs]
         ops = []
+        if method == "learner":   # gather to one rank: the others only send
+            if self.rank == self.learner:
+                for frm in range(self.world):
+                    if frm != self.rank:
+                        for _, dst in pairs:
+                            ops.append(dist.P2POp(dist.irecv, dst[frm * self.n:(frm + 1) * self.n], frm, group=self.group))
+                for src, dst in pairs:
+                    dst[self.rank * self.n:(self.rank + 1) * self.n].copy_(src, non_blocking=True)
+            else:
+                for src, _ in pairs:
+                    ops.append(dist.P2POp(dist.isend, src, self.learner, group=self.group))
+            return dist.batch_isend_irecv(ops) if ops else None
         for k in range(1, self.world):   # stagger the peers so that every link carries one transfer at a time
             to, frm = (self.rank + k) % self.world, (self.rank - k) % self.world
             for src, dst in pairs:
@@ -161,7 +178,51 @@ class ShardExchange:
     def _take(self, i):
         self._wait(self.work[i])
         self.work[i] = None
+        if self.method == "learner" and self.world > 1 and self.rank != self.learner:
+            return self.staging[i], self.aux_staging[i]   # only the learner holds the whole batch
         return self.gathered[i], self.aux_gathered[i]
+
+    def measure(self, iters=4):
+        """seconds per exchange of the method in use, unoverlapped (max over ranks); buffer 0 with whatever it holds"""
+        if self.world == 1:
+            return 0.0
+        torch, dist = self.torch, self.dist
+        self._wait(self._start(0, self.method))
+        if self.is_cuda:
+            torch.cuda.synchronize()
+        dist.barrier(group=self.group)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            self._wait(self._start(0, self.method))
+        if self.is_cuda:
+            torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.device if self.is_cuda else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item()) / iters
+
+    def verify(self, which="latest"):
+        """Did the round deliver EVERY rank's shard?  Each rank checksums what it staged (observation bytes and aux words); the
+        checksums travel by a separate tiny all-gather; every rank that holds the batch compares each shard of it with its
+        owner's checksum.  Returns (ok on all ranks, ranks seen).  Not for timed regions (host synchronisation)."""
+        torch, dist = self.torch, self.dist
+        i = self.cur ^ 1 if which == "latest" else self.cur
+        full, faux = self._take(i)
+        dev = self.device if self.is_cuda else "cpu"
+        cs = lambda o, a: torch.stack([o.reshape(-1).to(torch.int64).sum().to(torch.float64), a.reshape(-1).sum()])   # noqa: E731
+        mine = cs(self.staging[i], self.aux_staging[i]).to(dev)
+        if self.world == 1:
+            return bool(torch.equal(cs(full, faux).to(dev), mine)), 1
+        everyone = torch.empty((self.world * 2,), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(everyone, mine, group=self.group)
+        everyone = everyone.view(self.world, 2)
+        ok = 1
+        if not (self.method == "learner" and self.rank != self.learner):
+            for k in range(self.world):
+                got = cs(full[k * self.n:(k + 1) * self.n], faux[k * self.n:(k + 1) * self.n]).to(dev)
+                ok &= int(torch.equal(got, everyone[k]))
+        t = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item())), int(everyone.shape[0])
 
     def latest(self):
         return self._take(self.cur ^ 1)

@@ -67,14 +67,14 @@ class MiniWorldEnv:
         self.agent, self.box = _Ent(self._b.agent_radius, 1.6), _Ent(float(np.sqrt(0.8 * 0.8 + 0.8 * 0.8) / 2), 0.8)
         self.agent.carrying = None
         self.entities = [self.box, self.agent]
-        if self._b.n_boxes == 2:   # the two-box T-maze, tmaze.py:166-169
+        if self._b.n_boxes == 2 and not self._b.ent_task:   # the two-box T-maze, tmaze.py:166-169
             self.red_box, self.blue_box = self.box, _Ent(self.box.radius, 0.8)
             self.boxes = [self.red_box, self.blue_box]
             self.entities = [self.red_box, self.blue_box, self.agent]
             self.goal_box_idx, self.penalty_box_idx = 0, 1
             if self._b.task == "SimToRealPush":   # simtorealpush.py:88-99
                 self.box1, self.box2 = self.red_box, self.blue_box
-        elif self._b.n_boxes > 2:   # PutNext: one box per colour in COLOR_NAMES order (putnext.py:31-38, entity.py:18)
+        elif self._b.n_boxes > 2 and not self._b.ent_task:   # PutNext: one box per colour in COLOR_NAMES order (putnext.py:31-38, entity.py:18)
             self.boxes = [self.box] + [_Ent(self.box.radius, 0.8) for _ in range(self._b.n_boxes - 1)]
             for b, name in zip(self.boxes, ("blue", "green", "grey", "purple", "red", "yellow")):
                 b.color = name
@@ -229,7 +229,7 @@ class MiniWorldEnv:
         assert view in ("agent", "top") and mode == "rgb_array", "only mode='rgb_array' exists without a window"
         if view == "top":
             return self.render_top_view(800, 600)
-        raise NotImplementedError("view='agent' at 800 x 600 needs a second observation size: construct the env with obs_width=800, obs_height=600")
+        return self._b.render_view(800, 600).cpu().numpy()[0]   # render_obs(self.vis_fb): window_width x window_height (miniworld.py:461-462,505)
 
     def intersect(self, ent, pos, radius):
         """miniworld.py:933-959: True for a wall, the other entity for an entity hit, else None."""

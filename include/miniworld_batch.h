@@ -322,6 +322,14 @@ int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_rooms, double
  * debugging view, not part of the step pipeline. */
 int mwb_render_top_view(mwb_handle *h, uint8_t *out_dev, int width, int height, void *stream);
 
+/* replaces: MiniWorldEnv.render_obs(frame_buffer) / render_depth(frame_buffer) with ANOTHER frame buffer than the observation's
+ * (miniworld.py:1160-1220) - in particular render(mode='rgb_array', view='agent'), which draws the agent's view into the
+ * 800 x 600 `vis_fb` (miniworld.py:505,1317-1335): the current state of every env at width x height, same render spec as the
+ * observation (8 samples per pixel; the reference asks for 16 in vis_fb - not modelled).  out_dev: uint8
+ * [N][height][width][3], depth_dev: float32 [N][height][width] metres or NULL; device memory, enqueued on `stream`.  The view is
+ * rendered in tiles (one workgroup each), so its size is not bound by LDS.  Not part of the step pipeline. */
+int mwb_render_view(mwb_handle *h, uint8_t *out_dev, float *depth_dev, int width, int height, void *stream);
+
 /* replaces: MiniWorldEnv.get_visible_ents() (miniworld.py:1222-1315) for the whole batch: per env a bit mask over the boxes in
  * entity-list order, bit b set iff box b's 0.2 m query cube passes its occlusion query (any of the 8 x W x H samples of the
  * observation frame nearer than the rooms and than the cubes of the boxes before it).  mask_dev: uint32 [N] in device memory;

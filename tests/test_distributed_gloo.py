@@ -48,6 +48,8 @@ def _worker(rank, world, port, per_rank, method, out_q):
             good &= bool(u["done"][e]) == bool((e + step) % 2) and int(u["ep_steps"][e]) == step + 3 * e
         return good
 
+    learner_only = method == "learner" and rank != 0
+    verified = True
     for step in range(6):
         # the learner (rank 0) decides actions for every env; each rank gets its slice back
         all_actions = torch.tensor([(e * 5 + step) % 3 for e in range(total)], dtype=torch.int64).unsqueeze(1) if rank == 0 else None
@@ -60,11 +62,27 @@ def _worker(rank, world, port, per_rank, method, out_q):
             aux[i] = torch.tensor(expect_aux(first + i, step), dtype=torch.float64)
         g.push(obs, aux=aux)
         obs.fill_(255); aux.fill_(-1)   # the library overwrites its outputs right away: push must have snapshotted them
-        if step > 0:                     # a pipelined learner consumes the round before the newest one ...
-            po, pa = g.previous()
-            ok &= check(po, pa, step - 1)
-        full, faux = g.latest()          # ... and the newest one is right too
-        ok &= check(full, faux, step)
+        if learner_only:                # gather-to-learner: the other ranks keep their own shard only
+            mo, ma = g.latest()
+            ok &= mo.shape[0] == count and bool((mo[0] == expect_obs(first, step)).all()) and ma[0].tolist() == expect_aux(first, step)
+        else:
+            if step > 0:                     # a pipelined learner consumes the round before the newest one ...
+                po, pa = g.previous()
+                ok &= check(po, pa, step - 1)
+            full, faux = g.latest()          # ... and the newest one is right too
+            ok &= check(full, faux, step)
+        if step in (1, 4):                   # the self-check bench.py runs in its warm-up: every rank's shard arrived
+            good, seen = g.verify()
+            verified &= good and seen == world
+    ok &= verified
+    ok &= g.measure(2) >= 0.0
+    if method != "learner":   # a corrupted shard must be noticed
+        g.push(obs, aux=aux)
+        g.latest()      # waits for the round
+        if rank == 0:   # one byte of the LAST rank's shard flipped in rank 0's copy of the batch
+            g.gathered[g.cur ^ 1][(world - 1) * count] ^= 1
+        good, _ = g.verify()
+        ok &= not good
     g.drain()
     seeds = (1 + first + np.arange(count)).tolist()   # a function of the global env index only
     out_q.put((rank, ok, seeds, g.method))
@@ -72,7 +90,7 @@ def _worker(rank, world, port, per_rank, method, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,method", [(2, "ring"), (2, "direct"), (3, "direct"), (3, "ring"), (2, "auto")])
+@pytest.mark.parametrize("world,method", [(2, "ring"), (2, "direct"), (3, "direct"), (3, "ring"), (2, "auto"), (2, "learner"), (3, "learner")])
 def test_step_exchange_action_scatter_and_sharding(world, method):
     per_rank = 3
     port = _free_port()
@@ -87,4 +105,4 @@ def test_step_exchange_action_scatter_and_sharding(world, method):
         assert p.exitcode == 0
     assert all(ok for _, ok, _, _ in got)
     assert sum((s for _, _, s, _ in got), []) == list(range(1, per_rank * world + 1))
-    assert len({m for _, _, _, m in got}) == 1 and got[0][3] in ("ring", "direct")   # every rank took the same decision
+    assert len({m for _, _, _, m in got}) == 1 and got[0][3] in ("ring", "direct", "learner")   # every rank took the same decision

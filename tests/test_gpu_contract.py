@@ -29,7 +29,7 @@ def test_abi_refuses_misuse_loudly():
     assert L.mwb_step(b.h, None, None, None) == -1 and b"null actions" in L.mwb_last_error()
     b.close()
     with pytest.raises(KeyError):
-        BatchedMiniWorld("MiniWorld-PickupObjs-v0", num_envs=1)      # out of scope ids are named as such
+        BatchedMiniWorld("MiniWorld-RemoteBot-v0", num_envs=1)       # out of scope ids are named as such (the ZMQ robot bridge)
     h = ctypes.c_void_p()
     cfg = _lib.MwbConfig()
     cfg.abi_version, cfg.task, cfg.num_envs, cfg.obs_width, cfg.obs_height, cfg.use_default_params = 1, 3, 4, 80, 60, 1
