@@ -64,7 +64,7 @@ EXPORTS = [
     "mwb_step", "mwb_render", "mwb_get_outputs", "mwb_get_state", "mwb_set_agent", "mwb_intersect",
     "mwb_get_geometry", "mwb_timing_enable", "mwb_timing_read", "mwb_stack_enable", "mwb_stack_update", "mwb_stack_window", "mwb_check", "mwb_seed_key",
     "mwb_set_task_state", "mwb_set_domain_rand", "mwb_num_textures", "mwb_debug_wg_times", "mwb_set_state", "mwb_num_boxes", "mwb_room_words", "mwb_step_i64", "mwb_render_top_view", "mwb_visible_ents",
-    "mwb_set_mesh", "mwb_set_mesh_dims", "mwb_render_view",
+    "mwb_set_mesh", "mwb_set_mesh_dims", "mwb_render_view", "mwb_debug_counters",
 ]
 
 _lib = None
@@ -111,6 +111,7 @@ def load():
     L.mwb_set_domain_rand.argtypes = [vp, i32]
     L.mwb_num_textures.argtypes = [vp]
     L.mwb_debug_wg_times.argtypes = [vp, vp, i32]
+    L.mwb_debug_counters.argtypes = [vp, vp, i32]
     L.mwb_intersect.argtypes = [vp, i32, i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(i32)]
     L.mwb_get_geometry.argtypes = [vp, i32, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.mwb_timing_enable.argtypes = [vp, i32]

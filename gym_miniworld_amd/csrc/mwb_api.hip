@@ -222,6 +222,14 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     d.want_depth = cfg->want_depth ? 1 : 0; d.layout = cfg->layout; d.domain_rand = cfg->domain_rand ? 1 : 0;
     d.auto_reset = cfg->no_auto_reset ? 0 : 1;
     { const char *dbg = getenv("MWB_DEBUG"); d.debug_flags = dbg ? atoi(dbg) : 0; }
+    { const char *ex = getenv("MWB_EXP"); d.exp_flags = ex ? atoi(ex) : 0; }
+    d.tile_w = 0; d.tile_h = 0;
+    if (cfg->task >= MWB_TASK_PICKUPOBJS) {   // MWB_TILE=WxH (0x0: whole frames): the tile a workgroup renders in the entity tasks
+        int tw_ = 0, th_ = 0;   // default: whole frames (tiles cost 1.3 - 2.7x more in total: measured, scripts/ab_mesh_phases.py)
+        const char *tl = getenv("MWB_TILE");
+        if (tl && sscanf(tl, "%dx%d", &tw_, &th_) != 2) { tw_ = 0; th_ = 0; }
+        if (tw_ > 0 && th_ > 0) { d.tile_w = tw_ < cfg->obs_width ? tw_ : cfg->obs_width; d.tile_h = th_ < cfg->obs_height ? th_ : cfg->obs_height; }
+    }
     static const double dflt[MWB_NUM_TASKS][4] = {{12, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {8, 8, 3, 0}, {0, 0, 0, 0}, {0, 0, 0, 100}, {0, 0, 0, 0}, {0, 0, 0, 0}, {12, 0, 0, 0}, {0, 0, 0, 0},
                                                  {12, 5, 0, 0}, {10, 0, 0, 0}, {16, 0, 0, 0}, {0, 0, 0, 0}, {10, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     const bool sim2real = cfg->task == MWB_TASK_SIM2REAL_GOTO || cfg->task == MWB_TASK_SIM2REAL_PUSH;
@@ -334,6 +342,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     A(d.error_flag, (size_t)1);
 #undef A
     if (rc == MWB_OK && (d.debug_flags & 16)) rc = dev_alloc(h, &d.wg_ts, 2 * (N + (size_t)d.split_envs));
+    if (rc == MWB_OK && (d.exp_flags & 4)) rc = dev_alloc(h, &d.dbg_counters, (size_t)8);
     if (rc == MWB_OK) rc = dev_alloc(h, &d.cost, 2 * N);
     if (rc == MWB_OK) rc = dev_alloc(h, &d.bucket, N);
     if (rc == MWB_OK) rc = dev_alloc(h, &d.order_bufs[0], N);
@@ -362,7 +371,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     h->timing = false; h->timing_now = false; h->timing_period = 1; h->timing_tick = 0; h->ev_used = 0; h->ev = nullptr;
     { const char *no = getenv("MWB_NO_OVERLAP"); h->overlap_reset = !(no && atoi(no)); }
     h->side = nullptr; h->ev_fork = nullptr; h->ev_join = nullptr;
-    h->view_frame = nullptr; d.lds_geom = -1; d.lds_mesh_f4 = 0;
+    h->view_frame = nullptr;
     h->meshes_dirty = false; h->mesh_data_dev = nullptr; d.mesh_desc = h->mesh_desc_dev; d.mesh_data = nullptr;
     h->stack = nullptr; h->stack_n = 0; h->stack_dtype = 0; h->stack_bytes = 0; h->stack_planes = 0; h->stack_pos = 0; h->stack_fused = 0;
     int prio_lo = 0, prio_hi = 0;
@@ -574,16 +583,6 @@ static int upload_meshes(mwb_handle *h) {   // the caller holds the device guard
     if (!all.empty()) HIP_TRY(hipMemcpy(h->mesh_data_dev, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->mesh_desc_dev, desc, sizeof(desc), hipMemcpyHostToDevice));
     h->dev.mesh_data = h->mesh_data_dev;
-    {   // the small mesh of the task (a key, a medkit, a cone: <= 25 KB of nodes + triangle records) is walked from LDS
-        static const int prefer[MWB_NUM_TASKS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, MWB_MESH_KEY, MWB_MESH_KEY, MWB_MESH_MEDKIT, MWB_MESH_KEY, MWB_MESH_KEY, MWB_MESH_CONE, -1};
-        const int g = prefer[h->dev.task];
-        h->dev.lds_geom = -1; h->dev.lds_mesh_f4 = 0;
-        if (g >= 0 && h->meshes[g].set) {
-            const int f4 = 2 * h->meshes[g].n_nodes + 3 * h->meshes[g].n_tris;
-            if (f4 <= 1600) { h->dev.lds_geom = g; h->dev.lds_mesh_f4 = f4; }
-        }
-        if (int prc = mwb_prepare_kernels(h->dev)) return set_err(prc == -2 ? MWB_EHIP : MWB_EINVAL, "mesh staging does not fit LDS");
-    }
     h->meshes_dirty = false;
     return MWB_OK;
 }
@@ -827,6 +826,7 @@ extern "C" int mwb_stack_enable(mwb_handle *h, int nstack, int dtype) {
     if (h->stack) return set_err(MWB_ESTATE, "mwb_stack_enable: already enabled");
     // a fused window is filled by the render kernels as they produce frames: enabled after the first observation it would
     // lack the current frame until the next pass (the non-fused forms rebuild theirs from the observation buffer)
+    if (fused && h->dev.tile_w > 0) return set_err(MWB_EINVAL, "mwb_stack_enable: MWB_STACK_FUSED is not available for the tasks rendered in tiles (the mesh-entity tasks): use MWB_STACK_SLIDING");
     if (fused && h->have_obs) return set_err(MWB_ESTATE, "mwb_stack_enable: MWB_STACK_FUSED must be enabled before the first mwb_reset / mwb_step / mwb_render");
     if (fused && dtype == 0 && (d.W * d.H) % 16) return set_err(MWB_EINVAL, "mwb_stack_enable: a fused uint8 stack needs W*H to be a multiple of 16");
     USE_DEVICE(h->cfg.device);
@@ -1116,6 +1116,18 @@ extern "C" int mwb_debug_wg_times(mwb_handle *h, unsigned long long *out, int ma
     if (n > max_wgs) n = max_wgs;
     HIP_TRY(hipMemcpy(out, h->dev.wg_ts, (size_t)n * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return n;
+}
+
+/* timing experiments (MWB_EXP bit 2 at mwb_create): the entity render kernel's mesh-walk counters since the last call with
+ * reset != 0: sample rays entering the walk, walks started, node visits, triangle tests, wave loop iterations, wave calls */
+extern "C" int mwb_debug_counters(mwb_handle *h, unsigned long long *out8, int reset) {
+    if (!h || !out8) return set_err(MWB_EINVAL, "mwb_debug_counters: null argument");
+    if (!h->dev.dbg_counters) return set_err(MWB_ESTATE, "mwb_debug_counters: create the handle with MWB_EXP bit 2 set");
+    USE_DEVICE(h->cfg.device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out8, h->dev.dbg_counters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(h->dev.dbg_counters, 0, 8 * sizeof(unsigned long long)));
+    return MWB_OK;
 }
 
 extern "C" int mwb_set_domain_rand(mwb_handle *h, int domain_rand) {

@@ -206,7 +206,9 @@ struct MwbDev {
     const float4 *mesh_data;
     MwbMeshDims mesh_dims[MWB_MAX_MESH_DIMS];
     int n_mesh_dims;
-    int lds_geom, lds_mesh_f4;   // the task's small mesh geometry the render kernel stages in LDS (-1 none) and its size in float4
+    int tile_w, tile_h;   // entity tasks: every frame is rendered as tiles of this size, one workgroup each (0: whole frames)
+    unsigned long long *dbg_counters;   // [8] or null: walk_meshes counters (MWB_EXP bit 2)
+    int exp_flags;   // MWB_EXP env var at mwb_create: bit 0 = meshes are never hit, bit 1 = flat grey mesh shading (timing experiments)
 };
 
 // launch wrappers implemented in mwb_kernels.hip

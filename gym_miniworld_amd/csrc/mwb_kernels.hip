@@ -2036,6 +2036,9 @@ __device__ __forceinline__ int trace_box(const float *fc, const float *dv, float
 }
 
 // ---- mesh entities and frames (entity tasks; DESIGN.md 5, "meshes" / "frames": the written arithmetic) -------------------------
+#ifndef ENT_WGS_PER_CU
+#define ENT_WGS_PER_CU 4   // the entity kernels' residency target: 128 VGPRs (5 workgroups at 96 VGPRs spill 656 B/lane and run no faster)
+#endif
 #define KIND_MESH 5u
 #define KIND_FRAME 6u
 __device__ __forceinline__ float dot3f(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
@@ -2065,57 +2068,7 @@ __device__ __forceinline__ bool mesh_tri(const float *lo, const float *ld, const
 }
 // nearest front-facing triangle of the entity's mesh along (eye, dv) that is strictly nearer than t_max: its index in draw order
 // or -1.  Threaded BVH (host-built, gym_miniworld_amd/meshes.py): depth-first node order, `skip` links, no stack.
-typedef float f4n __attribute__((ext_vector_type(4)));   // a plain vector type: loadable through an address-space-qualified pointer
-typedef __attribute__((address_space(3))) const f4n lds_f4;
-template <typename P4>
-__device__ __forceinline__ int walk_mesh_bvh(P4 *nodes, P4 *tris, const int n_nodes, const float *lo, const float *ld, float t_max, float &t_out) {
-    const float ix = 1.0f / ld[0], iy = 1.0f / ld[1], iz = 1.0f / ld[2];
-    int node = 0, best = -1;
-    float bt = t_max;
-    while (node < n_nodes) {
-        const f4n a = nodes[2 * node], b = nodes[2 * node + 1];
-        float t0 = (a.x - lo[0]) * ix, t1 = (b.x - lo[0]) * ix;
-        float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-        t0 = (a.y - lo[1]) * iy; t1 = (b.y - lo[1]) * iy;
-        tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-        t0 = (a.z - lo[2]) * iz; t1 = (b.z - lo[2]) * iz;
-        tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-        const uint32_t fcnt = (uint32_t)__float_as_int(b.w);
-        if (!(tn <= tf && tf > 0.0f && tn <= bt)) { node = __float_as_int(a.w); continue; }   // boxes are padded: never rejects a real hit
-        const int cnt = (int)(fcnt >> 24);
-        if (cnt == 0) { node++; continue; }
-        const int first = (int)(fcnt & 0xFFFFFFu);
-        for (int k = 0; k < cnt; k++) {
-            const f4n q0 = tris[3 * (first + k)], q1 = tris[3 * (first + k) + 1], q2 = tris[3 * (first + k) + 2];
-            const float4 r0 = make_float4(q0.x, q0.y, q0.z, q0.w), r1 = make_float4(q1.x, q1.y, q1.z, q1.w), r2 = make_float4(q2.x, q2.y, q2.z, q2.w);
-            float t, u, v, det;
-            if (mesh_tri(lo, ld, r0, r1, r2, true, t, u, v, det)) {
-                const int idx = __float_as_int(r2.y);
-                if (t < bt || (t == bt && best >= 0 && idx < best)) { bt = t; best = idx; }   // ties: the first triangle drawn
-            }
-        }
-        node = __float_as_int(a.w);
-    }
-    t_out = bt;
-    return best;
-}
-// lds_geom: the geometry whose nodes + leaf-order triangle records this workgroup has staged in LDS at lds_mesh (-1 none): its walk
-// reads LDS (~100 cycles per dependent step instead of an L2 round trip)
-__device__ __forceinline__ int trace_mesh_bvh(const float *blk, const MwbMeshDesc *__restrict__ descs, const float4 *__restrict__ data,
-                                              const float *dv, float t_max, float &t_out, int lds_geom, const float4 *lds_mesh) {
-    float ld[3];
-    mesh_local_dir(blk, dv, ld);
-    const float lo[3] = {blk[FC_BOX_LO], blk[FC_BOX_LO + 1], blk[FC_BOX_LO + 2]};
-    const int geom = __builtin_amdgcn_readfirstlane(__float_as_int(blk[FC_LIT_BOX + FE_MESH_GEOM]));
-    const MwbMeshDesc &md = descs[geom];
-    const int n_nodes = md.n_nodes;
-    if (geom == lds_geom) {
-        lds_f4 *base = (lds_f4 *)lds_mesh;
-        return walk_mesh_bvh<lds_f4>(base, base + 2 * n_nodes, n_nodes, lo, ld, t_max, t_out);
-    }
-    const f4n *gd = (const f4n *)data;
-    return walk_mesh_bvh<const f4n>(gd + md.node_off, gd + md.tri_off, n_nodes, lo, ld, t_max, t_out);
-}
+typedef float f4n __attribute__((ext_vector_type(4)));   // a plain 16-byte vector for the mesh records (walk_meshes)
 // ImageFrame / TextFrame: slab [0, depth] x [-h/2, h/2] x [-w/2, w/2] in the frame's axes; returns the character cell of the
 // front (+x) face, 100 for a black side, -1 for a miss or the missing back
 __device__ __forceinline__ int trace_frame(const float *blk, const float *dv, float &t_out) {
@@ -2249,8 +2202,9 @@ struct RenderCtx {
     bool boxes_in_view;   // workgroup-uniform (scalar): false = no ray of this frame can touch a box
     const MwbMeshDesc *mesh_desc;   // entity tasks: mesh geometries in HBM (L2 resident), or null
     const float4 *mesh_data;
-    int lds_geom;                   // geometry staged in LDS for this frame (-1 none) ...
-    const float4 *lds_mesh;         // ... its nodes, then its triangle records in leaf order
+    int exp_flags;                  // MWB_EXP experiment switches (timing experiments only)
+    uint32_t mesh_slots;            // bit b: entity slot b is a mesh in this frame (workgroup-uniform)
+    unsigned long long *dbg_counters;   // MWB_EXP bit 2: [0] sample rays in walk_meshes, [1] walks, [2] node visits, [3] triangle tests, [4] wave loop iterations, [5] wave calls
     // per work item (15 x 15 pixels), which boxes can touch any of its rays at all (frame-level pre-test pass; null = unknown)
     const uint4 *item_res;
     int part_h_inv;       // ceil(65536 / rows per item): row -> quarter without a division
@@ -2345,11 +2299,88 @@ struct RenderCtx {
 
     // INTERIOR: the caller guarantees a room surface (floor / ceiling / wall) whose plane the pixel's centre ray meets
     // in front of the eye (the four corner rays of the pixel do): no sky / box cases, no fallback to a sample's ray.
+    // Every mesh entity whose gate sphere the ray (eye, dv) passes, walked by this lane on its own: ONE loop in which a lane either
+    // visits the next node of the mesh it is in or moves on to its next candidate - so a wave's time is its slowest lane's own
+    // work, not the sum over all the meshes any of its 64 pixels touches (a wave-uniform loop over the entities cost 5-15x more:
+    // scripts/ab_mesh_phases.py).  cand: the lane's candidate slots; th / key: the nearest surface so far, updated.  Slot order
+    // among meshes is kept (a later mesh wins only when strictly nearer; within a mesh the first triangle drawn wins a tie).
+    __device__ __forceinline__ void walk_meshes(uint32_t cand, const float *dv, float dd, float &th, uint32_t &key) const {
+        const f4n *gd = (const f4n *)mesh_data;
+        const f4n *nodes = gd, *tris = gd;
+        float lo[3] = {0, 0, 0}, ld[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+        int node = 0, n_nodes = 0, bi = 0, best = -1;
+        int leaf_first = 0, leaf_cnt = 0;   // a leaf this lane has reached and not yet tested
+        unsigned c_walks = 0, c_visits = 0, c_tris = 0, c_iters = 0;   // MWB_EXP bit 2: counters (timing experiments only)
+        for (;;) {
+            // phase 1 (node steps only - the loop body a wave repeats most often stays short): every lane moves on, through its
+            // candidates' hierarchies, until it stands at a leaf or has nothing left
+            while (leaf_cnt == 0 && (node < n_nodes || cand)) {
+                c_iters++;
+                if (node >= n_nodes) {   // this lane's next candidate
+                    bi = __builtin_ctz(cand);
+                    cand &= cand - 1u;
+                    best = -1;
+                    const float *blk = fc + bi * FC_BOX_STRIDE;
+                    const float cc = blk[FC_CULL_CC];
+                    const float b = dv[0] * blk[FC_CULL_OC] + dv[1] * blk[FC_CULL_OC + 1] + dv[2] * blk[FC_CULL_OC + 2];
+                    node = n_nodes = 0;
+                    if (!(cc <= 0.0f || (b > 0.0f && b * b >= dd * cc))) continue;
+                    mesh_local_dir(blk, dv, ld);
+                    lo[0] = blk[FC_BOX_LO]; lo[1] = blk[FC_BOX_LO + 1]; lo[2] = blk[FC_BOX_LO + 2];
+                    // the node boxes are padded by 1e-4 of the mesh (host): a 1-ulp reciprocal cannot lose a real hit
+                    inv[0] = __builtin_amdgcn_rcpf(ld[0]); inv[1] = __builtin_amdgcn_rcpf(ld[1]); inv[2] = __builtin_amdgcn_rcpf(ld[2]);
+                    const int geom = __float_as_int(blk[FC_LIT_BOX + FE_MESH_GEOM]);
+                    const MwbMeshDesc &md = mesh_desc[geom];
+                    nodes = gd + md.node_off; tris = gd + md.tri_off; n_nodes = md.n_nodes;
+                    c_walks++;
+                    continue;
+                }
+                c_visits++;
+                const f4n a = nodes[2 * node], bb = nodes[2 * node + 1];
+                float t0 = (a.x - lo[0]) * inv[0], t1 = (bb.x - lo[0]) * inv[0];
+                float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+                t0 = (a.y - lo[1]) * inv[1]; t1 = (bb.y - lo[1]) * inv[1];
+                tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                t0 = (a.z - lo[2]) * inv[2]; t1 = (bb.z - lo[2]) * inv[2];
+                tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                const uint32_t fcnt = (uint32_t)__float_as_int(bb.w);
+                const bool hit = tn <= tf * 1.00001f && tf > 0.0f && tn <= th;
+                const int cnt = (int)(fcnt >> 24);
+                node = (hit && cnt == 0) ? node + 1 : __float_as_int(a.w);   // into the first child, or on past this subtree / leaf
+                if (hit && cnt) { leaf_first = (int)(fcnt & 0xFFFFFFu); leaf_cnt = cnt; }
+            }
+            if (!__any(leaf_cnt != 0)) break;
+            // phase 2: the lanes that stand at a leaf test its triangles (spec arithmetic: correctly rounded t)
+            for (int q = 0; q < leaf_cnt; q++) {
+                const f4n q0 = tris[3 * (leaf_first + q)], q1 = tris[3 * (leaf_first + q) + 1], q2 = tris[3 * (leaf_first + q) + 2];
+                const float4 r0 = make_float4(q0.x, q0.y, q0.z, q0.w), r1 = make_float4(q1.x, q1.y, q1.z, q1.w), r2 = make_float4(q2.x, q2.y, q2.z, q2.w);
+                float t, u, v, det;
+                c_tris++;
+                if (mesh_tri(lo, ld, r0, r1, r2, true, t, u, v, det)) {
+                    const int idx = __float_as_int(r2.y);
+                    if (t < th || (t == th && best >= 0 && idx < best)) {
+                        th = t; best = idx;
+                        key = KIND_MESH | ((uint32_t)bi << 3) | ((uint32_t)idx << 8);
+                    }
+                }
+            }
+            leaf_cnt = 0;
+        }
+        if ((exp_flags & 4) && dbg_counters) {
+            atomicAdd(dbg_counters + 0, 1ull); atomicAdd(dbg_counters + 1, (unsigned long long)c_walks); atomicAdd(dbg_counters + 2, (unsigned long long)c_visits);
+            atomicAdd(dbg_counters + 3, (unsigned long long)c_tris);
+            unsigned mx = c_iters;   // the wave's loop count = its slowest lane's
+            for (int o = 32; o; o >>= 1) { const unsigned v = __shfl_xor(mx, o); mx = v > mx ? v : mx; }
+            if ((threadIdx.x & 63) == 0) { atomicAdd(dbg_counters + 4, (unsigned long long)mx); atomicAdd(dbg_counters + 5, 1ull); }
+        }
+    }
+
     // One shade per (pixel, triangle) with the attributes evaluated at the PIXEL CENTRE (extrapolated, as a multisampling
     // rasteriser without centroid sampling does): per-vertex fixed-function lighting with the normal R n / scale (not
     // renormalised: GL_NORMALIZE is off), clamped to 1, interpolated with the centre ray's barycentrics; where the centre ray sees
     // the triangle's back or edge, the covering sample's ray instead; a textured mesh modulates by its image.
     __device__ __noinline__ void shade_mesh(uint32_t key, int first_k, float cx, float cy, float *col) const {
+        if (exp_flags & 2) { col[0] = 0.5f; col[1] = 0.5f; col[2] = 0.5f; return; }   // experiment: flat grey meshes
         const int bi = (int)((key >> 3) & 31u), tri = (int)(key >> 8);
         const float *blk = fc + bi * FC_BOX_STRIDE;
         const float *me = blk + FC_LIT_BOX;
@@ -2578,7 +2609,7 @@ struct RenderCtx {
                 }
             } else {
 #pragma unroll 1
-                for (uint32_t bm = any_boxes; bm; bm &= bm - 1u) {   // a real loop: one copy of the slab test, constants from LDS
+                for (uint32_t bm = NBOX > MWB_MAX_BOXES ? any_boxes & ~mesh_slots : any_boxes; bm; bm &= bm - 1u) {   // a real loop: one copy of the slab test, constants from LDS
                     const int bi = __builtin_ctz(bm);                 // (entity order kept: a later box wins only when strictly nearer)
                     const float *fb_ = fc + bi * FC_BOX_STRIDE;
                     const float cc = fb_[FC_CULL_CC];
@@ -2590,9 +2621,7 @@ struct RenderCtx {
                             const float hxk = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb_[FC_BOX_HX])));
                             ekind = hxk == -1.0f ? 1 : hxk == -2.0f ? 2 : 0;
                         }
-                        if (ekind == 1) {
-                            const int tri = trace_mesh_bvh(fb_, mesh_desc, mesh_data, dv, th, tb, lds_geom, lds_mesh);
-                            if (tri >= 0) { key = KIND_MESH | ((uint32_t)bi << 3) | ((uint32_t)tri << 8); th = tb; }
+                        if (ekind == 1) {   // meshes: walked below, every lane through ITS OWN candidates at the same time
                         } else if (ekind == 2) {
                             const int code = trace_frame(fb_, dv, tb);
                             if (code >= 0 && tb < th) { key = KIND_FRAME | ((uint32_t)bi << 3) | ((uint32_t)code << 8); th = tb; }
@@ -2601,6 +2630,9 @@ struct RenderCtx {
                             if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, bi); th = tb; }
                         }
                     }
+                }
+                if constexpr (NBOX > MWB_MAX_BOXES) {
+                    if (!(exp_flags & 1)) walk_meshes(my_boxes & mesh_slots, dv, dd, th, key);
                 }
             }
             if (k == 0) { key_s0 = key; t_s0 = th; }
@@ -2715,7 +2747,9 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     uint16_t *ipix = (uint16_t *)(smem + off); off += (THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t);
     uint4 *item_res = (uint4 *)(smem + off); off += (size_t)ITEM_RES_BYTES(W);   // per work item: uniform rows + their key
     uint8_t *fb = smem + off;   // the frame is assembled in LDS and leaves as 16-byte coalesced stores
-    float4 *mesh_lds = (float4 *)(smem + ((off + (size_t)W * H * 3 + 15) & ~(size_t)15));   // entity tasks: a small mesh's BVH (d.lds_mesh_f4 float4)
+    // entity tasks: a third queue per wave for the 8-sample pixels a mesh may cover, and its leftover counts (behind the frame)
+    uint16_t *mqueues = (uint16_t *)(smem + ((off + (size_t)W * H * 3 + 15) & ~(size_t)15));
+    int *mleft = (int *)(mqueues + (THREADS / WAVE) * QUEUE_CAP);
 
     {   // stage the room table, the frame constants and the texture descriptors
         const int rw = POLY ? MWB_POLY_ROOM_WORDS : MWB_ROOM_WORDS;
@@ -2733,25 +2767,11 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     RenderCtx<NBOX, POLY> ctx;
     ctx.rooms = rooms; ctx.fc = fc; ctx.tex = tex; ctx.texels = d.texels; ctx.fb = fb;
     ctx.mesh_desc = d.mesh_desc; ctx.mesh_data = d.mesh_data;
-    ctx.lds_geom = -1; ctx.lds_mesh = mesh_lds;
-    if constexpr (NBOX > MWB_MAX_BOXES) {
-        // the task's small mesh (key / medkit / cone: d.lds_geom) moves into LDS for this frame if an entity made of it can be seen at all
-        if (d.lds_geom >= 0) {
-            bool wanted = false;
-            for (int bi = 0; bi < d.n_boxes; bi++) {
-                const float *fb_ = fc + bi * FC_BOX_STRIDE;
-                wanted = wanted || (fb_[FC_BOX_HX] == -1.0f && __float_as_int(fb_[FC_LIT_BOX + FE_MESH_GEOM]) == d.lds_geom && fb_[FC_BOX_HZ] != 0.0f);
-            }
-            if (__builtin_amdgcn_readfirstlane((int)wanted)) {
-                const MwbMeshDesc &md = d.mesh_desc[d.lds_geom];
-                const float4 *srcn = d.mesh_data + md.node_off, *srct = d.mesh_data + md.tri_off;
-                const int nn = 2 * md.n_nodes, nt = 3 * md.n_tris;
-                for (int i = tid; i < nn; i += THREADS) mesh_lds[i] = srcn[i];
-                for (int i = tid; i < nt; i += THREADS) mesh_lds[nn + i] = srct[i];
-                ctx.lds_geom = d.lds_geom;
-                __syncthreads();
-            }
-        }
+    ctx.exp_flags = d.exp_flags; ctx.mesh_slots = 0; ctx.dbg_counters = d.dbg_counters;
+    if constexpr (NBOX > MWB_MAX_BOXES) {   // which slots hold a mesh in this frame
+        uint32_t ms = 0;
+        for (int bi = 0; bi < d.n_boxes; bi++) ms |= fc[bi * FC_BOX_STRIDE + FC_BOX_HX] == -1.0f ? 1u << bi : 0u;
+        ctx.mesh_slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)ms);
     }
     ctx.depth = d.want_depth ? d.depth + (size_t)e * d.W * d.H + (TILED ? (size_t)ty0 * d.W + tx0 : 0) : nullptr;
     ctx.depth_stride = TILED ? d.W : W;
@@ -2824,6 +2844,8 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     uint32_t *iq_key = ikeys + wave * QUEUE_CAP;
     uint16_t *iq_pix = ipix + wave * QUEUE_CAP;
     int q_count = 0, iq_count = 0;   // wave-uniform
+    uint16_t *mqueue = mqueues + wave * QUEUE_CAP;
+    int mq_count = 0;
     const int ci = lane & (TILE_CX - 1), cj = lane / TILE_CX;
     const int n_strips = (W + TILE_CX - 2) / (TILE_CX - 1);
     // Work items = (strip, quarter of the rows): 24 at 80 x 60, 15 x 15 pixels each (16 corner rows = 4 passes,
@@ -2836,29 +2858,6 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
                                  : (split_x ? (part == 0 ? half_strips : n_strips - half_strips) * 4 : n_strips * 2);
     (void)n_waves;
 
-    // a classified pixel goes to its per-wave queue; a queue that reaches 64 entries is processed at once (dense lanes)
-    auto emit = [&](int px, int py, bool is_pixel, bool interior, uint32_t key, int skip) {
-        const bool edge = is_pixel && !interior;
-        const unsigned long long em = __ballot(edge);
-        if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)((skip << qshift) | (py << wshift) | px);
-        q_count += __popcll(em);
-        const unsigned long long im = __ballot(interior);
-        if (interior) {
-            const int slot = iq_count + __popcll(im & ((1ull << lane) - 1ull));
-            iq_key[slot] = key & 0x0FFFFFFFu; iq_pix[slot] = (uint16_t)((py << wshift) | px);
-        }
-        iq_count += __popcll(im);
-        if (iq_count >= WAVE) {
-            iq_count -= WAVE;
-            const int q = iq_pix[iq_count + lane];
-            if (!(d.debug_flags & 4)) ctx.pixel_interior(q & wmask, q >> wshift, iq_key[iq_count + lane]);
-        }
-        if (q_count >= WAVE) {
-            q_count -= WAVE;
-            const int q = queue[q_count + lane];
-            if (!(d.debug_flags & 2)) ctx.pixel_full(q & wmask, (q >> wshift) & hmask, q >> qshift);
-        }
-    };
     // may a box intrude into an otherwise uniform pixel?  centre ray against the footprint-inflated bounding spheres
     auto box_may_touch = [&](int px, int py, uint32_t boxes /* wave-uniform: the item's */) {
         if (NBOX > 1 && !boxes) return false;
@@ -2901,6 +2900,43 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         return touch;
     };
 
+    // a classified pixel goes to its per-wave queue; a queue that reaches 64 entries is processed at once (dense lanes)
+    auto emit = [&](int px, int py, bool is_pixel, bool interior, uint32_t key, int skip, uint32_t iboxes) {
+        bool edge = is_pixel && !interior;
+        if constexpr (NBOX > MWB_MAX_BOXES) {
+            // 8-sample pixels that a mesh may cover queue up apart: their batches walk mesh hierarchies with most lanes busy, while
+            // the other batches never wait for a few lanes' walks (mixed, ~1 lane in 8 was walking: scripts/ab_mesh_phases.py)
+            const bool mesh_px = edge && ctx.boxes_in_view && (iboxes & ctx.mesh_slots) && box_may_touch(px, py, iboxes & ctx.mesh_slots);
+            const unsigned long long mm = __ballot(mesh_px);
+            if (mesh_px) mqueue[mq_count + __popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)((skip << qshift) | (py << wshift) | px);
+            mq_count += __popcll(mm);
+            edge = edge && !mesh_px;
+            if (mq_count >= WAVE) {
+                mq_count -= WAVE;
+                const int q = mqueue[mq_count + lane];
+                if (!(d.debug_flags & 2)) ctx.pixel_full(q & wmask, (q >> wshift) & hmask, q >> qshift);
+            }
+        }
+        const unsigned long long em = __ballot(edge);
+        if (edge) queue[q_count + __popcll(em & ((1ull << lane) - 1ull))] = (uint16_t)((skip << qshift) | (py << wshift) | px);
+        q_count += __popcll(em);
+        const unsigned long long im = __ballot(interior);
+        if (interior) {
+            const int slot = iq_count + __popcll(im & ((1ull << lane) - 1ull));
+            iq_key[slot] = key & 0x0FFFFFFFu; iq_pix[slot] = (uint16_t)((py << wshift) | px);
+        }
+        iq_count += __popcll(im);
+        if (iq_count >= WAVE) {
+            iq_count -= WAVE;
+            const int q = iq_pix[iq_count + lane];
+            if (!(d.debug_flags & 4)) ctx.pixel_interior(q & wmask, q >> wshift, iq_key[iq_count + lane]);
+        }
+        if (q_count >= WAVE) {
+            q_count -= WAVE;
+            const int q = queue[q_count + lane];
+            if (!(d.debug_flags & 2)) ctx.pixel_full(q & wmask, (q >> wshift) & hmask, q >> qshift);
+        }
+    };
     // Item pre-tests, all at once.  If the corner rays of a screen rectangle reach the same convex piece of a room surface
     // through the same portals, so does every ray in between (the argument made for a pixel holds for any rectangle): all
     // its pixels are interior pixels of that surface.  Tested for every 15 x 15 item and for its upper / lower 8 rows: the
@@ -3036,7 +3072,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
                 const bool is_pixel = col < wi && py < row0 + ur1;
                 bool interior = is_pixel;
                 if (interior && ctx.boxes_in_view && box_may_touch(px, py, item_boxes)) interior = false;
-                emit(px, py, is_pixel, interior, ukey, 0);
+                emit(px, py, is_pixel, interior, ukey, 0, item_boxes);
             }
             if (prows <= 0) continue;
         }
@@ -3069,7 +3105,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             if (interior && ctx.boxes_in_view && box_may_touch(px, py, item_boxes)) interior = false;
             int skip = common_crossings4(path, p_br, p_tl, p_tr) + item_skip;
             skip = skip < skip_max ? skip : skip_max;
-            emit(px, py, is_pixel, interior, key, skip);
+            emit(px, py, is_pixel, interior, key, skip, item_boxes);
         }
     }
     // Leftovers (< 64 per wave and queue): pooled over the workgroup and dealt out again in full batches - interior
@@ -3077,6 +3113,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     // running two partly filled batches.
     int *left = cam_room_s + 4;
     if (lane == 0) { left[wave] = iq_count; left[n_waves + wave] = q_count; }
+    if constexpr (NBOX > MWB_MAX_BOXES) { if (lane == 0) mleft[wave] = mq_count; }
     __syncthreads();
     if (!(d.debug_flags & 4)) {
         int g = tid, owner = -1;
@@ -3102,15 +3139,37 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             ctx.pixel_full(q & wmask, (q >> wshift) & hmask, q >> qshift);
         }
     }
+    if constexpr (NBOX > MWB_MAX_BOXES) {
+        if (!(d.debug_flags & 2)) {   // the mesh pixels left over, pooled the same way
+            int g = tid, owner = -1;
+#pragma unroll
+            for (int w = 0; w < THREADS / WAVE; w++) {
+                const int c = mleft[w];
+                if (owner < 0) { if (g < c) owner = w; else g -= c; }
+            }
+            if (owner >= 0) {
+                const int q = mqueues[owner * QUEUE_CAP + g];
+                ctx.pixel_full(q & wmask, (q >> wshift) & hmask, q >> qshift);
+            }
+        }
+    }
     __syncthreads();
     {   // framebuffer LDS -> HBM, 16 bytes per lane where the alignment allows
         const int nbytes = W * H * 3;
         uint8_t *dst = d.obs + (size_t)e * nbytes;
-        if (TILED) {   // the tile's rows into the big HWC frame
-            uint8_t *big = d.obs + ((size_t)e * d.W * d.H + (size_t)ty0 * d.W + tx0) * 3;
-            for (int i = tid; i < H * W * 3; i += THREADS) {
-                const int row = i / (W * 3), col = i - row * (W * 3);
-                big[(size_t)row * d.W * 3 + col] = fb[i];
+        if (TILED) {
+            if (d.layout == MWB_LAYOUT_HWC) {   // the tile's rows into the big frame
+                uint8_t *big = d.obs + ((size_t)e * d.W * d.H + (size_t)ty0 * d.W + tx0) * 3;
+                for (int i = tid; i < H * W * 3; i += THREADS) {
+                    const int row = i / (W * 3), col = i - row * (W * 3);
+                    big[(size_t)row * d.W * 3 + col] = fb[i];
+                }
+            } else {   // CWH: the tile is [3][W][H] in LDS, its columns go into the planes [3][d.W][d.H]
+                uint8_t *big = d.obs + (size_t)e * d.W * d.H * 3;
+                for (int i = tid; i < H * W * 3; i += THREADS) {
+                    const int q = i / (W * H), r = i - q * (W * H), x = r / H, y = r - x * H;
+                    big[((size_t)q * d.W + tx0 + x) * d.H + ty0 + y] = fb[i];
+                }
             }
         } else if (part < 0) {
             copy_frame_range<THREADS>(dst, fb, 0, nbytes, tid);
@@ -3163,7 +3222,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
 // in profiles.
 // NBOX = MWB_MAX_ENTS: the entity tasks' instantiation (mesh BVH walks, frames): 4 workgroups per CU (128 VGPRs) instead of 5
 template <int THREADS, int MODE, int NBOX, bool POLY = false>
-__global__ void __launch_bounds__(THREADS, NBOX > MWB_MAX_BOXES ? 4 : 5) render_kernel(MwbDev d) {
+__global__ void __launch_bounds__(THREADS, NBOX > MWB_MAX_BOXES ? ENT_WGS_PER_CU : 5) render_kernel(MwbDev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (MODE == 1) {
         __builtin_amdgcn_s_setprio(3);   // the few regenerated envs, beside the bulk render (see reset_kernel)
@@ -3197,16 +3256,32 @@ __global__ void __launch_bounds__(THREADS, NBOX > MWB_MAX_BOXES ? 4 : 5) render_
 
 // The agent's view at any size (mwb_render_view): a grid of tiles per env, one workgroup each.  d.W x d.H is the view's size, d.obs /
 // d.depth / d.frame the caller's frame, the optional depth map and the frame constants prepared for that size.
-#define VIEW_TILE_W 75   // 5 strips of 15 pixels
+// MODE 0: every env; 1: the regenerated envs (compact list, grid-stride); 2: all the others.  The entity tasks render EVERY frame
+// this way (MWB_TILE, default 40 x 30: four workgroups per frame): a close-up of a 5 000-triangle ball makes one frame cost fifty
+// times the average, and a launch is as slow as its slowest workgroup (measured: 0.7 waves per SIMD resident on average).
+#define VIEW_TILE_W 75   // mwb_render_view: 5 strips of 15 pixels
 #define VIEW_TILE_H 60
-template <int THREADS, int NBOX, bool POLY>
-__global__ void __launch_bounds__(THREADS, NBOX > MWB_MAX_BOXES ? 4 : 5) render_view_kernel(MwbDev d, int tiles_x, int tiles_y) {
+template <int THREADS, int MODE, int NBOX, bool POLY>
+__global__ void __launch_bounds__(THREADS, NBOX > MWB_MAX_BOXES ? ENT_WGS_PER_CU : 5) render_view_kernel(MwbDev d, int tiles_x, int tiles_y, int tile_w, int tile_h) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int per_env = tiles_x * tiles_y;
+    if (MODE == 1) {
+        __builtin_amdgcn_s_setprio(3);
+        const int total = d.reset_count[0] * per_env;
+        for (int w = blockIdx.x; w < total; w += gridDim.x) {
+            const int li = w / per_env, t = w - li * per_env;
+            const int ty = t / tiles_x, tx = t - ty * tiles_x;
+            const int tx0 = tx * tile_w, ty0 = ty * tile_h;
+            render_env<THREADS, NBOX, true, POLY, true>(d, d.reset_list[li], -1, smem, tx0, ty0, d.W - tx0 < tile_w ? d.W - tx0 : tile_w, d.H - ty0 < tile_h ? d.H - ty0 : tile_h);
+            __syncthreads();
+        }
+        return;
+    }
     const int e = blockIdx.x / per_env, t = blockIdx.x - e * per_env;
+    if (MODE == 2 && d.reset_set[e]) return;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
-    const int tx0 = tx * VIEW_TILE_W, ty0 = ty * VIEW_TILE_H;
-    const int tw = d.W - tx0 < VIEW_TILE_W ? d.W - tx0 : VIEW_TILE_W, th = d.H - ty0 < VIEW_TILE_H ? d.H - ty0 : VIEW_TILE_H;
+    const int tx0 = tx * tile_w, ty0 = ty * tile_h;
+    const int tw = d.W - tx0 < tile_w ? d.W - tx0 : tile_w, th = d.H - ty0 < tile_h ? d.H - ty0 : tile_h;
     render_env<THREADS, NBOX, false, POLY, true>(d, e, -1, smem, tx0, ty0, tw, th);
 }
 
@@ -3344,19 +3419,23 @@ static size_t render_lds_bytes_for(const MwbDev &d, int W, int H) {
     size_t b = (((size_t)d.R_max * d.room_words * 4 + 15) & ~(size_t)15) + (size_t)d.frame_words * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
                (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)ITEM_RES_BYTES(W) + (size_t)W * H * 3;
     b = (b + 15) & ~(size_t)15;
-    if (d.ent_task) b += (size_t)d.lds_mesh_f4 * 16;   // a small mesh's BVH + triangle records, staged per frame
+    if (d.ent_task) b += (RENDER_THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t) + 16;   // the mesh-pixel queues and their leftover counts
     return (b + 15) & ~(size_t)15;
 }
 // d: the handle's MwbDev with W / H / obs / depth / frame / want_depth / layout set for the view
-int mwb_launch_render_view(const MwbDev &d, hipStream_t s) {
-    const int tiles_x = (d.W + VIEW_TILE_W - 1) / VIEW_TILE_W, tiles_y = (d.H + VIEW_TILE_H - 1) / VIEW_TILE_H;
-    const size_t lds = render_lds_bytes_for(d, VIEW_TILE_W, VIEW_TILE_H);
+#define LIST_GRID 1280   // blocks that walk the compact list of regenerated envs: a handful per step - but ALL of them in the step at
+                        // which a whole batch hits the episode limit together (a block with nothing to do exits at once)
+template <int MODE>
+static int launch_tiles(const MwbDev &d, int tile_w, int tile_h, hipStream_t s) {
+    const int tiles_x = (d.W + tile_w - 1) / tile_w, tiles_y = (d.H + tile_h - 1) / tile_h;
+    const size_t lds = render_lds_bytes_for(d, tile_w, tile_h);
     if (lds > 160 * 1024) return -1;
-    const dim3 g((unsigned)((size_t)d.N * tiles_x * tiles_y)), b(RENDER_THREADS);
+    const size_t blocks = MODE == 1 ? (size_t)(d.N < LIST_GRID ? d.N : LIST_GRID) * tiles_x * tiles_y : (size_t)d.N * tiles_x * tiles_y;
+    const dim3 g((unsigned)blocks), b(RENDER_THREADS);
 #define RV(NB, PL)                                                                                                                 \
     do {                                                                                                                           \
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)render_view_kernel<RENDER_THREADS, NB, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2; \
-        render_view_kernel<RENDER_THREADS, NB, PL><<<g, b, lds, s>>>(d, tiles_x, tiles_y);                                         \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void *)render_view_kernel<RENDER_THREADS, MODE, NB, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2; \
+        render_view_kernel<RENDER_THREADS, MODE, NB, PL><<<g, b, lds, s>>>(d, tiles_x, tiles_y, tile_w, tile_h);                   \
     } while (0)
     if (d.ent_task) RV(MWB_MAX_ENTS, false);
     else if (d.poly) RV(1, true);
@@ -3366,6 +3445,7 @@ int mwb_launch_render_view(const MwbDev &d, hipStream_t s) {
 #undef RV
     return 0;
 }
+int mwb_launch_render_view(const MwbDev &d, hipStream_t s) { return launch_tiles<0>(d, VIEW_TILE_W, VIEW_TILE_H, s); }
 
 size_t mwb_render_lds_bytes(const MwbDev &d) {
     if (d.ent_task) return render_lds_bytes_for(d, d.W, d.H);
@@ -3412,8 +3492,6 @@ int mwb_prepare_kernels(const MwbDev &d) {
     return 0;
 }
 
-#define LIST_GRID 1280   // blocks that walk the compact list of regenerated envs: a handful per step - but ALL of them in the step at
-                        // which a whole batch hits the episode limit together (a block with nothing to do exits at once)
 static reset_fn_t reset_fn(int task) {
     switch (task) {
 #define RK(t) case t: return reset_kernel<t>;
@@ -3435,6 +3513,12 @@ void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
     const dim3 g(d.N + d.split_envs), b(RENDER_THREADS);
     const size_t lds = mwb_render_lds_bytes(d);
     const dim3 gl(d.N < LIST_GRID ? d.N : LIST_GRID);
+    if (d.ent_task && d.tile_w > 0) {   // every frame as a few tiles, one workgroup each (see render_view_kernel)
+        if (mode == 1) (void)launch_tiles<1>(d, d.tile_w, d.tile_h, s);
+        else if (mode == 2) (void)launch_tiles<2>(d, d.tile_w, d.tile_h, s);
+        else (void)launch_tiles<0>(d, d.tile_w, d.tile_h, s);
+        return;
+    }
     if (d.ent_task) {   // the general entity list: boxes, meshes, frames in up to MWB_MAX_ENTS slots
         if (mode == 1) render_kernel<RENDER_THREADS, 1, MWB_MAX_ENTS><<<gl, b, lds, s>>>(d);
         else if (mode == 2) render_kernel<RENDER_THREADS, 2, MWB_MAX_ENTS><<<g, b, lds, s>>>(d);

@@ -143,7 +143,7 @@ class MiniWorldVecEnv(VecEnv):
             # fused in the library: the render kernels write each new frame (uint8 -> float on the way out of LDS) into a
             # sliding window of planes and zero the history of the envs they regenerate: no stack pass at all (a replayed
             # graph would freeze the host-side window position: the shifting stack there)
-            fuse = not graph and (to_float or (b.W * b.H) % 16 == 0)
+            fuse = not graph and (to_float or (b.W * b.H) % 16 == 0) and not b.ent_task   # (the mesh-entity tasks render in tiles)
             self.stackedobs = b.stack_enable(self.nstack, "float32" if to_float else "uint8", sliding=not graph, fused=fuse)
         VecEnv.__init__(self, num_envs, Box(0, 255, shape, np.float32 if to_float else np.uint8), Discrete(b.n_actions))
         self.device = b.device

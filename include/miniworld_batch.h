@@ -221,6 +221,9 @@ int mwb_set_mesh_dims(mwb_handle *h, int geom, double height, double scale, doub
 /* debugging aid (MWB_DEBUG bit 4 at mwb_create): start / end s_memrealtime ticks (100 MHz) of every workgroup of the
  * last bulk render launch, [2 * n] u64; returns n or a negative code */
 int mwb_debug_wg_times(mwb_handle *h, unsigned long long *out, int max_wgs);
+/* debugging aid (MWB_EXP bit 2 at mwb_create): counters of the entity render kernel's mesh walks since the last reset - sample rays
+ * entering the walk, walks started, node visits, triangle tests, wave loop iterations, wave calls (out8: 8 x u64) */
+int mwb_debug_counters(mwb_handle *h, unsigned long long *out8, int reset);
 int mwb_set_texture(mwb_handle *h, int tex_id, int width, int height, const uint8_t *rgb);
 
 /* ---- simulation -------------------------------------------------------------------------- */

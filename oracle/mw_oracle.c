@@ -1423,10 +1423,18 @@ static void make_ray(const Cam *c, float wx, float wy, float *d) {
 
 typedef struct { int kind; /* 0 sky, 1 floor, 2 ceil, 3 wall, 4 box */ int room, side; float t; } Hit;
 
+/* A wall with TWO portals (ThreeRooms: the big room's south wall opens into both small rooms) has no place in a room record with
+ * one portal per side: the room is cut in two RENDER rooms along the line midway between the two openings, joined by a "virtual"
+ * portal as wide and as high as the cut (nothing is drawn there).  The cut leaves visibility unchanged - a convex room cut by a
+ * plane is two convex rooms - and every surface keeps its texture origin.  The lower half (smaller coordinate along the wall) keeps
+ * the room's index, the upper half is appended behind the last room.  Returns the number of render rooms (<= 2 n). */
 static int build_rrooms(MwoEnv *e, RRoom *rr) {
-    int n = e->n_rooms;
+    int n = e->n_rooms, n_out = e->n_rooms;
     for (int i = 0; i < n; i++) {
         Room *r = &e->rooms[i]; RRoom *o = &rr[i];
+        int cut_s = -1, cut_ax = 0;
+        RSide cut_second;
+        memset(&cut_second, 0, sizeof(cut_second));
         o->min_x = (float)r->min_x; o->max_x = (float)r->max_x; o->min_z = (float)r->min_z; o->max_z = (float)r->max_z;
         o->height = (float)r->wall_height;
         o->wall_tex = r->wall_tex; o->floor_tex = r->floor_tex; o->ceil_tex = r->ceil_tex; o->no_ceiling = r->no_ceiling;
@@ -1440,16 +1448,44 @@ static int build_rrooms(MwoEnv *e, RRoom *rr) {
             int ax = (s == 0 || s == 2) ? 2 : 0; /* coordinate that runs along this side */
             double p0c = r->outline[ed][ax], dirc = r->edge_dirs[ed][ax];
             o->side[s].u_org = (float)p0c; o->side[s].u_sgn = (float)dirc;
-            if (r->n_portals[ed] > 1) fail("render: at most one portal per edge");
-            if (r->n_portals[ed] == 1) {
+            if (r->n_portals[ed] > 2) fail("render: at most two portals per edge");
+            if (r->n_portals[ed] >= 1) {
                 Portal *p = &r->portals[ed][0];
                 double c0 = p0c + dirc * p->start, c1 = p0c + dirc * p->end;
                 o->side[s].lo = (float)(c0 < c1 ? c0 : c1); o->side[s].hi = (float)(c0 < c1 ? c1 : c0);
                 o->side[s].min_y = (float)p->min_y; o->side[s].max_y = (float)p->max_y;
                 o->side[s].nbr = -2; /* resolved below */
             }
+            if (r->n_portals[ed] == 2) {   /* the second opening: the room is cut between the two (below) */
+                Portal *q = &r->portals[ed][1];
+                double d0 = p0c + dirc * q->start, d1 = p0c + dirc * q->end;
+                if (cut_s >= 0) fail("render: two walls with two portals each");
+                cut_s = s; cut_ax = ax;
+                cut_second = o->side[s];
+                cut_second.lo = (float)(d0 < d1 ? d0 : d1); cut_second.hi = (float)(d0 < d1 ? d1 : d0);
+                cut_second.min_y = (float)q->min_y; cut_second.max_y = (float)q->max_y;
+            }
+        }
+        if (cut_s >= 0) {
+            const int s = cut_s, ax = cut_ax;
+            if (r->n_portals[0] + r->n_portals[1] + r->n_portals[2] + r->n_portals[3] > 2) fail("render: a cut room may have portals on the cut wall only");
+            RSide first = o->side[s], second = cut_second;
+            if (second.lo < first.lo) { RSide t = first; first = second; second = t; }
+            const float cut = (float)(0.5 * ((double)first.hi + (double)second.lo));
+            RRoom *hi_half = &rr[n_out];
+            *hi_half = *o;
+            const int lo_end = ax == 0 ? 2 : 1, hi_end = ax == 0 ? 0 : 3;   /* the sides at the low / high end of the wall's axis: -x / +x, -z (side 1) / +z (side 3) */
+            if (ax == 0) { o->max_x = cut; hi_half->min_x = cut; } else { o->max_z = cut; hi_half->min_z = cut; }
+            o->side[s] = first; hi_half->side[s] = second;
+            RSide v;   /* the virtual portal: the whole cut, from the floor up */
+            v.lo = (ax == 0 ? o->min_z : o->min_x) - 1.0f; v.hi = (ax == 0 ? o->max_z : o->max_x) + 1.0f; v.min_y = 0.0f; v.max_y = 1e30f;
+            v.u_org = 0.0f; v.u_sgn = 1.0f;
+            v.nbr = n_out; o->side[hi_end] = v;
+            v.nbr = i; hi_half->side[lo_end] = v;
+            n_out++;
         }
     }
+    n = n_out;
     /* geometric neighbour inference: the room whose opposite side lies on the same plane with a matching portal */
     for (int i = 0; i < n; i++)
         for (int s = 0; s < 4; s++) {
@@ -1884,7 +1920,7 @@ static void shade_frame(const RFrame *f, int code, const float *o, const float *
 
 void mwo_render(MwoEnv *e, int W, int H, uint8_t *rgb, float *depth) {
     const int poly = e->task == MWO_YMAZE;   /* rooms with arbitrary edges: the polygon formulation */
-    RRoom *rr = (RRoom *)malloc(sizeof(RRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));   /* per call: thread-safe */
+    RRoom *rr = (RRoom *)malloc(sizeof(RRoom) * (size_t)(e->n_rooms > 0 ? 2 * e->n_rooms : 1));   /* per call: thread-safe */
     PRoom *pr = (PRoom *)malloc(sizeof(PRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));
     int n_rooms = poly ? build_prooms(e, pr) : build_rrooms(e, rr);
     /* camera: gluPerspective(fov_y, W/H, 0.04, 100), gluLookAt(cam_pos, cam_pos+cam_dir, +Y) */
@@ -2109,7 +2145,7 @@ static int cube_entry(const float *lo, const float *hi, const float *o, const fl
 
 uint32_t mwo_visible_ents(MwoEnv *e, int W, int H) {
     const int poly = e->task == MWO_YMAZE;
-    RRoom *rr = (RRoom *)malloc(sizeof(RRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));
+    RRoom *rr = (RRoom *)malloc(sizeof(RRoom) * (size_t)(e->n_rooms > 0 ? 2 * e->n_rooms : 1));
     PRoom *pr = (PRoom *)malloc(sizeof(PRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));
     int n_rooms = poly ? build_prooms(e, pr) : build_rrooms(e, rr);
     double cp[3], cd[3];
@@ -2178,7 +2214,7 @@ typedef struct { int kind, idx; float y; } TopHit;   /* kind: 0 clear colour, 1 
 
 void mwo_render_top(MwoEnv *e, int W, int H, uint8_t *rgb) {
     const int poly = e->task == MWO_YMAZE;
-    RRoom *rr = (RRoom *)malloc(sizeof(RRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));
+    RRoom *rr = (RRoom *)malloc(sizeof(RRoom) * (size_t)(e->n_rooms > 0 ? 2 * e->n_rooms : 1));
     PRoom *pr = (PRoom *)malloc(sizeof(PRoom) * (size_t)(e->n_rooms > 0 ? e->n_rooms : 1));
     int n_rooms = poly ? build_prooms(e, pr) : build_rrooms(e, rr);
     /* extents, miniworld.py:576-579 and 1108-1131 */
