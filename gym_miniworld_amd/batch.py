@@ -77,6 +77,7 @@ ENV_SPECS = {
     "MiniWorld-PickupObjs-v0": ("PickupObjs", [12, 5], 0, None, None),         # pickupobjs.py:13-22
     "MiniWorld-RoomObjs-v0": ("RoomObjs", [10], 0, None, None),                # roomobjs.py:14-21
     "MiniWorld-CollectHealth-v0": ("CollectHealth", [16], 0, None, None),      # collecthealth.py:19-26
+    "MiniWorld-ThreeRooms-v0": ("ThreeRooms", [], 0, None, None),              # threerooms.py:12-20: two openings in one wall
     "MiniWorld-Sign-v0": ("Sign", [10, 0, 0], 0, _sign_params, False),         # sign.py:41-71: its own params, domain_rand forced off
     "MiniWorld-Sidewalk-v0": ("Sidewalk", [], 0, None, None),
     "MiniWorld-WallGap-v0": ("WallGap", [], 0, None, None),

@@ -204,7 +204,6 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
     if (cfg->abi_version != MWB_ABI_VERSION) return set_err(MWB_EINVAL, "mwb_create: abi_version mismatch");
     if (cfg->num_envs <= 0) return set_err(MWB_EINVAL, "mwb_create: num_envs must be > 0");
     if (cfg->task < 0 || cfg->task >= MWB_NUM_TASKS) return set_err(MWB_EINVAL, "mwb_create: unknown task");
-    if (cfg->task == MWB_TASK_THREEROOMS) return set_err(MWB_EINVAL, "mwb_create: ThreeRooms needs two portals on one wall (not supported yet)");
     if (cfg->obs_width <= 0 || cfg->obs_height <= 0 || cfg->obs_width > 1024 || cfg->obs_height > 1024)
         return set_err(MWB_EINVAL, "mwb_create: bad observation size");
     if (cfg->layout != MWB_LAYOUT_HWC && cfg->layout != MWB_LAYOUT_CWH) return set_err(MWB_EINVAL, "mwb_create: bad layout");
@@ -313,7 +312,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
 #define A(ptr, n) if (rc == MWB_OK) rc = dev_alloc(h, &(ptr), (n))
     A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N * d.n_boxes); A(d.box_z, N * d.n_boxes); A(d.box_y, N * d.n_boxes); A(d.box_dir, N * d.n_boxes); A(d.carrying, N);
     A(d.box_color, N * d.n_boxes * 3); A(d.box_size, N * d.n_boxes); A(d.goal_dist, N); A(d.episode_count, N); A(d.task_step_count, N); A(d.goal_idx, N); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
-    A(d.step_count, N); A(d.n_rooms, N); A(d.n_segs, N); A(d.reset_set, N); A(d.reset_list, N); A(d.reset_count, (size_t)1);
+    A(d.step_count, N); A(d.n_rooms, N); A(d.n_rrooms, N); A(d.n_segs, N); A(d.reset_set, N); A(d.reset_list, N); A(d.reset_count, (size_t)1);
     if (d.ent_task) {
         A(d.ent_meta, N * d.n_boxes); A(d.ent_radius, N * d.n_boxes); A(d.ent_height, N * d.n_boxes); A(d.ent_scale, N * d.n_boxes);
         A(d.ent_order, N * MWB_ORDER_STRIDE); A(d.n_order, N); A(d.task_f, N); A(d.task_i, N); A(d.text_tex, N * 8);
@@ -1174,7 +1173,7 @@ extern "C" int mwb_get_geometry(mwb_handle *h, int env, float *rooms, int max_ro
     if (env < 0 || env >= d.N) return set_err(MWB_EINVAL, "mwb_get_geometry: env out of range");
     USE_DEVICE(h->cfg.device);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(n_rooms, d.n_rooms + env, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(n_rooms, d.n_rrooms + env, sizeof(int), hipMemcpyDeviceToHost));   // the table's records, cut rooms included
     HIP_TRY(hipMemcpy(n_segs, d.n_segs + env, sizeof(int), hipMemcpyDeviceToHost));
     if (rooms) {
         int n = *n_rooms < max_rooms ? *n_rooms : max_rooms;

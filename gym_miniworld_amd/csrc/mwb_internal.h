@@ -160,6 +160,7 @@ struct MwbDev {
     double *cam;            // [N][4] height, fwd_disp, pitch, fov_y
     double *sky_color, *light_pos, *light_color, *light_ambient;   // [N][3]
     int32_t *step_count, *n_rooms, *n_segs;
+    int32_t *n_rrooms;   // records in the env's room table: n_rooms, + 1 where a room with two openings on one wall was cut in two (reset_kernel)
     int32_t *error_flag;    // [1] set by reset_kernel when world generation hits a condition the reference asserts on
     uint8_t *reset_set;     // which envs are (re)generated in the current pass (set by step / mark_reset)
     int32_t *reset_list;    // [N] the same envs as a compact list (order arbitrary) ...

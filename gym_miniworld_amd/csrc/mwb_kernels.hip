@@ -673,6 +673,10 @@ struct WorldGen {
     double *ent_x, *ent_z, *ent_r;
     int *ent_f32;
     int n_placed;
+    // the one wall that carries a SECOND portal (ThreeRooms: the big room's wall towards both small rooms).  WRoom keeps the
+    // opening with the lower start_pos - Room.add_portal sorts the list, miniworld.py:214-215 - this record the other one.
+    int xp_room = -1, xp_edge = -1, xp_nbr = -1;
+    double xp_start = 0, xp_end = 0, xp_maxy = 0;
 
     // Room.__init__, miniworld.py:75-138
     __device__ int add_room(const double *ox, const double *oz, double height, int wall_fam, int floor_fam, int ceil_fam, int ne = 4) {
@@ -719,8 +723,9 @@ struct WorldGen {
         nx = ex / nn; nz = ez / nn;
     }
     // Room.add_portal, miniworld.py:140-218; mode 0 start/end, 1 min_x/max_x, 2 min_z/max_z
-    __device__ void add_portal(int ri, int e, int mode, double a, double b, bool has_max_y, double max_y_in,
-                               double &start, double &end) {
+    // returns the slot the opening went to: 0 the room's own record, 1 the second-portal record
+    __device__ int add_portal(int ri, int e, int mode, double a, double b, bool has_max_y, double max_y_in,
+                              double &start, double &end) {
         WRoom &r = rooms[ri];
         double dx, dz, len;
         edge(r, e, dx, dz, len);
@@ -733,10 +738,26 @@ struct WorldGen {
             if (m1 < m0) { double t = m0; m0 = m1; m1 = t; }
             start = m0; end = m1;
         } else { start = a; end = b; }
-        if (!(end > start) || !(start >= 0) || !(end <= len) || r.n_port[e] != 0) fail = true;
-        r.p_start[e] = start; r.p_end[e] = end;
-        r.p_maxy[e] = has_max_y ? max_y_in : r.height;
-        r.n_port[e] = 1;
+        if (!(end > start) || !(start >= 0) || !(end <= len)) fail = true;
+        const double my = has_max_y ? max_y_in : r.height;
+        if (r.n_port[e] == 0) {
+            r.p_start[e] = start; r.p_end[e] = end; r.p_maxy[e] = my;
+            r.n_port[e] = 1;
+            return 0;
+        }
+        if (r.n_port[e] != 1 || xp_room >= 0) { fail = true; return 0; }   // one wall with two openings per world at most
+        xp_room = ri; xp_edge = e;
+        r.n_port[e] = 2;
+        if (r.p_start[e] > start) {   // stable sort by start_pos: the new opening goes in front
+            xp_start = r.p_start[e]; xp_end = r.p_end[e]; xp_maxy = r.p_maxy[e]; xp_nbr = r.nbr[e];
+            r.p_start[e] = start; r.p_end[e] = end; r.p_maxy[e] = my; r.nbr[e] = -1;
+            return 0;
+        }
+        xp_start = start; xp_end = end; xp_maxy = my; xp_nbr = -1;
+        return 1;
+    }
+    __device__ void set_nbr(int ri, int e, int slot, int nb) {
+        if (slot == 0) rooms[ri].nbr[e] = nb; else xp_nbr = nb;
     }
     // connect_rooms, miniworld.py:757-843
     __device__ void connect_rooms(int ia, int ib, int mode, double lo, double hi, bool has_max_y, double max_y) {
@@ -758,8 +779,8 @@ struct WorldGen {
         }
         if (idx_a < 0) { fail = true; return; }
         double sa, ea, sb, eb;
-        add_portal(ia, idx_a, mode, lo, hi, has_max_y, max_y, sa, ea);
-        add_portal(ib, idx_b, mode, lo, hi, has_max_y, max_y, sb, eb);
+        const int slot_a = add_portal(ia, idx_a, mode, lo, hi, has_max_y, max_y, sa, ea);
+        const int slot_b = add_portal(ib, idx_b, mode, lo, hi, has_max_y, max_y, sb, eb);
         double adx, adz, bdx, bdz, l;
         edge(rooms[ia], idx_a, adx, adz, l);
         edge(rooms[ib], idx_b, bdx, bdz, l);
@@ -770,7 +791,7 @@ struct WorldGen {
         double d_x = B.ox[idx_b] + bdx * eb, d_z = B.oz[idx_b] + bdz * eb;
         double adx_ = a_x - d_x, adz_ = a_z - d_z;
         if (sqrt(adx_ * adx_ + 0.0 + adz_ * adz_) < 0.001) {   // portals directly connected
-            rooms[ia].nbr[idx_a] = ib; rooms[ib].nbr[idx_b] = ia;
+            set_nbr(ia, idx_a, slot_a, ib); set_nbr(ib, idx_b, slot_b, ia);
             return;
         }
         double len_a = sqrt((b_x - a_x) * (b_x - a_x) + 0.0 + (b_z - a_z) * (b_z - a_z));
@@ -782,7 +803,7 @@ struct WorldGen {
         double s0, e0;
         add_portal(ic, 1, 0, 0.0, len_a, false, 0.0, s0, e0);
         add_portal(ic, 3, 0, 0.0, len_b, false, 0.0, s0, e0);
-        rooms[ia].nbr[idx_a] = ic; rooms[ib].nbr[idx_b] = ic;
+        set_nbr(ia, idx_a, slot_a, ic); set_nbr(ib, idx_b, slot_b, ic);
         rooms[ic].nbr[1] = ia; rooms[ic].nbr[3] = ib;
     }
     // numpy add.reduce pairwise summation (np.sum at miniworld.py:998)
@@ -811,12 +832,17 @@ struct WorldGen {
         double dx, dz, len;
         edge(r, e, dx, dz, len);
         int n = 0;
-        double st[2], en[2];
+        double st[3], en[3];
         if (r.n_port[e] == 0) { st[0] = 0; en[0] = len; n = 1; }
-        else {
+        else if (r.n_port[e] == 1) {
             st[0] = 0; en[0] = r.p_start[e];
             st[1] = r.p_end[e]; en[1] = len;
             n = 2;
+        } else {   // two openings (this is the room of the second-portal record): wall, opening, wall, opening, wall
+            st[0] = 0; en[0] = r.p_start[e];
+            st[1] = r.p_end[e]; en[1] = xp_start;
+            st[2] = xp_end; en[2] = len;
+            n = 3;
         }
         int cnt = 0;
         for (int k = 0; k < n; k++) {
@@ -1525,6 +1551,35 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             }
         }
     }
+    // A wall with TWO openings (ThreeRooms) does not fit a room record with one portal per side: the room is cut into two RENDER
+    // rooms along the line midway between the openings, joined by a "virtual" portal over the whole cut (nothing is drawn there;
+    // a convex room cut by a plane is two convex rooms, visibility is unchanged and every surface keeps its texture origin).  The
+    // half at the lower coordinate keeps the room's index, the other one is appended behind the last room.
+    int cut_room = -1, cut_s = 0, n_rrooms = w.n_rooms;
+    float cut = 0.0f, c_first[3] = {0, 0, 0}, c_second[3] = {0, 0, 0};   // lo hi max_y of the opening at the lower / higher coordinate
+    int c_nbr[2] = {-1, -1};
+    if (!d.poly && w.xp_room >= 0) {
+        const WRoom &r = rooms[w.xp_room];
+        const int ed = w.xp_edge;
+        const double dx = r.edx[ed], dz = r.edz[ed], nx = dz, nz = -dx;
+        cut_room = w.xp_room;
+        cut_s = (nx == -1 && nz == 0) ? 0 : (nx == 0 && nz == 1) ? 1 : (nx == 1 && nz == 0) ? 2 : 3;
+        const bool along_z = (cut_s == 0 || cut_s == 2);
+        const double p0c = along_z ? r.oz[ed] : r.ox[ed], dirc = along_z ? dz : dx;
+        const double a0 = p0c + dirc * r.p_start[ed], a1 = p0c + dirc * r.p_end[ed], b0 = p0c + dirc * w.xp_start, b1 = p0c + dirc * w.xp_end;
+        float pa[3] = {(float)(a0 < a1 ? a0 : a1), (float)(a0 < a1 ? a1 : a0), (float)r.p_maxy[ed]};
+        float pb[3] = {(float)(b0 < b1 ? b0 : b1), (float)(b0 < b1 ? b1 : b0), (float)w.xp_maxy};
+        const bool swap = pb[0] < pa[0];
+        for (int k = 0; k < 3; k++) { c_first[k] = swap ? pb[k] : pa[k]; c_second[k] = swap ? pa[k] : pb[k]; }
+        c_nbr[0] = swap ? w.xp_nbr : r.nbr[ed]; c_nbr[1] = swap ? r.nbr[ed] : w.xp_nbr;
+        cut = (float)(0.5 * ((double)c_first[1] + (double)c_second[0]));
+        n_rrooms = w.n_rooms + 1;
+        if (r.n_port[0] + r.n_port[1] + r.n_port[2] + r.n_port[3] > 2 || n_rrooms > d.R_max || c_nbr[0] < 0 || c_nbr[1] < 0) {
+            atomicExch(d.error_flag, e + 1);
+            cut_room = -1; n_rrooms = w.n_rooms;
+        }
+    }
+    if (lane == 0) d.n_rrooms[e] = w.fail ? -1 : n_rrooms;
     for (int ri = lane; !d.poly && ri < w.n_rooms; ri += WAVE) {
         const WRoom &r = rooms[ri];
         float *o = grooms + (size_t)ri * MWB_ROOM_WORDS;
@@ -1550,8 +1605,31 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
                 double c0 = p0c + dirc * r.p_start[ed], c1 = p0c + dirc * r.p_end[ed];
                 sd[RS_LO] = (float)(c0 < c1 ? c0 : c1); sd[RS_HI] = (float)(c0 < c1 ? c1 : c0);
                 sd[RS_MAXY] = (float)r.p_maxy[ed];
-                nbrs[s] = (uint32_t)r.nbr[ed] & 0xFFFFu;
+                int nb = r.nbr[ed];
+                if (nb == cut_room && cut_room >= 0 && sd[RS_LO] >= cut) nb = w.n_rooms;   // the opening leads into the appended half
+                nbrs[s] = (uint32_t)nb & 0xFFFFu;
             }
+        }
+        if (ri == cut_room) {
+            const bool ax0 = (cut_s == 1 || cut_s == 3);   // the cut wall runs along x
+            const int lo_end = ax0 ? 2 : 1, hi_end = ax0 ? 0 : 3;   // the sides at the low / high end of that axis
+            float *h = grooms + (size_t)w.n_rooms * MWB_ROOM_WORDS;
+            for (int k = 0; k < MWB_ROOM_WORDS; k++) h[k] = o[k];
+            o[ax0 ? RW_MAXX : RW_MAXZ] = cut; h[ax0 ? RW_MINX : RW_MINZ] = cut;
+            float *so = o + RW_SIDE0 + RW_SIDE_WORDS * cut_s, *sh = h + RW_SIDE0 + RW_SIDE_WORDS * cut_s;
+            so[RS_LO] = c_first[0]; so[RS_HI] = c_first[1]; so[RS_MAXY] = c_first[2];
+            sh[RS_LO] = c_second[0]; sh[RS_HI] = c_second[1]; sh[RS_MAXY] = c_second[2];
+            float *vo = o + RW_SIDE0 + RW_SIDE_WORDS * hi_end, *vh = h + RW_SIDE0 + RW_SIDE_WORDS * lo_end;
+            vo[RS_LO] = vh[RS_LO] = (ax0 ? (float)r.min_z : (float)r.min_x) - 1.0f;
+            vo[RS_HI] = vh[RS_HI] = (ax0 ? (float)r.max_z : (float)r.max_x) + 1.0f;
+            vo[RS_MAXY] = vh[RS_MAXY] = 1e30f; vo[RS_UORG] = vh[RS_UORG] = 0.0f;
+            uint32_t nh[4] = {nbrs[0], nbrs[1], nbrs[2], nbrs[3]};
+            nbrs[cut_s] = (uint32_t)c_nbr[0] & 0xFFFFu; nh[cut_s] = (uint32_t)c_nbr[1] & 0xFFFFu;
+            nbrs[hi_end] = (uint32_t)w.n_rooms; nh[lo_end] = (uint32_t)ri;
+            h[RW_TEX] = __int_as_float((int)(texw & ~(1u << (24 + lo_end))));
+            texw &= ~(1u << (24 + hi_end));
+            h[RW_NBR01] = __int_as_float((int)(nh[0] | (nh[1] << 16)));
+            h[RW_NBR23] = __int_as_float((int)(nh[2] | (nh[3] << 16)));
         }
         o[RW_TEX] = __int_as_float((int)texw);
         o[RW_NBR01] = __int_as_float((int)(nbrs[0] | (nbrs[1] << 16)));
@@ -2735,7 +2813,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     int tid = threadIdx.x;
     if (LOOPED) asm volatile("" : "+v"(tid));
     const int W = TILED ? tw : d.W, H = TILED ? th : d.H;
-    int n_rooms = d.n_rooms[e];
+    int n_rooms = d.n_rrooms[e];
     if (n_rooms < 0) n_rooms = 0;
     float *rooms = (float *)smem;
     size_t off = ((size_t)d.R_max * d.room_words * 4 + 15) & ~(size_t)15;
@@ -3563,7 +3641,7 @@ __global__ void __launch_bounds__(256) top_view_kernel(MwbDev d, uint8_t *__rest
     const int e = blockIdx.x, tid = threadIdx.x;
     for (int i = tid; i < (int)(sizeof(TexLds) / 4) * d.n_tex; i += 256) ((uint32_t *)tex)[i] = ((const uint32_t *)d.tex_desc)[i];
     __syncthreads();
-    int n_rooms = d.n_rooms[e];
+    int n_rooms = d.n_rrooms[e];
     if (n_rooms < 0) n_rooms = 0;
     const float *rooms = d.rooms + (size_t)e * d.R_max * d.room_words;
     const float *fc = d.frame + (size_t)e * d.frame_words;
@@ -3698,7 +3776,7 @@ __global__ void __launch_bounds__(256) visible_kernel(MwbDev d, uint32_t *__rest
     __shared__ int cam_room_s;
     __shared__ uint32_t mask_s;
     const int e = blockIdx.x, tid = threadIdx.x, W = d.W, H = d.H;
-    int n_rooms = d.n_rooms[e];
+    int n_rooms = d.n_rrooms[e];
     if (n_rooms < 0) n_rooms = 0;
     const float *rooms = d.rooms + (size_t)e * d.R_max * d.room_words;
     const float *fc = d.frame + (size_t)e * d.frame_words;

@@ -94,7 +94,7 @@ def test_env_registry_covers_the_configured_tasks():
               "MiniWorld-MazeS2-v0", "MiniWorld-MazeS3-v0", "MiniWorld-OneRoomS6-v0",
               # round 3: the tasks with mesh entities / frames
               "MiniWorld-PickupObjs-v0", "MiniWorld-RoomObjs-v0", "MiniWorld-CollectHealth-v0", "MiniWorld-Sign-v0",
-              "MiniWorld-Sidewalk-v0", "MiniWorld-WallGap-v0"):
+              "MiniWorld-Sidewalk-v0", "MiniWorld-WallGap-v0", "MiniWorld-ThreeRooms-v0"):
         assert k in ENV_SPECS
 
 

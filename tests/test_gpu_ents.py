@@ -1,4 +1,4 @@
-"""GPU: the tasks with a general entity list - PickupObjs, RoomObjs, CollectHealth, Sign, Sidewalk, WallGap (mesh entities, image /
+"""GPU: the tasks with a general entity list - PickupObjs, RoomObjs, CollectHealth, ThreeRooms, Sign, Sidewalk, WallGap (mesh entities, image /
 text frames, entities that leave the list or re-enter it at its end) - through the C ABI against the oracle: state bit for bit
 (entity kinds, dimensions incl. the NumPy-2 float32 radii, poses, LIST ORDER, counters, RNG), rewards / dones / step counts at every
 step, frames within +-1 LSB and depth within 1e-4 m incl. the step's own frame of a pick-up (the object still in the agent's hands)."""
@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 # env id -> (oracle task, task_args, params)
 TASKS = {"MiniWorld-PickupObjs-v0": ("PickupObjs", [12, 5, 0, 0]), "MiniWorld-RoomObjs-v0": ("RoomObjs", [10, 0, 0, 0]),
-         "MiniWorld-CollectHealth-v0": ("CollectHealth", [16, 0, 0, 0]), "MiniWorld-Sign-v0": ("Sign", [10, 0, 0, 0]),
+         "MiniWorld-CollectHealth-v0": ("CollectHealth", [16, 0, 0, 0]), "MiniWorld-ThreeRooms-v0": ("ThreeRooms", None), "MiniWorld-Sign-v0": ("Sign", [10, 0, 0, 0]),
          "MiniWorld-Sidewalk-v0": ("Sidewalk", None), "MiniWorld-WallGap-v0": ("WallGap", None)}
 
 
@@ -107,7 +107,8 @@ def test_reset_state_and_first_obs(oracle_mod, env_id, dr):
                                               ("MiniWorld-RoomObjs-v0", 1, "collect"), ("MiniWorld-CollectHealth-v0", 0, "collect"),
                                               ("MiniWorld-CollectHealth-v0", 1, "random"), ("MiniWorld-Sign-v0", 0, "collect"),
                                               ("MiniWorld-Sidewalk-v0", 1, "collect"), ("MiniWorld-WallGap-v0", 0, "collect"),
-                                              ("MiniWorld-PickupObjs-v0", 1, "random")])
+                                              ("MiniWorld-PickupObjs-v0", 1, "random"), ("MiniWorld-ThreeRooms-v0", 0, "collect"),
+                                              ("MiniWorld-ThreeRooms-v0", 1, "random")])
 def test_rollout_exact_and_step_frames(oracle_mod, env_id, dr, policy):
     import torch
     O = oracle_mod
@@ -187,7 +188,7 @@ def test_random_views_and_fast_path(oracle_mod, env_id, monkeypatch):
             s = e.state()
             g = e.geometry()
             # a point inside the first room, looking roughly at a random entity half of the time
-            o = g["outline"][0]
+            o = g["outline"][int(rng.integers(0, 3)) if "ThreeRooms" in env_id else 0]   # ThreeRooms: any of the three rooms, through both openings
             lo, hi = o.min(axis=0) + 0.45, o.max(axis=0) - 0.45
             pos[i] = rng.uniform(lo, hi)
             if rng.random() < 0.6:
