@@ -200,8 +200,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo (+ --no-gather) only to rehearse the multi-rank flow on one GPU")
     ap.add_argument("--force-gather", action="store_true", help="run the staging + exchange path even at N = 1 (self-test)")
-    ap.add_argument("--gather", default="auto", choices=["auto", "ring", "direct"],
-                    help="exchange method of the per-step shard exchange (auto: time both in the warm-up, keep the faster)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "ring", "direct", "learner"],
+                    help="method of the per-step shard exchange (auto: time ring and direct in the warm-up, keep the faster; "
+                         "learner: only rank 0 receives the batch - 1/N of the bytes an all-gather moves)")
     args = ap.parse_args()
 
     import torch
@@ -263,8 +264,25 @@ def main():
             torch.cuda.synchronize(device)
 
     run(0, Wm)
+    multi = None
     if gather is not None:
+        # self-check, outside the timed region: every rank's shard of the newest round arrived where the method delivers it
+        # (per-shard checksums, all-gathered separately), on distinct devices, and what one exchange costs unoverlapped
+        gather.latest()
+        ok, seen = gather.verify()
         gather.drain()
+        props = torch.cuda.get_device_properties(dev_index)
+        me = {"rank": rank, "device": dev_index, "uuid": str(getattr(props, "uuid", "")), "name": props.name, "envs": [first, count]}
+        ranks = [me]
+        if world > 1:
+            ranks = [None] * world
+            dist.all_gather_object(ranks, me)
+        multi = {"ranks_seen": seen, "world_size": dist.get_world_size() if world > 1 else 1, "ranks": ranks,
+                 "distinct_devices": len({r["uuid"] or (r["rank"], r["device"]) for r in ranks}),
+                 "gather": {"method": gather.method, "verified": bool(ok), "exchange_ms": gather.measure(4) * 1e3,
+                            "bytes_per_rank_per_step": int(env.obs[0].numel()) * count + 64 * count}}
+        if not ok or seen != world:
+            sys.exit("bench.py: the shard exchange did not deliver every rank's shard (%r)" % (multi,))
     fence()
     # HIP events on the launch stream, every 4th step of the timed region whatever its length (seven events per step
     # cost ~2-5 % of a step's time); read back only after the timed region
@@ -303,6 +321,8 @@ def main():
                          "note": "nominally HBM-bound path; the practical limiter is VALU issue (DESIGN.md 4: issue-slot accounting from the committed SQ counter passes)"},
             "kernel_ms": {k: kt[k] for k in ("step", "reset", "prep", "render")},
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         if world == 1 and not args.no_vecenv:
             env.close()
             try:

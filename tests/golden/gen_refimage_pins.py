@@ -38,6 +38,19 @@ CASES = {
     "ymaze": ("YMaze", (-5.64, 0.48), 5, "ymaze_0.jpg"),
 }
 INSET_ONLY = {"ymaze"}
+# Scenes with mesh entities / frames (round 3).  The world of these tasks is fixed apart from the entities the task places at random,
+# which are unknown (unknown seed): those are moved out of view in the rendition and masked by their colour in the screenshot.  What is
+# NOT random stays in view and is pinned with the rooms: Sidewalk's building and cones (sidewalk.py:43-60: fixed positions), WallGap's
+# building (wallgap.py:44-52), ThreeRooms' ImageFrame (threerooms.py:47-52; objects.jpg is a ThreeRooms window).
+#   name: (oracle task, task_args, HUD (x, z), HUD angle, file, colour classes masked, kinds of entity kept in view)
+# Not used: sign.jpg (no HUD: pose unknown), textframe.jpg (a scene of no registered env).
+ENT_CASES = {
+    "pickupobjs": ("PickupObjs", [12, 5, 0, 0], (3.03, 4.12), 289, "pickupobjs_0.jpg", ("red", "green", "purple"), ()),
+    "collecthealth": ("CollectHealth", [16, 0, 0, 0], (15.55, 12.52), 163, "collecthealth_0.jpg", ("red",), ()),
+    "objects": ("ThreeRooms", None, (-1.17, 3.04), 291, "objects.jpg", ("red", "green", "blue"), ("frame",)),
+    "sidewalk": ("Sidewalk", None, (-1.89, 0.41), 298, "sidewalk_0.jpg", ("pure_red",), ("mesh",)),
+    "wallgap": ("WallGap", None, (-2.52, -5.01), 294, "wallgap_0.jpg", ("pure_red", "sky"), ("mesh",)),   # its sky is (110, 207, 255): a revision before today's sky_color
+}
 # window = 24-pixel title bar + 1-pixel frame left / right / below around the 1056x600 client area (the crop that
 # minimises the fit residual of all three screenshots; one pixel off in either direction doubles it)
 MAIN = (slice(24, 624), slice(1, 801))       # the 800x600 human view inside the 1058x625 screenshot
@@ -63,14 +76,43 @@ def non_box_mask(img, grow):
     return ~binary_dilation(colored, iterations=grow)
 
 
-def fit_pose(task, hx, hz, hang, ref, mask):
+def colour_mask(img, classes, grow):
+    """False on and around the pixels of the entities a task places at random, told by their colour class"""
+    from scipy.ndimage import binary_dilation
+    r, g, b = img[..., 0], img[..., 1], img[..., 2]
+    rules = {"red": (r > g + 40) & (r > b + 40), "pure_red": (r > 90) & (g < 60) & (b < 60) & (r > g + 60),
+             "green": (g > r + 60) & (g > b + 60), "blue": (b > r + 60) & (b > g + 60), "purple": (b > g + 40) & (r > g + 20),
+             "sky": (b > 200) & (g > 170) & (r < 160)}
+    m = np.zeros(r.shape, bool)
+    for c in classes:
+        m |= rules[c]
+    return ~binary_dilation(m, iterations=grow)
+
+
+def ent_scene(O, case, W, H):
+    """the oracle's env of an ENT_CASES entry with every randomly placed entity moved far behind the camera"""
+    task, args, (hx, hz), hang, _, _, keep = case
+    e = O.OracleEnv(task, seed=1, obs_width=W, obs_height=H, task_args=args)
+    e.reset(render=False)
+    s = e.state()
+    a0 = math.radians(hang + 0.5)
+    for k in range(s.n_boxes):
+        kind = {0: "box", 1: "mesh"}.get(int(s.ents_kind[k]), "frame")
+        if kind not in keep:
+            e.set_box(k, hx - 40.0 * math.cos(a0), hz + 40.0 * math.sin(a0), 0.0)
+    return e
+
+
+def fit_pose(task, hx, hz, hang, ref, mask, env=None):
     from scipy.optimize import minimize
     from oracle import oracle as O
     H, W, _ = ref.shape
-    e = O.OracleEnv(task, seed=1, obs_width=W, obs_height=H, task_args=[0, 0, 0, 0] if task == "YMaze" else None)
-    e.reset(render=False)
-    a0 = math.radians(hang + 0.5)
-    e.set_box(0, hx - 0.6 * math.cos(a0), hz + 0.6 * math.sin(a0), 0.0)   # behind the camera: not in view
+    e = env
+    if e is None:
+        e = O.OracleEnv(task, seed=1, obs_width=W, obs_height=H, task_args=[0, 0, 0, 0] if task == "YMaze" else None)
+        e.reset(render=False)
+        a0 = math.radians(hang + 0.5)
+        e.set_box(0, hx - 0.6 * math.cos(a0), hz + 0.6 * math.sin(a0), 0.0)   # behind the camera: not in view
     best = None
     for lo, hi in hud_angle_interval(hang):
         def cost(p, lo=lo, hi=hi):
@@ -92,7 +134,10 @@ def fit_pose(task, hx, hz, hang, ref, mask):
 
 def main():
     from PIL import Image
+    only = set(sys.argv[1:])   # optional: the cases to regenerate
     for name, (task, (hx, hz), hang, fn) in CASES.items():
+        if only and name not in only:
+            continue
         im = np.asarray(Image.open(os.path.join(IMAGES, fn)).convert("RGB")).astype(np.float64)
         main_view = im[MAIN]
         inset_f = np.asarray(Image.fromarray(im[INSET].astype(np.uint8)).resize((80, 60), Image.BOX)).astype(np.float64)
@@ -122,6 +167,37 @@ def main():
             **({"top400": np.rint(box_down(main_view, 2)).astype(np.uint8)} if name in INSET_ONLY else {}))
         print("%-8s pose %.4f %.4f %.3f deg  cost %.2f  box faces %s -> %s" %
               (name, pose[0], pose[1], math.degrees(pose[2]), cost, np.round(faces).tolist(), os.path.basename(out)))
+    from oracle import oracle as O
+    for name, case in ENT_CASES.items():
+        if only and name not in only:
+            continue
+        task, args, (hx, hz), hang, fn, classes, keep = case
+        im = np.asarray(Image.open(os.path.join(IMAGES, fn)).convert("RGB")).astype(np.float64)
+        main_view = im[MAIN]
+        ref200 = box_down(main_view, 4)   # 200 x 150: the building's hierarchy makes a 400 x 300 fit an hour's work on the CPU
+        cost, pose = fit_pose(task, hx, hz, hang, ref200, colour_mask(ref200, classes, 4), env=ent_scene(O, case, 200, 150))
+        main160, main80 = box_down(main_view, 5), box_down(main_view, 10)
+        inset = np.asarray(Image.fromarray(im[INSET].astype(np.uint8)).resize((80, 60), Image.BOX)).astype(np.float64)
+        out = os.path.join(HERE, "refimg_%s.npz" % name)
+        np.savez_compressed(
+            out, task=task, hud_pos=np.array([hx, hz]), hud_angle=hang, fit_pose=np.array(pose), fit_cost=cost,
+            main160=np.rint(main160).astype(np.uint8), main80=np.rint(main80).astype(np.uint8), inset_only=False,
+            inset80=np.rint(inset).astype(np.uint8), mask160=colour_mask(main160, classes, 3), mask80=colour_mask(main80, classes, 2),
+            mask_inset=colour_mask(inset, classes, 2))
+        print("%-13s pose %.4f %.4f %.3f deg  cost %.2f -> %s" % (name, pose[0], pose[1], math.degrees(pose[2]), cost, os.path.basename(out)))
+    if not only or "maze_top" in only:
+        # maze_top_view.jpg (manual_control.py --top_view on Maze): the layout is random, the FRAME is not - the glOrtho extents of
+        # render_top_view (miniworld.py:1087-1158), the cell pitch 3.25 m and the 0.25 m gaps between rooms through which the sky shows
+        # (maze.py:33-52), the agent's triangle at the HUD position.  Kept: where the sky colour shows, where red shows.  (The floor's
+        # brightness falls off away from the corner at the origin: the positional light of that revision - colours are not compared.)
+        im = np.asarray(Image.open(os.path.join(IMAGES, "maze_top_view.jpg")).convert("RGB")).astype(np.float64)
+        mv = im[MAIN]
+        sky = np.abs(mv - mv[5, 5]).max(axis=2) < 50
+        red = (mv[..., 0] > mv[..., 1] + 60) & (mv[..., 0] > mv[..., 2] + 60)
+        np.savez_compressed(os.path.join(HERE, "refimg_maze_top.npz"), sky_mask=sky, red_mask=red, hud_pos=np.array([17.10, 18.52]), hud_angle=168)
+        print("maze_top_view -> refimg_maze_top.npz")
+    if only and "depth_map" not in only:
+        return
     # depth_map.jpg: grey level of the human view = displayed depth.  Kept: the 160x120 box-filtered luminance.
     im = np.asarray(Image.open(os.path.join(IMAGES, "depth_map.jpg")).convert("L")).astype(np.float64)
     d160 = box_down(im[MAIN][..., None], 5)[..., 0]

@@ -32,6 +32,47 @@ VIEWS = (
 )
 
 
+# Scenes with mesh entities / frames (generator: ENT_CASES of gen_refimage_pins.py): the entities the task places at random are moved
+# out of view and masked in the screenshot by their colour; what the task puts at FIXED poses stays in view and is pinned with the
+# rooms - Sidewalk's building + cones, WallGap's building, ThreeRooms' ImageFrame (objects.jpg).
+#   name: (env id, oracle task, task_args, entity kinds kept in view, tolerance overrides per view or None = view not pinned)
+# collecthealth_0.jpg and wallgap_0.jpg were taken with a POSITIONAL light at light_pos (walls behind the lamp dark, far walls lit,
+# the floor darker away from it): GL_POSITION = (*light_pos + [1]) with a LIST light_pos is (x, y, z, 1); with today's ndarray it is
+# (x + 1, y + 1, z + 1, 0), a directional light (miniworld.py:1026; the captured GL streams under tests/golden confirm w = 0).  Their
+# colours are therefore not comparable; they pin geometry and texture orientation only (correlations).
+_GEOM_ONLY = dict(mean_abs=None, median=None, block_max=None, corr=None)
+ENT_CASES = {
+    "pickupobjs": ("MiniWorld-PickupObjs-v0", "PickupObjs", [12, 5, 0, 0], (),
+                   {"main160": dict(floor_corr=0.7), "main80": dict(floor_corr=0.7), "inset80": dict(floor_corr=None)}),   # asphalt: noise-like texture
+    "objects": ("MiniWorld-ThreeRooms-v0", "ThreeRooms", None, ("frame",), {"main160": {}, "main80": {}, "inset80": {}}),
+    # the cones' headings are random (their square bases differ), the building's far windows alias: block means looser
+    "sidewalk": ("MiniWorld-Sidewalk-v0", "Sidewalk", None, ("mesh",),
+                 {"main160": dict(block_max=10.0), "main80": dict(block_max=16.0), "inset80": dict(block_max=10.0)}),
+    "collecthealth": ("MiniWorld-CollectHealth-v0", "CollectHealth", [16, 0, 0, 0], (),
+                      {"main160": dict(_GEOM_ONLY, hp_corr=0.5, floor_corr=0.7), "main80": dict(_GEOM_ONLY, floor_corr=0.65), "inset80": None}),
+    "wallgap": ("MiniWorld-WallGap-v0", "WallGap", None, ("mesh",),
+                {"main160": dict(_GEOM_ONLY, hp_corr=0.6, floor_corr=0.8), "main80": dict(_GEOM_ONLY, floor_corr=0.8), "inset80": None}),
+}
+KIND_NAMES = {0: "box", 1: "mesh"}   # entity kind -> class of ENT_CASES' "kept" tuple; everything else is a "frame"
+
+
+def ent_views(name):
+    """(fixture key, mask key, W, H, block, tolerances) of an ENT_CASES entry"""
+    out = []
+    for key, mkey, W, H, block, tol in VIEWS:
+        over = ENT_CASES[name][4].get(key)
+        if over is not None:
+            out.append((key, mkey, W, H, block, dict(tol, **over)))
+    return out
+
+
+def far_behind(fx):
+    """where the randomly placed entities go: 40 m behind the camera"""
+    hx, hz = fx["hud_pos"]
+    a0 = math.radians(float(fx["hud_angle"]) + 0.5)
+    return hx - 40.0 * math.cos(a0), hz + 40.0 * math.sin(a0)
+
+
 def load(name):
     d = np.load(os.path.join(GOLDEN, "refimg_%s.npz" % name))
     return {k: d[k] for k in d.files}
@@ -99,6 +140,7 @@ def check(st, tol, tag):
         if lim is None:
             continue
         v = st[k]
+        assert v == v, "%s: %s is nan" % (tag, k)
         if k in ("corr", "hp_corr", "floor_corr"):
             assert v >= lim, "%s: %s = %.3f < %.3f" % (tag, k, v, lim)
         else:
@@ -133,3 +175,56 @@ def depth_is_planar_and_linear(lum160):
     k = (band.mean(axis=1) / z)
     assert k.std() / k.mean() < 0.01, k           # one proportionality constant for all rows
     return float(k.mean())
+
+
+def maze_top_stats(sky, red, agent_xz, rows=8, cols=8, room=3.0, gap=0.25):
+    """Layout-independent statistics of a top view of Maze (maze_top_view.jpg; maze.py:33-52, render_top_view miniworld.py:1087-1158)
+    from where the sky colour shows (sky, bool [H, W]) and where red shows (red):
+      bbox        first / last row and column of the maze square in the frame
+      scale       pixels per metre, from the square's width and the maze's extent cols * room + (cols - 1) * gap
+      in_band     share of the sky pixels INSIDE the square that lie in the gaps between rooms, x or z in [k * 3.25 - 0.25, k * 3.25]
+                  (+- 2.5 px: JPEG edges, coverage)
+      thickness   mean width in pixels of the sky runs crossing the middle of a cell row / column
+      agent_err   distance in pixels between the red blob nearest to where agent_xz projects and that projection"""
+    H, W = sky.shape
+    inside = ~sky
+    r = np.where(inside.mean(axis=1) > 0.3)[0]
+    c = np.where(inside.mean(axis=0) > 0.3)[0]
+    r0, r1, c0, c1 = int(r[0]), int(r[-1]), int(c[0]), int(c[-1])
+    ext = cols * room + (cols - 1) * gap
+    scale = (c1 - c0 + 1) / ext
+    pitch = room + gap
+    xs = (np.arange(W) + 0.5 - c0) / scale
+    zs = (np.arange(H) + 0.5 - r0) / scale
+    pad = 2.5 / scale
+
+    def band(v, n):
+        k = np.floor(v / pitch + 1e-9)
+        lo = (k + 1) * pitch - gap
+        return (v >= lo - pad) | (v - k * pitch <= pad)   # (the square's own border rows / columns count as a gap's edge)
+    bx, bz = band(xs, cols), band(zs, rows)
+    sq = sky[r0:r1 + 1, c0:c1 + 1]
+    allowed = (bx[None, :] | bz[:, None])[r0:r1 + 1, c0:c1 + 1]
+    in_band = float((sq & allowed).sum()) / max(1, int(sq.sum()))
+    runs = []
+    for k in range(cols):   # a horizontal scan through the middle of every cell row, a vertical one through every cell column
+        for line in (sky[int(r0 + (k * pitch + room / 2) * scale), c0:c1 + 1], sky[r0:r1 + 1, int(c0 + (k * pitch + room / 2) * scale)]):
+            edges = np.diff(np.concatenate([[0], line.astype(np.int8), [0]]))
+            runs += list(np.where(edges == -1)[0] - np.where(edges == 1)[0])
+    px, pz = c0 + agent_xz[0] * scale, r0 + agent_xz[1] * scale
+    yy, xx = np.where(red)
+    near = (np.hypot(xx + 0.5 - px, yy + 0.5 - pz) < 0.6 * scale)
+    err = float(np.hypot(xx[near].mean() + 0.5 - px, yy[near].mean() + 0.5 - pz)) if near.sum() > 10 else float("inf")
+    return {"bbox": (r0, r1, c0, c1), "scale": scale, "in_band": in_band, "thickness": float(np.mean(runs)) if runs else 0.0,
+            "n_runs": len(runs), "agent_err": err}
+
+
+def check_maze_top(st, ref):
+    """our top view against the screenshot's: same frame (+- 2 px), same pitch, gaps where the reference has them and as wide"""
+    for a, b in zip(st["bbox"], ref["bbox"]):
+        assert abs(a - b) <= 2, (st["bbox"], ref["bbox"])
+    assert abs(st["scale"] - ref["scale"]) <= 0.1
+    assert st["in_band"] >= 0.985 and ref["in_band"] >= 0.985, (st["in_band"], ref["in_band"])
+    assert st["n_runs"] > 20 and ref["n_runs"] > 20 and abs(st["thickness"] - ref["thickness"]) <= 1.0, (st["thickness"], ref["thickness"])
+    assert abs(st["thickness"] - 0.25 * st["scale"]) <= 1.5   # the colour threshold eats about half a pixel of either edge
+    assert st["agent_err"] <= 0.2 * st["scale"] and ref["agent_err"] <= 0.2 * ref["scale"], (st["agent_err"], ref["agent_err"])

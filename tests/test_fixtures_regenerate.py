@@ -51,3 +51,15 @@ def test_reference_image_pins_round_trip(tmp_path):
         assert np.array_equal(np.rint(G.box_down(main_view, 10)).astype(np.uint8), fx["main80"]), name
         assert np.array_equal(G.non_box_mask(G.box_down(main_view, 5), 3), fx["mask160"]), name
         assert list(fx["hud_pos"]) == [hx, hz] and int(fx["hud_angle"]) == hang
+    for name, (task, args, (hx, hz), hang, fn, classes, keep) in G.ENT_CASES.items():   # the entity tasks' scenes
+        fx = np.load(os.path.join(GOLDEN, "refimg_%s.npz" % name))
+        im = np.asarray(Image.open(os.path.join(G.IMAGES, fn)).convert("RGB")).astype(np.float64)
+        main_view = im[G.MAIN]
+        assert np.array_equal(np.rint(G.box_down(main_view, 5)).astype(np.uint8), fx["main160"]), name
+        assert np.array_equal(np.rint(G.box_down(main_view, 10)).astype(np.uint8), fx["main80"]), name
+        assert np.array_equal(G.colour_mask(G.box_down(main_view, 5), classes, 3), fx["mask160"]), name
+        assert list(fx["hud_pos"]) == [hx, hz] and int(fx["hud_angle"]) == hang and str(fx["task"]) == task
+    fx = np.load(os.path.join(GOLDEN, "refimg_maze_top.npz"))   # maze_top_view.jpg: the two colour masks
+    mv = np.asarray(Image.open(os.path.join(G.IMAGES, "maze_top_view.jpg")).convert("RGB")).astype(np.float64)[G.MAIN]
+    assert np.array_equal(np.abs(mv - mv[5, 5]).max(axis=2) < 50, fx["sky_mask"])
+    assert np.array_equal((mv[..., 0] > mv[..., 1] + 60) & (mv[..., 0] > mv[..., 2] + 60), fx["red_mask"])

@@ -37,6 +37,29 @@ def test_hip_render_matches_the_reference_screenshot(name):
         RS.check(RS.stats(img, fx[key], fx[mkey], block), tol, "%s/%s" % (name, key))
 
 
+@pytest.mark.parametrize("name", RS.ENT_CASES)
+def test_hip_render_matches_the_reference_screenshots_of_the_entity_tasks(name):
+    """the entity tasks' scenes: rooms, the building, the cones, the ImageFrame - through mwb_set_state + mwb_render"""
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    fx = RS.load(name)
+    env_id, _, _, keep, _ = RS.ENT_CASES[name]
+    x, z, d = fx["fit_pose"]
+    bx, bz = RS.far_behind(fx)
+    for key, mkey, W, H, block, tol in RS.ent_views(name):
+        b = BatchedMiniWorld(env_id, num_envs=2, seed=1, obs_width=W, obs_height=H)
+        b.reset()
+        st = b.get_state()
+        pos, dirs = st["boxes_pos"].copy(), st["boxes_dir"].copy()
+        for k in range(b.n_boxes):
+            if RS.KIND_NAMES.get(int(st["ent_kind"][0, k]), "frame") not in keep:
+                pos[0, k] = [bx, 0.0, bz]
+                dirs[0, k] = 0.0
+        b.set_state(0, agent_pos=[[x, 0.0, z]] * 2, agent_dir=[d] * 2, boxes_pos=pos, boxes_dir=dirs)
+        img = b.render().cpu().numpy()[0]
+        b.close()
+        RS.check(RS.stats(img, fx[key], fx[mkey], block), tol, "%s/%s" % (name, key))
+
+
 def test_hip_box_face_colours_match_the_screenshots():
     fx = RS.load("hallway")
     x, z, d = fx["fit_pose"]

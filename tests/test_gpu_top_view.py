@@ -86,6 +86,25 @@ def test_hip_top_view_matches_the_reference_screenshot():
     TV.check_top_view_pin(TV.top_view_pin_stats(img, fx["top400"]))
 
 
+def test_hip_maze_top_view_frame_matches_the_reference_screenshot():
+    """images/maze_top_view.jpg through mwb_render_top_view: frame, cell pitch, gap width, the agent's triangle (layout-independent)"""
+    import math
+    import refimg_stats as RS
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    fx = np.load(os.path.join(TV.GOLD, "refimg_maze_top.npz"))
+    ref = RS.maze_top_stats(fx["sky_mask"], fx["red_mask"], fx["hud_pos"])
+    b = BatchedMiniWorld("MiniWorld-Maze-v0", num_envs=2, seed=1)
+    b.reset()
+    x, z = float(fx["hud_pos"][0]), float(fx["hud_pos"][1])
+    b.set_state(0, agent_pos=[[x, 0.0, z]] * 2, agent_dir=[math.radians(float(fx["hud_angle"]) + 0.5)] * 2)
+    imgs = b.render_top_view(800, 600).cpu().numpy().astype(np.float64)
+    b.close()
+    for t in imgs:
+        sky = np.abs(t - t[5, 5]).max(axis=2) < 50
+        red = (t[..., 0] > t[..., 1] + 60) & (t[..., 0] > t[..., 2] + 60)
+        RS.check_maze_top(RS.maze_top_stats(sky, red, fx["hud_pos"]), ref)
+
+
 @pytest.mark.parametrize("env_id,task,args", CASES)
 def test_visible_ents_matches_oracle(oracle_mod, env_id, task, args):
     """get_visible_ents (miniworld.py:1222-1315) through mwb_visible_ents against the oracle's restatement (itself equal to the

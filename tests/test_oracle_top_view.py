@@ -122,6 +122,25 @@ def test_top_view_matches_the_reference_screenshot(oracle_mod):
     check_top_view_pin(st)
 
 
+def test_maze_top_view_frame_matches_the_reference_screenshot(oracle_mod):
+    """images/maze_top_view.jpg: the layout is random, the frame is not - glOrtho extents, cell pitch, gap width, the agent's
+    triangle at the HUD position (tests/refimg_stats.maze_top_stats); two layouts of ours against the screenshot's"""
+    import math
+    import refimg_stats as RS
+    fx = np.load(os.path.join(GOLD, "refimg_maze_top.npz"))
+    ref = RS.maze_top_stats(fx["sky_mask"], fx["red_mask"], fx["hud_pos"])
+    for seed in (1, 2):
+        env = oracle_mod.OracleEnv("Maze", seed=seed)
+        env.reset(render=False)
+        env.set_agent(float(fx["hud_pos"][0]), float(fx["hud_pos"][1]), math.radians(float(fx["hud_angle"]) + 0.5))
+        t = env.render_top(800, 600).astype(np.float64)
+        sky = np.abs(t - t[5, 5]).max(axis=2) < 50
+        red = (t[..., 0] > t[..., 1] + 60) & (t[..., 0] > t[..., 2] + 60)
+        RS.check_maze_top(RS.maze_top_stats(sky, red, fx["hud_pos"]), ref)
+    # teeth: the same statistics with another cell pitch do not describe the screenshot
+    assert RS.maze_top_stats(fx["sky_mask"], fx["red_mask"], fx["hud_pos"], room=2.9, gap=0.35)["in_band"] < 0.6
+
+
 # ------------------------------------------------------------------------------------------- get_visible_ents
 VIS_STREAMS = [("PutNext", 0, "PutNext", None), ("PutNext", 1, "PutNext", None), ("TMazeTwoBoxFeatures", 1, "TMazeTwoBox", [1, 0, 0, 100000]),
                ("FourRooms", 0, "FourRooms", None), ("YMaze", 1, "YMaze", [0, 0, 0, 0]), ("Hallway", 1, "Hallway", None)]

@@ -33,6 +33,43 @@ def test_oracle_matches_the_reference_screenshot(oracle_mod, name):
         RS.check(RS.stats(img, fx[key], fx[mkey], block), tol, "%s/%s" % (name, key))
 
 
+@pytest.mark.parametrize("name", RS.ENT_CASES)
+def test_oracle_matches_the_reference_screenshots_of_the_entity_tasks(oracle_mod, name):
+    """rooms + what the task puts at fixed poses (Sidewalk's building and cones, WallGap's building, ThreeRooms' ImageFrame) against
+    pickupobjs_0 / collecthealth_0 / objects / sidewalk_0 / wallgap_0 .jpg; the randomly placed entities are out of view and masked"""
+    O = oracle_mod
+    fx = RS.load(name)
+    assert RS.pose_inside_hud_interval(fx)
+    _, task, args, keep, _ = RS.ENT_CASES[name]
+    for key, mkey, W, H, block, tol in RS.ent_views(name):
+        e = O.OracleEnv(task, seed=1, obs_width=W, obs_height=H, task_args=args)
+        e.reset(render=False)
+        s = e.state()
+        bx, bz = RS.far_behind(fx)
+        for k in range(s.n_boxes):
+            if RS.KIND_NAMES.get(int(s.ents_kind[k]), "frame") not in keep:
+                e.set_box(k, bx, bz, 0.0)
+        e.set_agent(*fx["fit_pose"])
+        RS.check(RS.stats(e.render_obs(), fx[key], fx[mkey], block), tol, "%s/%s" % (name, key))
+
+
+@pytest.mark.parametrize("name,stat,limit", [("objects", "block_max", 20.0), ("sidewalk", "block_max", 100.0), ("wallgap", "hp_corr", 0.3)])
+def test_entity_scene_pins_have_teeth(oracle_mod, name, stat, limit):
+    """negative control: with the ImageFrame / the building and the cones moved out of view as well, the statistics collapse"""
+    O = oracle_mod
+    fx = RS.load(name)
+    _, task, args, _, _ = RS.ENT_CASES[name]
+    key, mkey, W, H, block, tol = RS.ent_views(name)[0]
+    e = O.OracleEnv(task, seed=1, obs_width=W, obs_height=H, task_args=args)
+    e.reset(render=False)
+    bx, bz = RS.far_behind(fx)
+    for k in range(e.state().n_boxes):
+        e.set_box(k, bx, bz, 0.0)
+    e.set_agent(*fx["fit_pose"])
+    v = RS.stats(e.render_obs(), fx[key], fx[mkey], block)[stat]
+    assert (v < limit) if stat.endswith("corr") else (v > limit), (name, stat, v)
+
+
 def test_texture_statistic_has_teeth(oracle_mod):
     """negative control: with the wall and ceiling textures flipped the high-pass correlation collapses"""
     O = oracle_mod
