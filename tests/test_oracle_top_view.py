@@ -137,8 +137,8 @@ def test_maze_top_view_frame_matches_the_reference_screenshot(oracle_mod):
         sky = np.abs(t - t[5, 5]).max(axis=2) < 50
         red = (t[..., 0] > t[..., 1] + 60) & (t[..., 0] > t[..., 2] + 60)
         RS.check_maze_top(RS.maze_top_stats(sky, red, fx["hud_pos"]), ref)
-    # teeth: the same statistics with another cell pitch do not describe the screenshot
-    assert RS.maze_top_stats(fx["sky_mask"], fx["red_mask"], fx["hud_pos"], room=2.9, gap=0.35)["in_band"] < 0.6
+    # teeth: the same statistics with another cell count do not describe the screenshot
+    assert RS.maze_top_stats(fx["sky_mask"], fx["red_mask"], fx["hud_pos"], rows=7, cols=7, room=3.5, gap=0.25)["in_band"] < 0.6
 
 
 # ------------------------------------------------------------------------------------------- get_visible_ents
