@@ -705,7 +705,7 @@ static int step_impl(mwb_handle *h, const int32_t *actions_dev, const uint8_t *s
     TMARK(1);
     if (!h->overlap_reset) {
         TMARK(5);
-        mwb_launch_reset(h->dev, 512, s);
+        mwb_launch_reset(h->dev, 1024, s);
         rc = check_launch("reset_kernel"); if (rc) return rc;
         TMARK(6); TMARK(2);
         rc = render_tail(h, 0, s); if (rc) return rc;
@@ -717,7 +717,7 @@ static int step_impl(mwb_handle *h, const int32_t *actions_dev, const uint8_t *s
     HIP_TRY(hipEventRecord(h->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     if (h->timing_now) HIP_TRY(hipEventRecord(h->ev[5], h->side));
-    mwb_launch_reset(h->dev, 512, h->side);   // a handful of envs end per step - or all of them (mass time-out); started ahead of the bulk render
+    mwb_launch_reset(h->dev, 1024, h->side);   // a handful of envs end per step - or all of them (mass time-out); started ahead of the bulk render
     rc = check_launch("reset_kernel"); if (rc) return rc;
     if (h->timing_now) HIP_TRY(hipEventRecord(h->ev[6], h->side));
     mwb_launch_render(h->dev, 1, h->side);   // reset_kernel has prepared the frame constants of the envs it regenerated

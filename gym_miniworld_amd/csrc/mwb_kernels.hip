@@ -45,26 +45,32 @@ struct MtSerial {
     int pos;
     __device__ void load(uint32_t *st) { key = st; pos = (int)st[624]; }
     __device__ void store() { key[624] = (uint32_t)pos; }
-    __device__ uint32_t next32() {
+    __device__ __forceinline__ uint32_t next32() {
         if (pos == 624) {
             for (int i = 0; i < 624; i++) key[i] = mt_mix(key[i], key[(i + 1) % 624], key[(i + 397) % 624]);
             pos = 0;
         }
         return mt_temper(key[pos++]);
     }
-    __device__ double next_double() {
+    __device__ __forceinline__ double next_double() {
         uint32_t a = next32() >> 5, b = next32() >> 6;
         return (a * 67108864.0 + b) / 9007199254740992.0;
     }
-    __device__ double uniform(double lo, double hi) { double sc = hi - lo; return lo + sc * next_double(); }
+    __device__ __forceinline__ double uniform(double lo, double hi) { double sc = hi - lo; return lo + sc * next_double(); }
 };
 
 // wave-cooperative generator over a state staged in LDS (reset kernel): every lane carries the same
 // position and computes the same draw; the twist is done by all 64 lanes.
+// Pointers into LDS carry their address space in the type: the generator's state is reached through `this` in functions the compiler does
+// not inline, where a generic pointer would make every access a FLAT instruction (slower than ds_read, and counted as VMEM).
+#define LDS_AS __attribute__((address_space(3)))
+typedef LDS_AS double lds_f64;
+typedef LDS_AS int lds_i32;
+typedef LDS_AS uint32_t lds_u32;
 struct MtWave {
-    uint32_t *key;   // LDS, 624 words
+    lds_u32 *key;   // LDS, 624 words
     int pos, lane;
-    __device__ void twist() {
+    __device__ __forceinline__ void twist() {
         for (int base = 0; base < 624; base += WAVE) {
             int i = base + lane;
             uint32_t v = 0;
@@ -75,17 +81,17 @@ struct MtWave {
         }
         pos = 0;
     }
-    __device__ uint32_t next32() {
+    __device__ __forceinline__ uint32_t next32() {
         if (pos == 624) twist();
         return mt_temper(key[pos++]);
     }
-    __device__ double next_double() {
+    __device__ __forceinline__ double next_double() {
         uint32_t a = next32() >> 5, b = next32() >> 6;
         return (a * 67108864.0 + b) / 9007199254740992.0;
     }
-    __device__ double uniform(double lo, double hi) { double sc = hi - lo; return lo + sc * next_double(); }
+    __device__ __forceinline__ double uniform(double lo, double hi) { double sc = hi - lo; return lo + sc * next_double(); }
     // RandomState.randint(lo, hi): masked rejection on 32-bit words, no draw when the range is 1
-    __device__ int randint(int lo, int hi) {
+    __device__ __forceinline__ int randint(int lo, int hi) {
         uint32_t rng = (uint32_t)(hi - 1 - lo);
         if (rng == 0) return lo;
         uint32_t mask = rng;
@@ -98,7 +104,8 @@ struct MtWave {
 
 // ================================================================================== step kernel
 // circle vs wall segments, reference math.py:25-57 (strict <, y flattened)
-__device__ __forceinline__ bool seg_hit(const double *sg, double px, double pz, double radius) {
+template <class SegPtr>
+__device__ __forceinline__ bool seg_hit(SegPtr sg, double px, double pz, double radius) {
     double ax = sg[0], az = sg[1], bx = sg[2], bz = sg[3];
     double abx = bx - ax, abz = bz - az;
     double apx = px - ax, apz = pz - az;
@@ -646,11 +653,12 @@ struct alignas(16) WRoom {
     double height;
     double p_start[4], p_end[4], p_maxy[4];   // at most one portal per edge in the four tasks
     double min_x, max_x, min_z, max_z, area;
-    double edx[4], edz[4], elen[4];   // edge direction (p1 - p0) / norm and length, computed once
     int n_port[4], nbr[4];
     int tex_fam[3], tex_id[3];      // wall, floor, ceil
     int ne, pad_;                   // num_walls: 4, or 3 for YMaze's triangular hub
 };
+
+typedef LDS_AS WRoom LRoom;
 
 enum { TEXF_FLOOR_TILES_BW = 0, TEXF_CONCRETE, TEXF_CONCRETE_TILES, TEXF_BRICK_WALL,
        TEXF_CARDBOARD, TEXF_WOOD, TEXF_WOOD_PLANKS, TEXF_DRYWALL, TEXF_STUCCO, TEXF_CEILING_TILES,
@@ -660,18 +668,18 @@ __constant__ int c_texf_count[14] = {1, 4, 1, 1, 4, 2, 1, 1, 1, 1, 1, 1, 1, 1}; 
 
 
 struct WorldGen {
-    WRoom *rooms;
+    LRoom *rooms;
     int n_rooms;
-    double *cdf;
-    double *segs;     // LDS copy, S_max x 4
+    lds_f64 *cdf;
+    lds_f64 *segs;     // LDS copy, S_max x 4
     int n_segs;
-    int *seg_off;
+    lds_i32 *seg_off;
     MtWave rng;
     int lane;
     bool fail;
     // entity tasks: the entities placed so far (slot order = list order while the world is built), in LDS
-    double *ent_x, *ent_z, *ent_r;
-    int *ent_f32;
+    lds_f64 *ent_x, *ent_z, *ent_r;
+    lds_i32 *ent_f32;
     int n_placed;
     // the one wall that carries a SECOND portal (ThreeRooms: the big room's wall towards both small rooms).  WRoom keeps the
     // opening with the lower start_pos - Room.add_portal sorts the list, miniworld.py:214-215 - this record the other one.
@@ -679,8 +687,8 @@ struct WorldGen {
     double xp_start = 0, xp_end = 0, xp_maxy = 0;
 
     // Room.__init__, miniworld.py:75-138
-    __device__ int add_room(const double *ox, const double *oz, double height, int wall_fam, int floor_fam, int ceil_fam, int ne = 4) {
-        WRoom &r = rooms[n_rooms];
+    __device__ __forceinline__ int add_room(const double *ox, const double *oz, double height, int wall_fam, int floor_fam, int ceil_fam, int ne = 4) {
+        LRoom &r = rooms[n_rooms];
         double mnx = ox[0], mxx = ox[0], mnz = oz[0], mxz = oz[0];
         r.ne = ne;
         for (int i = 0; i < 4; i++) {
@@ -691,42 +699,46 @@ struct WorldGen {
         }
         r.min_x = mnx; r.max_x = mxx; r.min_z = mnz; r.max_z = mxz;
         r.area = (mxx - mnx) * (mxz - mnz);
-        for (int e = 0; e < 4; e++) {   // edge direction as Room.__init__ / add_portal compute it
-            const int e1 = e + 1 < ne ? e + 1 : 0;
-            double ex = r.ox[e1] - r.ox[e], ez = r.oz[e1] - r.oz[e];
-            double len = sqrt((ex * ex + 0.0) + ez * ez);
-            if (e >= ne) { ex = 1; ez = 0; len = 1; }
-            r.edx[e] = ex / len; r.edz[e] = ez / len; r.elen[e] = len;
-        }
         r.height = height;
         r.tex_fam[0] = wall_fam; r.tex_fam[1] = floor_fam; r.tex_fam[2] = ceil_fam;
         return n_rooms++;
     }
     // add_rect_room, miniworld.py:718-743
-    __device__ int add_rect_room(double min_x, double max_x, double min_z, double max_z, int wall_fam) {
+    __device__ __forceinline__ int add_rect_room(double min_x, double max_x, double min_z, double max_z, int wall_fam) {
         double ox[4] = {max_x, max_x, min_x, min_x}, oz[4] = {max_z, min_z, min_z, max_z};
         return add_room(ox, oz, 2.74, wall_fam, TEXF_FLOOR_TILES_BW, TEXF_CONCRETE_TILES);
     }
-    __device__ int add_rect_room_ex(double min_x, double max_x, double min_z, double max_z, int wall_fam, int floor_fam, int ceil_fam) {
+    __device__ __forceinline__ int add_rect_room_ex(double min_x, double max_x, double min_z, double max_z, int wall_fam, int floor_fam, int ceil_fam) {
         double ox[4] = {max_x, max_x, min_x, min_x}, oz[4] = {max_z, min_z, min_z, max_z};
         return add_room(ox, oz, 2.74, wall_fam, floor_fam, ceil_fam);
     }
     // edge direction as Room.__init__ / add_portal compute it: (p1 - p0) / norm
-    __device__ __forceinline__ void edge(const WRoom &r, int e, double &dx, double &dz, double &len) const {
-        dx = r.edx[e]; dz = r.edz[e]; len = r.elen[e];
+    // Not kept in the room record (96 B x 127 rooms of Maze: the difference between two and three workgroups per CU).  An axis-
+    // aligned edge needs no arithmetic: sqrt(fl(x * x)) == |x| and x / |x| == +-1 exactly, 0 / len keeps the zero's sign.
+    __device__ __forceinline__ void edge(const LRoom &r, int e, double &dx, double &dz, double &len) const {
+        if (e >= r.ne) { dx = 1; dz = 0; len = 1; return; }   // a triangle's unused 4th slot (never read as an edge)
+        const int e1 = e + 1 < r.ne ? e + 1 : 0;
+        const double ex = r.ox[e1] - r.ox[e], ez = r.oz[e1] - r.oz[e];
+        if (ez == 0.0 && ex != 0.0) { len = fabs(ex); dx = copysign(1.0, ex); dz = ez; return; }
+        if (ex == 0.0 && ez != 0.0) { len = fabs(ez); dz = copysign(1.0, ez); dx = ex; return; }
+        len = sqrt((ex * ex + 0.0) + ez * ez);
+        dx = ex / len; dz = ez / len;
     }
     // edge_norms = -cross(edge_dir, Y), normalised (miniworld.py:119-120): (dz, 0, -dx) / its norm - exactly (dz, -dx) for
     // the axis-aligned edges of the rectangle tasks, one more rounding for YMaze's rotated arms
-    __device__ __forceinline__ void edge_normal(const WRoom &r, int e, double &nx, double &nz) const {
-        const double ex = r.edz[e], ez = -r.edx[e];
+    __device__ __forceinline__ void edge_normal(const LRoom &r, int e, double &nx, double &nz) const {
+        double edx_, edz_, elen_;
+        edge(r, e, edx_, edz_, elen_);
+        const double ex = edz_, ez = -edx_;
+        if ((ex == 0.0 && fabs(ez) == 1.0) || (ez == 0.0 && fabs(ex) == 1.0)) { nx = ex; nz = ez; return; }   // norm 1: x / 1 == x
         const double nn = sqrt((ex * ex + 0.0) + ez * ez);
         nx = ex / nn; nz = ez / nn;
     }
     // Room.add_portal, miniworld.py:140-218; mode 0 start/end, 1 min_x/max_x, 2 min_z/max_z
     // returns the slot the opening went to: 0 the room's own record, 1 the second-portal record
-    __device__ int add_portal(int ri, int e, int mode, double a, double b, bool has_max_y, double max_y_in,
+    __device__ __forceinline__ int add_portal(int ri, int e, int mode, double a, double b, bool has_max_y, double max_y_in,
                               double &start, double &end) {
-        WRoom &r = rooms[ri];
+        LRoom &r = rooms[ri];
         double dx, dz, len;
         edge(r, e, dx, dz, len);
         if (mode == 1) {
@@ -756,11 +768,11 @@ struct WorldGen {
         xp_start = start; xp_end = end; xp_maxy = my; xp_nbr = -1;
         return 1;
     }
-    __device__ void set_nbr(int ri, int e, int slot, int nb) {
+    __device__ __forceinline__ void set_nbr(int ri, int e, int slot, int nb) {
         if (slot == 0) rooms[ri].nbr[e] = nb; else xp_nbr = nb;
     }
     // connect_rooms, miniworld.py:757-843
-    __device__ void connect_rooms(int ia, int ib, int mode, double lo, double hi, bool has_max_y, double max_y) {
+    __device__ __forceinline__ void connect_rooms(int ia, int ib, int mode, double lo, double hi, bool has_max_y, double max_y) {
         // find_facing_edges (miniworld.py:771-790): first (i, j) in i-major order whose inward normals face
         // each other and whose lines touch.  The 16 candidates are tested by 16 lanes; the lowest set
         // bit of the ballot is the pair the sequential loops would return.
@@ -784,7 +796,7 @@ struct WorldGen {
         double adx, adz, bdx, bdz, l;
         edge(rooms[ia], idx_a, adx, adz, l);
         edge(rooms[ib], idx_b, bdx, bdz, l);
-        const WRoom &A = rooms[ia], &B = rooms[ib];
+        const LRoom &A = rooms[ia], &B = rooms[ib];
         double a_x = A.ox[idx_a] + adx * sa, a_z = A.oz[idx_a] + adz * sa;
         double b_x = A.ox[idx_a] + adx * ea, b_z = A.oz[idx_a] + adz * ea;
         double c_x = B.ox[idx_b] + bdx * sb, c_z = B.oz[idx_b] + bdz * sb;
@@ -806,29 +818,60 @@ struct WorldGen {
         set_nbr(ia, idx_a, slot_a, ic); set_nbr(ib, idx_b, slot_b, ic);
         rooms[ic].nbr[1] = ia; rooms[ic].nbr[3] = ib;
     }
-    // numpy add.reduce pairwise summation (np.sum at miniworld.py:998)
-    __device__ double pairwise_area_sum(int first, int n) const {
+    // numpy add.reduce pairwise summation (np.sum at miniworld.py:998): up to 128 terms in eight interleaved partial sums ...
+    __device__ __forceinline__ double area_sum_block(int first, int n) const {
         if (n < 8) {
             double res = 0.;
             for (int i = 0; i < n; i++) res += rooms[first + i].area;
             return res;
-        } else if (n <= 128) {
-            double r[8];
-            for (int k = 0; k < 8; k++) r[k] = rooms[first + k].area;
-            int i;
-            for (i = 8; i < n - (n % 8); i += 8)
-                for (int k = 0; k < 8; k++) r[k] += rooms[first + i + k].area;
-            double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-            for (; i < n; i++) res += rooms[first + i].area;
-            return res;
-        } else {
-            int n2 = n / 2;
-            n2 -= n2 % 8;
-            return pairwise_area_sum(first, n2) + pairwise_area_sum(first + n2, n - n2);
         }
+        double r[8];
+        for (int k = 0; k < 8; k++) r[k] = rooms[first + k].area;
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; k++) r[k] += rooms[first + i + k].area;
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += rooms[first + i].area;
+        return res;
+    }
+    // ... above that the range is halved (left half rounded down to a multiple of 8) and the halves' sums are added, left + right.
+    // numpy recurses; here the pending ranges sit on a small explicit stack (a recursive member function would keep the whole
+    // generator in scratch memory: its `this` escapes).  Depth 8 covers 128 * 2^8 rooms.
+    __device__ __forceinline__ double pairwise_area_sum(int first, int n) const {
+        if (n <= 128) return area_sum_block(first, n);
+        int sf[9], sn[9], phase[9];
+        double left[9];
+        int sp = 0;
+        sf[0] = first; sn[0] = n; phase[0] = 0;
+        double ret = 0.0;
+        while (sp >= 0) {
+            if (sn[sp] <= 128) {   // a leaf: sum it and hand the value to the ranges waiting above
+                ret = area_sum_block(sf[sp], sn[sp]);
+                sp--;
+                while (sp >= 0) {
+                    if (phase[sp] == 1) {   // the left half is done: keep it, descend into the right half
+                        int n2 = sn[sp] / 2;
+                        n2 -= n2 % 8;
+                        left[sp] = ret; phase[sp] = 2;
+                        sf[sp + 1] = sf[sp] + n2; sn[sp + 1] = sn[sp] - n2; phase[sp + 1] = 0;
+                        sp++;
+                        break;
+                    }
+                    ret = left[sp] + ret;
+                    sp--;
+                }
+            } else {
+                int n2 = sn[sp] / 2;
+                n2 -= n2 % 8;
+                phase[sp] = 1;
+                sf[sp + 1] = sf[sp]; sn[sp + 1] = n2; phase[sp + 1] = 0;
+                sp++;
+            }
+        }
+        return ret;
     }
     // number of collidable segments edge e of room r produces (gen_seg_poly calls, miniworld.py:312-375)
-    __device__ int edge_segs(const WRoom &r, int e, double *out /* may be null */) const {
+    __device__ int edge_segs(const LRoom &r, int e, lds_f64 *out /* may be null */) const {
         double dx, dz, len;
         edge(r, e, dx, dz, len);
         int n = 0;
@@ -858,7 +901,7 @@ struct WorldGen {
         return cnt;
     }
     // MiniWorldEnv._gen_static_data, miniworld.py:981-998 (+ Room._gen_static_data 243-245, 311-375)
-    __device__ void gen_static_data(bool use_rng, int S_max) {
+    __device__ __forceinline__ void gen_static_data(bool use_rng, int S_max) {
         if (use_rng) {   // Texture.get, opengl.py:40-69: rng.int(0, n_variants) per room and slot, in order
             for (int i = 0; i < n_rooms; i++)
                 for (int k = 0; k < 3; k++) {
@@ -912,7 +955,7 @@ struct WorldGen {
         __syncthreads();
     }
     // MiniWorldEnv.intersect walls part, all lanes
-    __device__ bool walls_hit(double px, double pz, double radius) const {
+    __device__ __forceinline__ bool walls_hit(double px, double pz, double radius) const {
         bool h = false;
         for (int i = lane; i < n_segs; i += WAVE) h = h || seg_hit(segs + i * 4, px, pz, radius);
         return __any(h);
@@ -929,7 +972,7 @@ struct WorldGen {
         double other_r[MWB_MAX_BOXES] = {-1, -1, -1, -1, -1, -1};   // per-entity radii where given (>= 0), else the two above
         bool lds_ents = false, self_f32 = false;   // entity tasks: the others are WorldGen::ent_* [0, n_placed); radius is a float32 scalar
     };
-    __device__ void place_entity(double radius, bool has_other, double other_x, double other_z, double other_radius,
+    __device__ __forceinline__ void place_entity(double radius, bool has_other, double other_x, double other_z, double other_radius,
                                  bool has_dir, double dir_in, bool has_min_x, double min_x, bool has_max_x, double max_x,
                                  double &out_x, double &out_z, double &out_dir) {
         PlaceOpt o;
@@ -937,7 +980,7 @@ struct WorldGen {
         o.n_others = has_other ? 1 : 0; o.other_x[0] = other_x; o.other_z[0] = other_z; o.other_radius = other_radius;
         place_entity_ex(radius, o, out_x, out_z, out_dir);
     }
-    __device__ void place_entity_ex(double radius, const PlaceOpt &opt, double &out_x, double &out_z, double &out_dir) {
+    __device__ __forceinline__ void place_entity_ex(double radius, const PlaceOpt &opt, double &out_x, double &out_z, double &out_dir) {
         const bool has_dir = opt.has_dir;
         const double dir_in = opt.dir;
         for (int attempt = 0; attempt < 100000; attempt++) {
@@ -948,7 +991,7 @@ struct WorldGen {
                 lo = 0;
                 while (lo < hi) { int mid = (lo + hi) / 2; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
             }
-            const WRoom &r = rooms[lo < n_rooms ? lo : n_rooms - 1];
+            const LRoom &r = rooms[lo < n_rooms ? lo : n_rooms - 1];
             double lx = opt.has_min_x ? opt.min_x : r.min_x, hx = opt.has_max_x ? opt.max_x : r.max_x;
             double lz = opt.has_min_z ? opt.min_z : r.min_z, hz = opt.has_max_z ? opt.max_z : r.max_z;
             double px = rng.uniform(lx + radius, hx - radius);
@@ -1003,17 +1046,17 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     const int e = d.reset_list[li];
     __syncthreads();   // LDS is reused from the previous env of this block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    WRoom *rooms = (WRoom *)smem;
+    LRoom *rooms = (LRoom *)smem;
     size_t off = (size_t)d.R_max * sizeof(WRoom);
-    double *segs = (double *)(smem + off); off += (size_t)d.S_max * 4 * sizeof(double);
-    double *cdf = (double *)(smem + off); off += (size_t)d.R_max * sizeof(double);
-    int *seg_off = (int *)(smem + off); off += (size_t)((d.R_max + 3) & ~3) * sizeof(int);
-    uint32_t *key = (uint32_t *)(smem + off); off += 624 * sizeof(uint32_t);
+    lds_f64 *segs = (lds_f64 *)(smem + off); off += (size_t)d.S_max * 4 * sizeof(double);
+    lds_f64 *cdf = (lds_f64 *)(smem + off); off += (size_t)d.R_max * sizeof(double);
+    lds_i32 *seg_off = (lds_i32 *)(smem + off); off += (size_t)((d.R_max + 3) & ~3) * sizeof(int);
+    lds_u32 *key = (lds_u32 *)(smem + off); off += 624 * sizeof(uint32_t);
     // entity tasks: per slot x y z dir size radius height scale bias[3] (f64) and meta, radius-is-float32, colour index (i32); text textures
-    double *E_x = (double *)(smem + off), *E_y = E_x + MWB_MAX_ENTS, *E_z = E_y + MWB_MAX_ENTS, *E_dir = E_z + MWB_MAX_ENTS,
+    lds_f64 *E_x = (lds_f64 *)(smem + off), *E_y = E_x + MWB_MAX_ENTS, *E_z = E_y + MWB_MAX_ENTS, *E_dir = E_z + MWB_MAX_ENTS,
            *E_size = E_dir + MWB_MAX_ENTS, *E_rad = E_size + MWB_MAX_ENTS, *E_hgt = E_rad + MWB_MAX_ENTS, *E_scale = E_hgt + MWB_MAX_ENTS,
            *E_bias = E_scale + MWB_MAX_ENTS;
-    int *E_meta = (int *)(E_bias + 3 * MWB_MAX_ENTS), *E_f32 = E_meta + MWB_MAX_ENTS, *E_col = E_f32 + MWB_MAX_ENTS, *E_text = E_col + MWB_MAX_ENTS;
+    lds_i32 *E_meta = (lds_i32 *)(E_bias + 3 * MWB_MAX_ENTS), *E_f32 = E_meta + MWB_MAX_ENTS, *E_col = E_f32 + MWB_MAX_ENTS, *E_text = E_col + MWB_MAX_ENTS;
 
     uint32_t *st = d.rng + (size_t)e * MWB_MT_WORDS;
     for (int i = lane; i < 624; i += WAVE) key[i] = st[i];
@@ -1508,7 +1551,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     // A room whose outline runs the other way round (the connectors connect_rooms builds between YMaze's hub and arms:
     // miniworld.py:826 lists their corners clockwise there) has every polygon facing away from its inside - with back-face
     // culling on (miniworld.py:498-499) nothing of it is drawn.  Test: the "inward" normals point away from the centroid.
-    auto culled = [&](const WRoom &r) {
+    auto culled = [&](const LRoom &r) {
         double cx = 0, cz = 0, inward = 0;
         for (int k = 0; k < r.ne; k++) { cx += r.ox[k] / r.ne; cz += r.oz[k] / r.ne; }
         for (int k = 0; k < r.ne; k++) {
@@ -1519,7 +1562,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
         return inward < 0;
     };
     for (int ri = lane; d.poly && ri < w.n_rooms; ri += WAVE) {   // polygon room table (mwb_internal.h)
-        const WRoom &r = rooms[ri];
+        const LRoom &r = rooms[ri];
         float *o = grooms + (size_t)ri * MWB_POLY_ROOM_WORDS;
         const bool cull_r = culled(r);
         o[PW_HEIGHT] = d.no_ceiling ? -(float)r.height : (float)r.height;
@@ -1533,13 +1576,15 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
             if (k >= r.ne) continue;
             double nx, nz;
             w.edge_normal(r, k, nx, nz);
-            ed[0] = (float)r.ox[k]; ed[1] = (float)r.oz[k]; ed[2] = (float)r.edx[k]; ed[3] = (float)r.edz[k];
+            double edx_, edz_, elen_;
+            w.edge(r, k, edx_, edz_, elen_);
+            ed[0] = (float)r.ox[k]; ed[1] = (float)r.oz[k]; ed[2] = (float)edx_; ed[3] = (float)edz_;
             ed[4] = (float)nx; ed[5] = (float)nz;
             if (r.n_port[k]) {
                 ed[6] = (float)r.p_start[k]; ed[7] = (float)r.p_end[k]; ed[8] = (float)r.p_maxy[k];
                 int nb = r.nbr[k];
                 if (nb >= 0 && !cull_r && culled(rooms[nb])) {   // by-pass a culled connector: on to the room behind its other portal
-                    const WRoom &c = rooms[nb];
+                    const LRoom &c = rooms[nb];
                     int onward = -1;
                     for (int q = 0; q < c.ne; q++)
                         if (c.n_port[q] == 1 && c.nbr[q] != ri) onward = c.nbr[q];
@@ -1559,9 +1604,11 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     float cut = 0.0f, c_first[3] = {0, 0, 0}, c_second[3] = {0, 0, 0};   // lo hi max_y of the opening at the lower / higher coordinate
     int c_nbr[2] = {-1, -1};
     if (!d.poly && w.xp_room >= 0) {
-        const WRoom &r = rooms[w.xp_room];
+        const LRoom &r = rooms[w.xp_room];
         const int ed = w.xp_edge;
-        const double dx = r.edx[ed], dz = r.edz[ed], nx = dz, nz = -dx;
+        double dx, dz, elen_;
+        w.edge(r, ed, dx, dz, elen_);
+        const double nx = dz, nz = -dx;
         cut_room = w.xp_room;
         cut_s = (nx == -1 && nz == 0) ? 0 : (nx == 0 && nz == 1) ? 1 : (nx == 1 && nz == 0) ? 2 : 3;
         const bool along_z = (cut_s == 0 || cut_s == 2);
@@ -1581,7 +1628,7 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     }
     if (lane == 0) d.n_rrooms[e] = w.fail ? -1 : n_rrooms;
     for (int ri = lane; !d.poly && ri < w.n_rooms; ri += WAVE) {
-        const WRoom &r = rooms[ri];
+        const LRoom &r = rooms[ri];
         float *o = grooms + (size_t)ri * MWB_ROOM_WORDS;
         o[RW_MINX] = (float)r.min_x; o[RW_MAXX] = (float)r.max_x; o[RW_MINZ] = (float)r.min_z; o[RW_MAXZ] = (float)r.max_z;
         o[RW_HEIGHT] = d.no_ceiling ? -(float)r.height : (float)r.height;   // negative: no ceiling polygon (trace_rooms)
