@@ -312,7 +312,7 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
 #define A(ptr, n) if (rc == MWB_OK) rc = dev_alloc(h, &(ptr), (n))
     A(d.agent_x, N); A(d.agent_z, N); A(d.agent_dir, N); A(d.box_x, N * d.n_boxes); A(d.box_z, N * d.n_boxes); A(d.box_y, N * d.n_boxes); A(d.box_dir, N * d.n_boxes); A(d.carrying, N);
     A(d.box_color, N * d.n_boxes * 3); A(d.box_size, N * d.n_boxes); A(d.goal_dist, N); A(d.episode_count, N); A(d.task_step_count, N); A(d.goal_idx, N); A(d.cam, N * 4); A(d.sky_color, N * 3); A(d.light_pos, N * 3); A(d.light_color, N * 3); A(d.light_ambient, N * 3);
-    A(d.step_count, N); A(d.n_rooms, N); A(d.n_rrooms, N); A(d.n_segs, N); A(d.reset_set, N); A(d.reset_list, N); A(d.reset_count, (size_t)1);
+    A(d.step_count, N); A(d.n_rooms, N); A(d.n_rrooms, N); A(d.seg_stage, (size_t)MWB_RESET_MAX_BLOCKS * d.S_max * 4); A(d.n_segs, N); A(d.reset_set, N); A(d.reset_list, N); A(d.reset_count, (size_t)1);
     if (d.ent_task) {
         A(d.ent_meta, N * d.n_boxes); A(d.ent_radius, N * d.n_boxes); A(d.ent_height, N * d.n_boxes); A(d.ent_scale, N * d.n_boxes);
         A(d.ent_order, N * MWB_ORDER_STRIDE); A(d.n_order, N); A(d.task_f, N); A(d.task_i, N); A(d.text_tex, N * 8);
@@ -670,7 +670,7 @@ extern "C" int mwb_reset(mwb_handle *h, const uint8_t *mask_dev, void *stream) {
     mwb_launch_mark_reset(h->dev, mask_dev, s);
     rc = check_launch("mark_reset_kernel"); if (rc) return rc;
     TMARK(1); TMARK(5);
-    mwb_launch_reset(h->dev, 4096, s);   // possibly every env: many blocks
+    mwb_launch_reset(h->dev, MWB_RESET_MAX_BLOCKS, s);   // possibly every env: many blocks
     rc = check_launch("reset_kernel"); if (rc) return rc;
     TMARK(6); TMARK(2);
     rc = render_tail(h, 0, s); if (rc) return rc;

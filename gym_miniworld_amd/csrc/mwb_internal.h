@@ -19,6 +19,7 @@
 #define MWB_MAX_TEX MWB_NUM_TEXTURES
 #define MWB_MAX_LEVELS 12
 #define MWB_MAX_BOXES 6   // box-only tasks (templated step / render kernels); entity tasks: MWB_MAX_ENTS slots
+#define MWB_RESET_MAX_BLOCKS 4096   // largest grid reset_kernel is launched with
 #define MWB_ENT_AGENT 255 // the agent's entry in an env's entity order list
 #define MWB_ORDER_STRIDE 24   // bytes per env of d.ent_order (MWB_MAX_ENTS + 1 entries, padded)
 // frame constants: 36 fixed words, then one block of FC_BOX_STRIDE words per box; d.frame_words = that, rounded up to 4
@@ -160,6 +161,7 @@ struct MwbDev {
     double *cam;            // [N][4] height, fwd_disp, pitch, fov_y
     double *sky_color, *light_pos, *light_color, *light_ambient;   // [N][3]
     int32_t *step_count, *n_rooms, *n_segs;
+    double *seg_stage;   // reset_kernel's staging of an env's collision segments, MWB_RESET_MAX_BLOCKS x S_max x 4 (one row set per block)
     int32_t *n_rrooms;   // records in the env's room table: n_rooms, + 1 where a room with two openings on one wall was cut in two (reset_kernel)
     int32_t *error_flag;    // [1] set by reset_kernel when world generation hits a condition the reference asserts on
     uint8_t *reset_set;     // which envs are (re)generated in the current pass (set by step / mark_reset)

@@ -671,7 +671,7 @@ struct WorldGen {
     LRoom *rooms;
     int n_rooms;
     lds_f64 *cdf;
-    lds_f64 *segs;     // LDS copy, S_max x 4
+    double *segs;      // this block's staging rows in HBM (d.seg_stage), S_max x 4: read lane-parallel by walls_hit, transposed into d.segs at the end
     int n_segs;
     lds_i32 *seg_off;
     MtWave rng;
@@ -871,7 +871,7 @@ struct WorldGen {
         return ret;
     }
     // number of collidable segments edge e of room r produces (gen_seg_poly calls, miniworld.py:312-375)
-    __device__ int edge_segs(const LRoom &r, int e, lds_f64 *out /* may be null */) const {
+    __device__ int edge_segs(const LRoom &r, int e, double *out /* may be null */) const {
         double dx, dz, len;
         edge(r, e, dx, dz, len);
         int n = 0;
@@ -1048,15 +1048,19 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LRoom *rooms = (LRoom *)smem;
     size_t off = (size_t)d.R_max * sizeof(WRoom);
-    lds_f64 *segs = (lds_f64 *)(smem + off); off += (size_t)d.S_max * 4 * sizeof(double);
     lds_f64 *cdf = (lds_f64 *)(smem + off); off += (size_t)d.R_max * sizeof(double);
     lds_i32 *seg_off = (lds_i32 *)(smem + off); off += (size_t)((d.R_max + 3) & ~3) * sizeof(int);
     lds_u32 *key = (lds_u32 *)(smem + off); off += 624 * sizeof(uint32_t);
-    // entity tasks: per slot x y z dir size radius height scale bias[3] (f64) and meta, radius-is-float32, colour index (i32); text textures
+    // Maze: the frames of the depth-first search (3 ints per cell + 1) and the visited flags; entity tasks: per slot x y z dir size
+    // radius height scale bias[3] (f64) and meta, radius-is-float32, colour index (i32), text textures.  (mwb_reset_lds_bytes)
+    lds_i32 *dfs = (lds_i32 *)(smem + off);
     lds_f64 *E_x = (lds_f64 *)(smem + off), *E_y = E_x + MWB_MAX_ENTS, *E_z = E_y + MWB_MAX_ENTS, *E_dir = E_z + MWB_MAX_ENTS,
            *E_size = E_dir + MWB_MAX_ENTS, *E_rad = E_size + MWB_MAX_ENTS, *E_hgt = E_rad + MWB_MAX_ENTS, *E_scale = E_hgt + MWB_MAX_ENTS,
            *E_bias = E_scale + MWB_MAX_ENTS;
     lds_i32 *E_meta = (lds_i32 *)(E_bias + 3 * MWB_MAX_ENTS), *E_f32 = E_meta + MWB_MAX_ENTS, *E_col = E_f32 + MWB_MAX_ENTS, *E_text = E_col + MWB_MAX_ENTS;
+    // The collision segments are staged in HBM, one row set per block (8 KB of Maze's LDS: the difference between three and four
+    // workgroups per CU); the placement loop reads them lane-parallel, coalesced, out of L1 / L2.
+    double *segs = d.seg_stage + (size_t)blockIdx.x * d.S_max * 4;
 
     uint32_t *st = d.rng + (size_t)e * MWB_MT_WORDS;
     for (int i = lane; i < 624; i += WAVE) key[i] = st[i];
@@ -1404,9 +1408,9 @@ __global__ void __launch_bounds__(WAVE) reset_kernel(MwbDev d) {
                 double min_z = j * (room_size + gap), max_z = min_z + room_size;
                 w.add_rect_room(min_x, max_x, min_z, max_z, TEXF_BRICK_WALL);
             }
-        // DFS frames live in the (not yet used) segment buffer: cell, packed neighbour order, next index
-        int *stack = (int *)segs;
-        uint8_t *visited = (uint8_t *)(stack + 3 * (num_rows * num_cols + 1));
+        // DFS frames: cell, packed neighbour order, next index
+        lds_i32 *stack = dfs;
+        LDS_AS uint8_t *visited = (LDS_AS uint8_t *)(stack + 3 * (num_rows * num_cols + 1));
         for (int i = 0; i < num_rows * num_cols; i++) visited[i] = 0;
         __syncthreads();
         int sp = 0;
@@ -3535,9 +3539,9 @@ __global__ void intersect_kernel(MwbDev d, int e, int ent, double x, double z, d
 // ====================================================================================== launch
 #define RENDER_THREADS 256
 size_t mwb_reset_lds_bytes(const MwbDev &d) {
-    size_t b = (size_t)d.R_max * sizeof(WRoom) + (size_t)d.S_max * 4 * sizeof(double) + (size_t)d.R_max * sizeof(double) +
-               (size_t)((d.R_max + 3) & ~3) * sizeof(int) + 624 * sizeof(uint32_t) +
-               (size_t)MWB_MAX_ENTS * (11 * sizeof(double) + 3 * sizeof(int)) + 8 * sizeof(int);   // the entity tasks' slot records
+    size_t b = (size_t)d.R_max * sizeof(WRoom) + (size_t)d.R_max * sizeof(double) + (size_t)((d.R_max + 3) & ~3) * sizeof(int) + 624 * sizeof(uint32_t);
+    if (d.ent_task) b += (size_t)MWB_MAX_ENTS * (11 * sizeof(double) + 3 * sizeof(int)) + 8 * sizeof(int);   // the entity tasks' slot records
+    if (d.task == MWB_TASK_MAZE) b += (size_t)(d.R_max + 1) / 2 * 13 + 16;   // rows * cols cells: 3 ints + 1 flag each, one frame more
     return (b + 15) & ~(size_t)15;
 }
 static size_t render_lds_bytes_for(const MwbDev &d, int W, int H) {
