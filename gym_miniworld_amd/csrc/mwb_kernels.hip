@@ -667,6 +667,15 @@ __constant__ int c_texf_first[14] = {0, 1, 5, 6, 7, 11, 13, 14, 15, 16, 17, 18, 
 __constant__ int c_texf_count[14] = {1, 4, 1, 1, 4, 2, 1, 1, 1, 1, 1, 1, 1, 1};   // <name>_<i>.png variants, opengl.py:50-58
 
 
+// |(x, z)| as numpy's norm of (x, 0, z) gives it, sqrt((x x + 0) + z z); an axis-aligned vector needs no arithmetic: sqrt(fl(x x)) == |x|
+__device__ __forceinline__ double norm_xz(double x, double z) {
+    if (z == 0.0) return fabs(x);
+    if (x == 0.0) return fabs(z);
+    return sqrt((x * x + 0.0) + z * z);
+}
+// q / d where d is very often exactly +-1 (an axis-aligned edge direction): q / +-1 == q * +-1
+__device__ __forceinline__ double div_unit(double q, double d) { return fabs(d) == 1.0 ? q * d : q / d; }
+
 struct WorldGen {
     LRoom *rooms;
     int n_rooms;
@@ -742,11 +751,11 @@ struct WorldGen {
         double dx, dz, len;
         edge(r, e, dx, dz, len);
         if (mode == 1) {
-            double m0 = (a - r.ox[e]) / dx, m1 = (b - r.ox[e]) / dx;
+            double m0 = div_unit(a - r.ox[e], dx), m1 = div_unit(b - r.ox[e], dx);
             if (m1 < m0) { double t = m0; m0 = m1; m1 = t; }
             start = m0; end = m1;
         } else if (mode == 2) {
-            double m0 = (a - r.oz[e]) / dz, m1 = (b - r.oz[e]) / dz;
+            double m0 = div_unit(a - r.oz[e], dz), m1 = div_unit(b - r.oz[e], dz);
             if (m1 < m0) { double t = m0; m0 = m1; m1 = t; }
             start = m0; end = m1;
         } else { start = a; end = b; }
@@ -802,12 +811,12 @@ struct WorldGen {
         double c_x = B.ox[idx_b] + bdx * sb, c_z = B.oz[idx_b] + bdz * sb;
         double d_x = B.ox[idx_b] + bdx * eb, d_z = B.oz[idx_b] + bdz * eb;
         double adx_ = a_x - d_x, adz_ = a_z - d_z;
-        if (sqrt(adx_ * adx_ + 0.0 + adz_ * adz_) < 0.001) {   // portals directly connected
+        if (norm_xz(adx_, adz_) < 0.001) {   // portals directly connected
             set_nbr(ia, idx_a, slot_a, ib); set_nbr(ib, idx_b, slot_b, ia);
             return;
         }
-        double len_a = sqrt((b_x - a_x) * (b_x - a_x) + 0.0 + (b_z - a_z) * (b_z - a_z));
-        double len_b = sqrt((d_x - c_x) * (d_x - c_x) + 0.0 + (d_z - c_z) * (d_z - c_z));
+        double len_a = norm_xz(b_x - a_x, b_z - a_z);
+        double len_b = norm_xz(d_x - c_x, d_z - c_z);
         double ox[4] = {c_x, b_x, a_x, d_x}, oz[4] = {c_z, b_z, a_z, d_z};
         double my = has_max_y ? max_y : A.height;
         int wf = A.tex_fam[0], ff = A.tex_fam[1], cf = A.tex_fam[2];
