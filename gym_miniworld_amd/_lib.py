@@ -91,7 +91,7 @@ def load():
     L.mwb_create.argtypes = [ctypes.POINTER(MwbConfig), ctypes.POINTER(vp)]
     L.mwb_destroy.argtypes = [vp]
     L.mwb_set_texture.argtypes = [vp, i32, i32, i32, vp]
-    L.mwb_set_mesh.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp]
+    L.mwb_set_mesh.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp]
     L.mwb_set_mesh_dims.argtypes = [vp, i32, ctypes.c_double, ctypes.c_double, ctypes.c_double, i32]
     L.mwb_seed.argtypes = [vp, vp]
     L.mwb_reset.argtypes = [vp, vp, vp]

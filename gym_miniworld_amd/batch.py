@@ -216,14 +216,16 @@ class BatchedMiniWorld:
             m = M.get(name)
             if geom not in done:
                 done.add(geom)
-                nodes, perm = M.build_bvh(m.verts)
+                octants = os.environ.get("MWB_BVH_OCTANTS", "1") != "0"   # 0: one threading for every ray direction (A/B timing)
+                nodes, perm = M.build_bvh(m.verts, octants=octants)
+                n_orders = 8 if octants else 1
                 tex = TEX_FILES.index("../meshes/" + geom) if m.chunks[0][2] is not None else -1
                 assert len(m.chunks) == 1, "one material per mesh"
                 arrs = [np.ascontiguousarray(a, np.float32) for a in (m.verts, m.norms, m.texcs, m.min_coords, m.max_coords, nodes)]
                 perm = np.ascontiguousarray(perm, np.int32)
                 _lib.check(self.L.mwb_set_mesh(self.h, _lib.MESH_GEOMS.index(geom), m.n_tris, arrs[0].ctypes.data_as(vp), arrs[1].ctypes.data_as(vp),
                                                arrs[2].ctypes.data_as(vp), tex, arrs[3].ctypes.data_as(vp), arrs[4].ctypes.data_as(vp),
-                                               nodes.shape[0], arrs[5].ctypes.data_as(vp), perm.ctypes.data_as(vp)))
+                                               nodes.shape[0] // n_orders, n_orders, arrs[5].ctypes.data_as(vp), perm.ctypes.data_as(vp)))
             scale, radius = M.mesh_ent_dims(name, height)
             _lib.check(self.L.mwb_set_mesh_dims(self.h, _lib.MESH_GEOMS.index(geom), float(height), float(scale), float(radius),
                                                 int(isinstance(radius, np.float32))))

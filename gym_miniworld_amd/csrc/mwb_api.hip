@@ -70,7 +70,7 @@ struct mwb_handle {
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
     // entity tasks: mesh geometries (host copies until the first pass uploads them in one allocation)
-    struct HostMesh { bool set = false; int n_tris = 0, n_nodes = 0, tex_id = -1; float min_c[3], max_c[3]; std::vector<float> nodes, tris, tris2, shade; };
+    struct HostMesh { bool set = false; int n_tris = 0, n_nodes = 0, n_orders = 1, tex_id = -1; float min_c[3], max_c[3]; std::vector<float> nodes, tris, tris2, shade; };
     HostMesh meshes[MWB_NUM_MESHES];
     bool meshes_dirty;
     float4 *mesh_data_dev;
@@ -487,15 +487,16 @@ static int upload_textures(mwb_handle *h) {
 
 // -------------------------------------------------------------------------------------- meshes
 extern "C" int mwb_set_mesh(mwb_handle *h, int geom, int n_tris, const float *verts, const float *norms, const float *texcs, int tex_slot,
-                            const float *min_coords, const float *max_coords, int n_nodes, const float *nodes, const int32_t *perm) {
+                            const float *min_coords, const float *max_coords, int n_nodes, int n_orders, const float *nodes, const int32_t *perm) {
     if (!h || !verts || !norms || !texcs || !min_coords || !max_coords || !nodes || !perm) return set_err(MWB_EINVAL, "mwb_set_mesh: null argument");
-    if (geom < 0 || geom >= MWB_NUM_MESHES || n_tris <= 0 || n_tris >= (1 << 24) || n_nodes <= 0 || tex_slot >= MWB_MAX_TEX)
+    if (geom < 0 || geom >= MWB_NUM_MESHES || n_tris <= 0 || n_tris >= (1 << 24) || n_nodes <= 0 || tex_slot >= MWB_MAX_TEX || (n_orders != 1 && n_orders != 8))
         return set_err(MWB_EINVAL, "mwb_set_mesh: bad geometry id / sizes");
-    {   // the hierarchy is walked by a kernel: every link must stay inside the arrays and move forward (the walk terminates)
+    for (int ord = 0; ord < n_orders; ord++) {   // the hierarchy is walked by a kernel: every link must stay inside the arrays and move forward (the walk terminates)
         std::vector<char> seen((size_t)n_tris, 0);
+        const float *on = nodes + (size_t)ord * n_nodes * 8;
         for (int i = 0; i < n_nodes; i++) {
             int32_t skip, fc;
-            memcpy(&skip, nodes + (size_t)i * 8 + 3, 4); memcpy(&fc, nodes + (size_t)i * 8 + 7, 4);
+            memcpy(&skip, on + (size_t)i * 8 + 3, 4); memcpy(&fc, on + (size_t)i * 8 + 7, 4);
             const int cnt = (int)((uint32_t)fc >> 24), first = (int)((uint32_t)fc & 0xFFFFFFu);
             if (skip <= i || skip > n_nodes || first + cnt > n_tris || (cnt == 0 && i + 1 >= n_nodes))
                 return set_err(MWB_EINVAL, "mwb_set_mesh: malformed hierarchy");
@@ -505,9 +506,9 @@ extern "C" int mwb_set_mesh(mwb_handle *h, int geom, int n_tris, const float *ve
             if (!seen[i] || perm[i] < 0 || perm[i] >= n_tris) return set_err(MWB_EINVAL, "mwb_set_mesh: the leaves must cover every triangle once");
     }
     mwb_handle::HostMesh &m = h->meshes[geom];
-    m.set = true; m.n_tris = n_tris; m.n_nodes = n_nodes; m.tex_id = tex_slot;
+    m.set = true; m.n_tris = n_tris; m.n_nodes = n_nodes; m.n_orders = n_orders; m.tex_id = tex_slot;
     for (int k = 0; k < 3; k++) { m.min_c[k] = min_coords[k]; m.max_c[k] = max_coords[k]; }
-    m.nodes.assign(nodes, nodes + (size_t)n_nodes * 8);
+    m.nodes.assign(nodes, nodes + (size_t)n_orders * n_nodes * 8);
     auto rec = [&](int tri, float *o) {   // v0.xyz e1.x | e1.yz e2.xy | e2.z idx 0 0 with e1 = v1 - v0, e2 = v2 - v0 in float32
         const float *v = verts + (size_t)tri * 9;
         const float e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
@@ -569,7 +570,7 @@ static int upload_meshes(mwb_handle *h) {   // the caller holds the device guard
     for (int g = 0; g < MWB_NUM_MESHES; g++) {
         const mwb_handle::HostMesh &m = h->meshes[g];
         if (!m.set) continue;
-        desc[g].n_tris = m.n_tris; desc[g].n_nodes = m.n_nodes; desc[g].tex_id = m.tex_id;
+        desc[g].n_tris = m.n_tris; desc[g].n_nodes = m.n_nodes; desc[g].tex_id = m.tex_id; desc[g].n_orders = m.n_orders;
         for (int k = 0; k < 3; k++) { desc[g].min_c[k] = m.min_c[k]; desc[g].max_c[k] = m.max_c[k]; }
         desc[g].node_off = (uint32_t)(all.size() / 4); all.insert(all.end(), m.nodes.begin(), m.nodes.end());
         desc[g].tri_off = (uint32_t)(all.size() / 4); all.insert(all.end(), m.tris.begin(), m.tris.end());

@@ -116,7 +116,8 @@
 // (3 float4: v0.xyz e1.x | e1.yz e2.xy | e2.z, original index (int bits), 0, 0) and shading records by ORIGINAL index
 // (4 float4: n0.xyz n1.x | n1.yz n2.xy | n2.z tc0.st tc1.s | tc1.t tc2.st 0)
 struct MwbMeshDesc {
-    int n_tris, n_nodes, tex_id, pad;
+    int n_tris, n_nodes, tex_id;
+    int n_orders;   // threadings of the hierarchy stored one after the other at node_off: 1, or 8 = one per sign pattern of the ray direction
     uint32_t node_off, tri_off, shade_off, tri2_off;   // float4 offsets into d.mesh_data; tri2 = the triangle records by ORIGINAL index (shading)
     float min_c[4], max_c[4];
 };

@@ -2469,7 +2469,9 @@ struct RenderCtx {
                     inv[0] = __builtin_amdgcn_rcpf(ld[0]); inv[1] = __builtin_amdgcn_rcpf(ld[1]); inv[2] = __builtin_amdgcn_rcpf(ld[2]);
                     const int geom = __float_as_int(blk[FC_LIT_BOX + FE_MESH_GEOM]);
                     const MwbMeshDesc &md = mesh_desc[geom];
-                    nodes = gd + md.node_off; tris = gd + md.tri_off; n_nodes = md.n_nodes;
+                    // the threading that visits the nearer child first for this ray's direction (bit a: component a negative)
+                    const int oct = md.n_orders == 8 ? ((ld[0] < 0.0f ? 1 : 0) | (ld[1] < 0.0f ? 2 : 0) | (ld[2] < 0.0f ? 4 : 0)) : 0;
+                    nodes = gd + md.node_off + (size_t)oct * 2u * (uint32_t)md.n_nodes; tris = gd + md.tri_off; n_nodes = md.n_nodes;
                     c_walks++;
                     continue;
                 }

@@ -143,31 +143,35 @@ def mesh_ent_dims(mesh_name, height):
 
 
 # ------------------------------------------------------------------------------------------------------------ BVH
-def build_bvh(verts, leaf_size=4):
+def build_bvh(verts, leaf_size=4, octants=True):
     """Threaded (stackless) BVH over the triangles [F, 3, 3] float32 for the render kernel: nodes in depth-first order,
     node i = (lo[3], hi[3], skip, first, count): an inner node's first child is node i + 1, `skip` is where to go when the
     box is missed (or after a leaf); a leaf lists triangles perm[first : first + count].  Splits by the surface-area heuristic
     (a median split costs 2.6x the node visits on the building's long facade triangles).  Boxes are inflated by 1e-4 of
     the mesh's extent so that the float32 slab test never rejects a ray that meets one of the box's triangles.
-    -> (nodes float32 [M, 8], ints stored as bit patterns; perm int32 [F]: leaf order -> triangle index in draw order)"""
+    A threaded hierarchy fixes the order in which the children of a node are visited; with octants=True EIGHT threadings of the
+    same tree are returned, one per sign pattern of the ray direction (bit a set: the direction's component a is negative): in
+    threading k the child nearer along the split axis comes first, so that a hit found early culls what lies behind it.
+    -> (nodes float32 [K * M, 8] with K = 8 or 1, ints stored as bit patterns; perm int32 [F]: leaf order -> triangle index in
+    draw order, the same for every threading)"""
     F = verts.shape[0]
     v = verts.astype(np.float64)
     tlo, thi = v.min(axis=1), v.max(axis=1)
     cen = (tlo + thi) / 2
     pad = 1e-4 * float(max(1e-6, (v.max() - v.min())))
-    nodes, order = [], []
+    tree, order = [], []   # tree[i] = [lo, hi, first, count, axis, left, right]
 
     def area(lo, hi):
         dd = hi - lo
         return 2.0 * (dd[..., 0] * dd[..., 1] + dd[..., 1] * dd[..., 2] + dd[..., 0] * dd[..., 2])
 
     def rec(idx):
-        me = len(nodes)
+        me = len(tree)
         lo, hi = tlo[idx].min(axis=0) - pad, thi[idx].max(axis=0) + pad
-        nodes.append([lo, hi, -1, 0, 0])
+        tree.append([lo, hi, 0, 0, -1, -1, -1])
         n = len(idx)
         if n <= leaf_size:
-            nodes[me][3], nodes[me][4] = len(order), n
+            tree[me][2], tree[me][3] = len(order), n
             order.extend(int(i) for i in idx)
         else:   # surface-area heuristic over the three centroid orders (full sweep: the meshes are a few thousand triangles)
             best = None
@@ -179,18 +183,42 @@ def build_bvh(verts, leaf_size=4):
                 cost = area(plo[:-1], phi[:-1]) * k + area(slo[1:], shi[1:]) * (n - k)
                 j = int(np.argmin(cost))
                 if best is None or cost[j] < best[0]:
-                    best = (float(cost[j]), srt, j + 1)
-            _, srt, cut = best
-            rec(srt[:cut])
-            rec(srt[cut:])
-        nodes[me][2] = len(nodes)   # next node in depth-first order after this subtree
+                    best = (float(cost[j]), srt, j + 1, ax)
+            _, srt, cut, ax = best
+            tree[me][4] = ax
+            tree[me][5] = rec(srt[:cut])    # the child at the lower coordinates of the split axis
+            tree[me][6] = rec(srt[cut:])
+        return me
     rec(np.arange(F))
-    M = len(nodes)
-    out = np.zeros((M, 8), np.float32)   # lo.x lo.y lo.z skip | hi.x hi.y hi.z first | count << 24   (32 B per node)
+    M = len(tree)
+    K = 8 if octants else 1
+    out = np.zeros((K * M, 8), np.float32)   # lo.x lo.y lo.z skip | hi.x hi.y hi.z first | count << 24   (32 B per node)
     ints = out.view(np.int32)
-    for i, (lo, hi, skip, first, count) in enumerate(nodes):
-        out[i, 0:3] = np.nextafter(lo.astype(np.float32), np.float32(-np.inf))
-        out[i, 4:7] = np.nextafter(hi.astype(np.float32), np.float32(np.inf))
-        ints[i, 3] = skip
-        ints[i, 7] = first | (count << 24)
+    for k in range(K):
+        base = k * M
+        pos = 0
+        stack = [0]
+        rows = []   # (row, tree index); skip = the row after the node's subtree, filled when the subtree is complete
+        ends = {}
+
+        def emit(t):
+            nonlocal pos
+            row = pos
+            pos += 1
+            lo, hi, first, count, ax, left, right = tree[t]
+            out[base + row, 0:3] = np.nextafter(lo.astype(np.float32), np.float32(-np.inf))
+            out[base + row, 4:7] = np.nextafter(hi.astype(np.float32), np.float32(np.inf))
+            ints[base + row, 7] = first | (count << 24)
+            if ax >= 0:
+                near_first = (left, right) if not (k >> ax) & 1 else (right, left)
+                for c in near_first:
+                    emit(c)
+            ints[base + row, 3] = pos   # next node in depth-first order after this subtree
+        import sys
+        lim = sys.getrecursionlimit()
+        sys.setrecursionlimit(max(lim, 10000))
+        try:
+            emit(0)
+        finally:
+            sys.setrecursionlimit(lim)
     return out, np.asarray(order, np.int32)

@@ -208,12 +208,14 @@ int mwb_num_textures(mwb_handle *h);   /* how many leading slots the handle's ta
 /* replaces: ObjMesh.get / ObjMesh.__init__ (objmesh.py:16-216) for one mesh geometry, shared by all envs of the handle: the
  * triangle soup as the reference hands it to OpenGL - verts / norms float32 [n_tris][3][3], texcs [n_tris][3][2], in draw order -
  * its extents (ObjMesh.min_coords / max_coords), the texture slot of its image (-1 none) and a threaded bounding-volume
- * hierarchy over the triangles for the render kernel: nodes float32 [n_nodes][8] = lo.xyz, skip (int bits) | hi.xyz,
+ * hierarchy over the triangles for the render kernel: nodes float32 [n_orders][n_nodes][8] = lo.xyz, skip (int bits) | hi.xyz,
  * first | count << 24 (int bits) in depth-first order (an inner node's first child follows it; `skip` = next node when the box
- * is missed or the leaf is done); perm int32 [n_tris] = triangle indices in leaf order.  Host pointers; synchronous.
+ * is missed or the leaf is done); perm int32 [n_tris] = triangle indices in leaf order.  n_orders is 1, or 8: eight threadings
+ * of the same tree over the same leaves, threading k for rays whose direction (in the mesh's frame) has component a negative
+ * iff bit a of k is set - the child nearer along the split axis first.  Host pointers; synchronous.
  * The vertex colour is the material's Kd, which the entity carries (ball_<c> / key_<c> share their geometry). */
 int mwb_set_mesh(mwb_handle *h, int geom, int n_tris, const float *verts, const float *norms, const float *texcs, int tex_slot,
-                 const float *min_coords, const float *max_coords, int n_nodes, const float *nodes, const int32_t *perm);
+                 const float *min_coords, const float *max_coords, int n_nodes, int n_orders, const float *nodes, const int32_t *perm);
 /* replaces: MeshEnt.__init__'s arithmetic (entity.py:118-127) - `scale = height / sy`, `radius = sqrt(sx^2 + sz^2) * scale` -
  * evaluated by the host with the reference's expressions, because their scalar type follows the installed NumPy (float32 under
  * NumPy >= 2, where sums with Python floats are then float32 too): one call per (geometry, height) the task builds. */
