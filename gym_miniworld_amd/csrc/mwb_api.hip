@@ -780,7 +780,6 @@ extern "C" int mwb_render_view(mwb_handle *h, uint8_t *out_dev, float *depth_dev
 
 extern "C" int mwb_visible_ents(mwb_handle *h, uint32_t *mask_dev, void *stream) {
     if (!h || !mask_dev) return set_err(MWB_EINVAL, "mwb_visible_ents: null argument");
-    if (h->dev.ent_task) return set_err(MWB_EINVAL, "mwb_visible_ents: not available for the tasks with mesh entities");
     USE_DEVICE(h->cfg.device);
     int rc = ensure_ready(h, false); if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;

@@ -3865,9 +3865,21 @@ __global__ void __launch_bounds__(256) visible_kernel(MwbDev d, uint32_t *__rest
     }
     __syncthreads();
     const int cam_room = cam_room_s == 0x7fffffff ? -1 : cam_room_s;
-    float lo[MWB_MAX_BOXES][3], hi[MWB_MAX_BOXES][3];
-    for (int b = 0; b < d.n_boxes; b++) {   // glVertex3f arguments: float32 of the float64 sums
-        const size_t be = (size_t)b * d.N + e;
+    // the cubes in the order the reference draws them: self.entities without the agent (entity tasks: the env's order list)
+    float lo[MWB_MAX_ENTS][3], hi[MWB_MAX_ENTS][3];
+    int slot[MWB_MAX_ENTS];
+    int n_cubes = 0;
+    if (d.ent_task) {
+        const int n_ord = d.n_order[e];
+        for (int q = 0; q < n_ord && n_cubes < MWB_MAX_ENTS; q++) {
+            const int sl = d.ent_order[(size_t)e * MWB_ORDER_STRIDE + q];
+            if (sl != MWB_ENT_AGENT) slot[n_cubes++] = sl;
+        }
+    } else {
+        for (int b = 0; b < d.n_boxes; b++) slot[n_cubes++] = b;
+    }
+    for (int b = 0; b < n_cubes; b++) {   // glVertex3f arguments: float32 of the float64 sums
+        const size_t be = (size_t)slot[b] * d.N + e;
         const double px = d.box_x[be], py = d.box_y[be], pz = d.box_z[be];
         lo[b][0] = (float)(px - 0.1); hi[b][0] = (float)(px + 0.1);
         lo[b][1] = (float)py;         hi[b][1] = (float)(py + 0.2);
@@ -3879,10 +3891,10 @@ __global__ void __launch_bounds__(256) visible_kernel(MwbDev d, uint32_t *__rest
         const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
 #pragma unroll 1
         for (int k = 0; k < 8; k++) {
-            float dv[3], tb[MWB_MAX_BOXES];
+            float dv[3], tb[MWB_MAX_ENTS];
             make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
             bool any = false;
-            for (int b = 0; b < d.n_boxes; b++) {
+            for (int b = 0; b < n_cubes; b++) {
                 float tn = -INFINITY, tf = INFINITY;
                 bool miss = false;
 #pragma unroll
@@ -3904,8 +3916,8 @@ __global__ void __launch_bounds__(256) visible_kernel(MwbDev d, uint32_t *__rest
             const uint32_t key = POLY ? trace_rooms_poly<false>(rooms, n_rooms, cam_room, cam.eye, dv, th, path)
                                       : trace_rooms<false>(rooms, n_rooms, cam_room, cam.eye, dv, th, path);
             float depth = (key & 7u) != KIND_SKY ? th : INFINITY;   // the depth buffer at this sample so far
-            for (int b = 0; b < d.n_boxes; b++)
-                if (tb[b] < depth) { mask |= 1u << b; depth = tb[b]; }
+            for (int b = 0; b < n_cubes; b++)
+                if (tb[b] < depth) { mask |= 1u << slot[b]; depth = tb[b]; }
         }
     }
     if (mask) atomicOr(&mask_s, mask);

@@ -216,6 +216,8 @@ class MiniWorldEnv:
     def get_visible_ents(self):
         """miniworld.py:1222-1315: the set of entities (never the agent) whose query cube is visible"""
         mask = int(self._b.visible_ents().cpu().numpy()[0])
+        if self._b.ent_task:   # bits name slots; entities that left the list have no cube
+            return {ent for i, ent in enumerate(self._slots) if (mask >> i) & 1 and any(ent is x for x in self.entities)}
         return {ent for i, ent in enumerate(self.entities[:-1]) if (mask >> i) & 1}
 
     def render_top_view(self, width=None, height=None):

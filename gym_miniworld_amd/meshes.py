@@ -143,7 +143,7 @@ def mesh_ent_dims(mesh_name, height):
 
 
 # ------------------------------------------------------------------------------------------------------------ BVH
-def build_bvh(verts, leaf_size=4, octants=True):
+def build_bvh(verts, leaf_size=8, octants=True):
     """Threaded (stackless) BVH over the triangles [F, 3, 3] float32 for the render kernel: nodes in depth-first order,
     node i = (lo[3], hi[3], skip, first, count): an inner node's first child is node i + 1, `skip` is where to go when the
     box is missed (or after a leaf); a leaf lists triangles perm[first : first + count].  Splits by the surface-area heuristic

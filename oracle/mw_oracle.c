@@ -2172,9 +2172,17 @@ uint32_t mwo_visible_ents(MwoEnv *e, int W, int H) {
             if (in) cam_room = i;
         }
     }
+    /* the cubes in drawing order: self.entities without the agent (e->order: entities that were removed are not in it) */
     float lo[MWO_MAX_BOXES][3], hi[MWO_MAX_BOXES][3];
-    for (int b = 0; b < e->n_boxes; b++) {   /* glVertex3f arguments: float32 of the float64 sums */
-        const double *p = e->boxes[b].pos;
+    int slot[MWO_MAX_BOXES], n_cubes = 0;
+    if (e->task >= MWO_PICKUPOBJS) {
+        for (int q = 0; q < e->n_order; q++)
+            if (e->order[q] != AGENT_SLOT) slot[n_cubes++] = e->order[q];
+    } else {   /* the box tasks place their boxes in slot order */
+        for (int b = 0; b < e->n_boxes; b++) slot[n_cubes++] = b;
+    }
+    for (int b = 0; b < n_cubes; b++) {   /* glVertex3f arguments: float32 of the float64 sums */
+        const double *p = e->boxes[slot[b]].pos;
         lo[b][0] = (float)(p[0] - 0.1); hi[b][0] = (float)(p[0] + 0.1);
         lo[b][1] = (float)p[1];         hi[b][1] = (float)(p[1] + 0.2);
         lo[b][2] = (float)(p[2] - 0.1); hi[b][2] = (float)(p[2] + 0.1);
@@ -2187,12 +2195,12 @@ uint32_t mwo_visible_ents(MwoEnv *e, int W, int H) {
                 float d[3], tb[MWO_MAX_BOXES];
                 int any = 0;
                 make_ray(&c, cx + SAMPLE_X[k] * 0.0625f, cy + SAMPLE_Y[k] * 0.0625f, d);
-                for (int b = 0; b < e->n_boxes; b++) { tb[b] = INFINITY; if (cube_entry(lo[b], hi[b], c.eye, d, &tb[b])) any = 1; else tb[b] = INFINITY; }
+                for (int b = 0; b < n_cubes; b++) { tb[b] = INFINITY; if (cube_entry(lo[b], hi[b], c.eye, d, &tb[b])) any = 1; else tb[b] = INFINITY; }
                 if (!any) continue;
                 Hit h = poly ? trace_rooms_poly(pr, n_rooms, cam_room, c.eye, d) : trace_rooms(rr, n_rooms, cam_room, c.eye, d);
                 float depth = h.kind != 0 ? h.t : INFINITY;   /* the depth buffer at this sample so far */
-                for (int b = 0; b < e->n_boxes; b++)
-                    if (tb[b] < depth) { mask |= 1u << b; depth = tb[b]; }
+                for (int b = 0; b < n_cubes; b++)
+                    if (tb[b] < depth) { mask |= 1u << slot[b]; depth = tb[b]; }
             }
         }
     free(rr);

@@ -149,6 +149,38 @@ def test_visible_ents_matches_oracle(oracle_mod, env_id, task, args):
     b.close()
 
 
+@pytest.mark.parametrize("env_id,task,args", [("MiniWorld-PickupObjs-v0", "PickupObjs", [12, 5, 0, 0]), ("MiniWorld-CollectHealth-v0", "CollectHealth", [16, 0, 0, 0]),
+                                              ("MiniWorld-ThreeRooms-v0", "ThreeRooms", None), ("MiniWorld-Sidewalk-v0", "Sidewalk", None)])
+def test_visible_ents_of_the_entity_tasks_matches_oracle(oracle_mod, env_id, task, args):
+    """the same for a general entity list: a cube per entry of self.entities (meshes, frames, boxes alike), in LIST order, none
+    for entities that left the list - through rollouts in which objects are picked up (removed / moved to the list's end)"""
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    O = oracle_mod
+    n = 24
+    b = BatchedMiniWorld(env_id, num_envs=n, seed=19, domain_rand=0)
+    envs = [O.OracleEnv(task, seed=19 + i, domain_rand=0, task_args=args) for i in range(n)]
+    b.reset()
+    for e in envs:
+        e.reset(render=False)
+    rng = np.random.default_rng(8)
+    seen = 0
+    for rnd in range(6):
+        got = b.visible_ents().cpu().numpy()
+        want = np.array([e.visible_ents() for e in envs], dtype=np.int64)
+        assert np.array_equal(got.astype(np.int64), want), (env_id, rnd, got.tolist(), want.tolist())
+        seen += int((want != 0).sum())
+        for t in range(25):
+            a = rng.integers(0, b.n_actions, n).astype(np.int32)
+            b.step(torch.from_numpy(a))
+            for i, e in enumerate(envs):
+                _, _, dn, _ = e.step(int(a[i]))
+                if dn:
+                    e.reset(render=False)
+    assert seen > 0
+    b.close()
+
+
 def test_get_visible_ents_gym_view():
     from gym_miniworld_amd.env import MiniWorldEnv
     env = MiniWorldEnv("MiniWorld-PutNext-v0", seed=3)

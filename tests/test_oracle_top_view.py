@@ -175,3 +175,33 @@ def test_visible_ents_equals_occlusion_queries_on_the_reference_polygons(oracle_
         seen_any += len(got)
     if name == "PutNext":
         assert seen_any > 0
+
+
+@pytest.mark.parametrize("name,dr", [("PickupObjs", 0), ("PickupObjs", 1), ("RoomObjs", 1), ("ThreeRooms", 0), ("Sidewalk", 1), ("CollectHealth", 0)])
+def test_visible_ents_of_an_entity_list_equals_the_queries_on_the_reference_polygons(oracle_mod, name, dr):
+    """the tasks with a general entity list: one cube per entry of self.entities (whatever the entity is: mesh, frame, box), in list
+    order, none for entities that left the list - against the queries evaluated on the streams' room polygons"""
+    import math
+    import test_oracle_ents_render as ER
+    import soup_renderer as SR
+    g = ER.load_stream(name, dr)
+    env = ER.replay(oracle_mod, g, name, dr)
+    s = env.state()
+    slots = [int(q) for q in list(s.order)[:s.n_order] if 0 <= int(q) < s.n_boxes]
+    positions = [list(s.boxes_pos[b]) for b in slots]
+    seen_any = 0
+    for turn in range(8):
+        ang = s.agent_dir + turn * math.pi / 4
+        env.set_agent(s.agent_pos[0], s.agent_pos[2], ang)
+        st = env.state()
+        g2 = dict(g)
+        g2["misc"] = dict(g["misc"])
+        cp, cdir = np.array(st.cam_pos), np.array(st.cam_dir)
+        g2["misc"]["gluLookAt"] = list(cp) + list(cp + cdir) + [0.0, 1.0, 0.0]
+        g2["polys"] = g["room_polys"]
+        want = {slots[i] for i in SR.visible_cubes(g2, positions)}
+        mask = env.visible_ents()
+        got = {b for b in range(s.n_boxes) if (mask >> b) & 1}
+        assert got == want, (name, dr, turn, got, want)
+        seen_any += len(got)
+    assert seen_any > 0
