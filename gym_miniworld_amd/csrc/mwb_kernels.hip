@@ -2339,6 +2339,7 @@ struct RenderCtx {
     float cull_cc[1], cull_oc[1][3], zA, zB;   // the box's cull constants (NBOX == 1 only: scalar registers)
     bool boxes_in_view;   // workgroup-uniform (scalar): false = no ray of this frame can touch a box
     const MwbMeshDesc *mesh_desc;   // entity tasks: mesh geometries in HBM (L2 resident), or null
+    const uint4 *mdesc;             // the walk's part of every descriptor, staged in LDS: node_off, tri_off, n_nodes, n_orders
     const float4 *mesh_data;
     int exp_flags;                  // MWB_EXP experiment switches (timing experiments only)
     uint32_t mesh_slots;            // bit b: entity slot b is a mesh in this frame (workgroup-uniform)
@@ -2450,57 +2451,71 @@ struct RenderCtx {
         int leaf_first = 0, leaf_cnt = 0;   // a leaf this lane has reached and not yet tested
         unsigned c_walks = 0, c_visits = 0, c_tris = 0, c_iters = 0;   // MWB_EXP bit 2: counters (timing experiments only)
         for (;;) {
-            // phase 1 (node steps only - the loop body a wave repeats most often stays short): every lane moves on, through its
-            // candidates' hierarchies, until it stands at a leaf or has nothing left
-            while (leaf_cnt == 0 && (node < n_nodes || cand)) {
-                c_iters++;
-                if (node >= n_nodes) {   // this lane's next candidate
-                    bi = __builtin_ctz(cand);
-                    cand &= cand - 1u;
-                    best = -1;
-                    const float *blk = fc + bi * FC_BOX_STRIDE;
-                    const float cc = blk[FC_CULL_CC];
-                    const float b = dv[0] * blk[FC_CULL_OC] + dv[1] * blk[FC_CULL_OC + 1] + dv[2] * blk[FC_CULL_OC + 2];
-                    node = n_nodes = 0;
-                    if (!(cc <= 0.0f || (b > 0.0f && b * b >= dd * cc))) continue;
-                    mesh_local_dir(blk, dv, ld);
-                    lo[0] = blk[FC_BOX_LO]; lo[1] = blk[FC_BOX_LO + 1]; lo[2] = blk[FC_BOX_LO + 2];
-                    // the node boxes are padded by 1e-4 of the mesh (host): a 1-ulp reciprocal cannot lose a real hit
-                    inv[0] = __builtin_amdgcn_rcpf(ld[0]); inv[1] = __builtin_amdgcn_rcpf(ld[1]); inv[2] = __builtin_amdgcn_rcpf(ld[2]);
-                    const int geom = __float_as_int(blk[FC_LIT_BOX + FE_MESH_GEOM]);
-                    const MwbMeshDesc &md = mesh_desc[geom];
-                    // the threading that visits the nearer child first for this ray's direction (bit a: component a negative)
-                    const int oct = md.n_orders == 8 ? ((ld[0] < 0.0f ? 1 : 0) | (ld[1] < 0.0f ? 2 : 0) | (ld[2] < 0.0f ? 4 : 0)) : 0;
-                    nodes = gd + md.node_off + (size_t)oct * 2u * (uint32_t)md.n_nodes; tris = gd + md.tri_off; n_nodes = md.n_nodes;
-                    c_walks++;
-                    continue;
-                }
-                c_visits++;
-                const f4n a = nodes[2 * node], bb = nodes[2 * node + 1];
-                float t0 = (a.x - lo[0]) * inv[0], t1 = (bb.x - lo[0]) * inv[0];
-                float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-                t0 = (a.y - lo[1]) * inv[1]; t1 = (bb.y - lo[1]) * inv[1];
-                tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-                t0 = (a.z - lo[2]) * inv[2]; t1 = (bb.z - lo[2]) * inv[2];
-                tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-                const uint32_t fcnt = (uint32_t)__float_as_int(bb.w);
-                const bool hit = tn <= tf * 1.00001f && tf > 0.0f && tn <= th;
-                const int cnt = (int)(fcnt >> 24);
-                node = (hit && cnt == 0) ? node + 1 : __float_as_int(a.w);   // into the first child, or on past this subtree / leaf
-                if (hit && cnt) { leaf_first = (int)(fcnt & 0xFFFFFFu); leaf_cnt = cnt; }
+            // (a) the lanes with no mesh in progress take their next candidate whose gate the ray passes.  Kept OUT of the node loop: in
+            // one merged loop every iteration of the wave paid for this path too - ~100 instructions and a descriptor fetch - because
+            // some lane or other is always between two meshes.
+            while (node >= n_nodes && cand) {
+                bi = __builtin_ctz(cand);
+                cand &= cand - 1u;
+                best = -1;
+                const float *blk = fc + bi * FC_BOX_STRIDE;
+                const float cc = blk[FC_CULL_CC];
+                const float b = dv[0] * blk[FC_CULL_OC] + dv[1] * blk[FC_CULL_OC + 1] + dv[2] * blk[FC_CULL_OC + 2];
+                node = n_nodes = 0;
+                if (!(cc <= 0.0f || (b > 0.0f && b * b >= dd * cc))) continue;
+                mesh_local_dir(blk, dv, ld);
+                lo[0] = blk[FC_BOX_LO]; lo[1] = blk[FC_BOX_LO + 1]; lo[2] = blk[FC_BOX_LO + 2];
+                // the node boxes are padded by 1e-4 of the mesh (host): a 1-ulp reciprocal cannot lose a real hit
+                inv[0] = __builtin_amdgcn_rcpf(ld[0]); inv[1] = __builtin_amdgcn_rcpf(ld[1]); inv[2] = __builtin_amdgcn_rcpf(ld[2]);
+                const uint4 md = mdesc[__float_as_int(blk[FC_LIT_BOX + FE_MESH_GEOM])];   // node_off, tri_off, n_nodes, n_orders (LDS)
+                // the threading that visits the nearer child first for this ray's direction (bit a: component a negative)
+                const uint32_t oct = md.w == 8u ? ((ld[0] < 0.0f ? 1u : 0u) | (ld[1] < 0.0f ? 2u : 0u) | (ld[2] < 0.0f ? 4u : 0u)) : 0u;
+                nodes = gd + md.x + (size_t)(oct * 2u * md.z); tris = gd + md.y; n_nodes = (int)md.z;
+                c_walks++;
             }
-            if (!__any(leaf_cnt != 0)) break;
-            // phase 2: the lanes that stand at a leaf test its triangles (spec arithmetic: correctly rounded t)
-            for (int q = 0; q < leaf_cnt; q++) {
-                const f4n q0 = tris[3 * (leaf_first + q)], q1 = tris[3 * (leaf_first + q) + 1], q2 = tris[3 * (leaf_first + q) + 2];
-                const float4 r0 = make_float4(q0.x, q0.y, q0.z, q0.w), r1 = make_float4(q1.x, q1.y, q1.z, q1.w), r2 = make_float4(q2.x, q2.y, q2.z, q2.w);
-                float t, u, v, det;
-                c_tris++;
-                if (mesh_tri(lo, ld, r0, r1, r2, true, t, u, v, det)) {
-                    const int idx = __float_as_int(r2.y);
-                    if (t < th || (t == th && best >= 0 && idx < best)) {
-                        th = t; best = idx;
-                        key = KIND_MESH | ((uint32_t)bi << 3) | ((uint32_t)idx << 8);
+            if (!__any(node < n_nodes)) break;
+            // (b) node steps only - the loop body a wave repeats most often stays short - until every lane stands at a leaf or at the
+            // end of its mesh.  The records of a node AND of the one behind it (its first child, if it has children: depth-first
+            // order) are fetched together: a descent - the commonest move - costs no second round trip to L2.
+            while (leaf_cnt == 0 && node < n_nodes) {
+                c_iters++;
+                const int nx = node + 1 < n_nodes ? node + 1 : node;
+                const f4n a = nodes[2 * node], bb = nodes[2 * node + 1], a2 = nodes[2 * nx], b2 = nodes[2 * nx + 1];
+                auto visit = [&](const f4n &a, const f4n &bb) {
+                    c_visits++;
+                    float t0 = (a.x - lo[0]) * inv[0], t1 = (bb.x - lo[0]) * inv[0];
+                    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+                    t0 = (a.y - lo[1]) * inv[1]; t1 = (bb.y - lo[1]) * inv[1];
+                    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                    t0 = (a.z - lo[2]) * inv[2]; t1 = (bb.z - lo[2]) * inv[2];
+                    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                    const uint32_t fcnt = (uint32_t)__float_as_int(bb.w);
+                    const bool hit = tn <= tf * 1.00001f && tf > 0.0f && tn <= th;
+                    const int cnt = (int)(fcnt >> 24);
+                    const bool down = hit && cnt == 0;
+                    node = down ? node + 1 : __float_as_int(a.w);   // into the first child, or on past this subtree / leaf
+                    if (hit && cnt) { leaf_first = (int)(fcnt & 0xFFFFFFu); leaf_cnt = cnt; }
+                    return down;
+                };
+                if (visit(a, bb)) visit(a2, b2);
+            }
+            // (c) the lanes that stand at a leaf test its triangles (spec arithmetic: correctly rounded t).  The record of
+            // triangle q + 1 is requested before triangle q is tested: one exposed round trip per leaf, not one per triangle.
+            if (leaf_cnt) {
+                c_iters++;
+                f4n p0 = tris[3 * leaf_first], p1 = tris[3 * leaf_first + 1], p2 = tris[3 * leaf_first + 2];
+                for (int q = 0; q < leaf_cnt; q++) {
+                    const f4n q0 = p0, q1 = p1, q2 = p2;
+                    if (q + 1 < leaf_cnt) { p0 = tris[3 * (leaf_first + q + 1)]; p1 = tris[3 * (leaf_first + q + 1) + 1]; p2 = tris[3 * (leaf_first + q + 1) + 2]; }
+                    const float4 r0 = make_float4(q0.x, q0.y, q0.z, q0.w), r1 = make_float4(q1.x, q1.y, q1.z, q1.w), r2 = make_float4(q2.x, q2.y, q2.z, q2.w);
+                    float t, u, v, det;
+                    c_tris++;
+                    if (mesh_tri(lo, ld, r0, r1, r2, true, t, u, v, det)) {
+                        const int idx = __float_as_int(r2.y);
+                        if (t < th || (t == th && best >= 0 && idx < best)) {
+                            th = t; best = idx;
+                            key = KIND_MESH | ((uint32_t)bi << 3) | ((uint32_t)idx << 8);
+                        }
                     }
                 }
             }
@@ -2890,6 +2905,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     // entity tasks: a third queue per wave for the 8-sample pixels a mesh may cover, and its leftover counts (behind the frame)
     uint16_t *mqueues = (uint16_t *)(smem + ((off + (size_t)W * H * 3 + 15) & ~(size_t)15));
     int *mleft = (int *)(mqueues + (THREADS / WAVE) * QUEUE_CAP);
+    uint4 *mdesc = (uint4 *)(mleft + 4);   // entity tasks: [MWB_NUM_MESHES], see RenderCtx::mdesc
 
     {   // stage the room table, the frame constants and the texture descriptors
         const int rw = POLY ? MWB_POLY_ROOM_WORDS : MWB_ROOM_WORDS;
@@ -2902,11 +2918,13 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         uint32_t *tdst = (uint32_t *)tex;
         for (int i = tid; i < (int)(sizeof(TexLds) / 4) * d.n_tex; i += THREADS) tdst[i] = tsrc[i];
         if (tid == 0) { cam_room_s[0] = 0x7fffffff; cam_room_s[1] = 0; }   // eye room (atomicMin), work-item counter
+        if constexpr (NBOX > MWB_MAX_BOXES)
+            if (tid < MWB_NUM_MESHES) { const MwbMeshDesc &m = d.mesh_desc[tid]; mdesc[tid] = make_uint4(m.node_off, m.tri_off, (uint32_t)m.n_nodes, (uint32_t)m.n_orders); }
     }
     __syncthreads();
     RenderCtx<NBOX, POLY> ctx;
     ctx.rooms = rooms; ctx.fc = fc; ctx.tex = tex; ctx.texels = d.texels; ctx.fb = fb;
-    ctx.mesh_desc = d.mesh_desc; ctx.mesh_data = d.mesh_data;
+    ctx.mesh_desc = d.mesh_desc; ctx.mesh_data = d.mesh_data; ctx.mdesc = mdesc;
     ctx.exp_flags = d.exp_flags; ctx.mesh_slots = 0; ctx.dbg_counters = d.dbg_counters;
     if constexpr (NBOX > MWB_MAX_BOXES) {   // which slots hold a mesh in this frame
         uint32_t ms = 0;
@@ -3559,7 +3577,7 @@ static size_t render_lds_bytes_for(const MwbDev &d, int W, int H) {
     size_t b = (((size_t)d.R_max * d.room_words * 4 + 15) & ~(size_t)15) + (size_t)d.frame_words * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
                (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)ITEM_RES_BYTES(W) + (size_t)W * H * 3;
     b = (b + 15) & ~(size_t)15;
-    if (d.ent_task) b += (RENDER_THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t) + 16;   // the mesh-pixel queues and their leftover counts
+    if (d.ent_task) b += (RENDER_THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t) + 16 + 16 * MWB_NUM_MESHES;   // the mesh-pixel queues, their leftover counts, the mesh descriptors
     return (b + 15) & ~(size_t)15;
 }
 // d: the handle's MwbDev with W / H / obs / depth / frame / want_depth / layout set for the view
