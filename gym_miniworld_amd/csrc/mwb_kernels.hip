@@ -2206,6 +2206,9 @@ __device__ __forceinline__ bool mesh_tri(const float *lo, const float *ld, const
 }
 // nearest front-facing triangle of the entity's mesh along (eye, dv) that is strictly nearer than t_max: its index in draw order
 // or -1.  Threaded BVH (host-built, gym_miniworld_amd/meshes.py): depth-first node order, `skip` links, no stack.
+#define MB_HALF 4      // pixels_mesh: samples per round
+#define MB_TASKS 320   //   (ray, mesh) pairs per round
+#define MB_WAVE_BYTES (MB_HALF * 64 * 8 + MB_TASKS * 2 + 64 * 4 + 16)   // per wave: slots, pairs, pixel coordinates, counter
 typedef float f4n __attribute__((ext_vector_type(4)));   // a plain 16-byte vector for the mesh records (walk_meshes)
 // ImageFrame / TextFrame: slab [0, depth] x [-h/2, h/2] x [-w/2, w/2] in the frame's axes; returns the character cell of the
 // front (+x) face, 100 for a black side, -1 for a miss or the missing back
@@ -2340,6 +2343,12 @@ struct RenderCtx {
     bool boxes_in_view;   // workgroup-uniform (scalar): false = no ray of this frame can touch a box
     const MwbMeshDesc *mesh_desc;   // entity tasks: mesh geometries in HBM (L2 resident), or null
     const uint4 *mdesc;             // the walk's part of every descriptor, staged in LDS: node_off, tri_off, n_nodes, n_orders
+    // this wave's scratch for a batch of mesh pixels (pixels_mesh): per (sample-in-half, lane) the nearest surface so far as an
+    // ordered 64-bit word, the (ray, mesh) pairs that passed their gate, the batch's pixel coordinates, the pair counter
+    unsigned long long *mb_slots;   // [MB_HALF][64]
+    uint16_t *mb_tasks;             // [MB_TASKS]
+    uint32_t *mb_pix;               // [64]
+    int *mb_count;
     const float4 *mesh_data;
     int exp_flags;                  // MWB_EXP experiment switches (timing experiments only)
     uint32_t mesh_slots;            // bit b: entity slot b is a mesh in this frame (workgroup-uniform)
@@ -2624,7 +2633,11 @@ struct RenderCtx {
         if constexpr (POLY) { shade_poly<INTERIOR>(key, first_k, cx, cy, col); return; }
         const uint32_t kind = key & 7u, side = (key >> 3) & 3u;
         if constexpr (!INTERIOR && NBOX > MWB_MAX_BOXES) {   // entity tasks
-            if (kind == KIND_MESH) { shade_mesh(key, first_k, cx, cy, col); return; }
+            if (kind == KIND_MESH) {
+                if (exp_flags & 8) { col[0] = col[1] = col[2] = 0.5f; return; }   // experiment: no call at all (the cost of the call itself)
+                shade_mesh(key, first_k, cx, cy, col);
+                return;
+            }
             if (kind == KIND_FRAME) { shade_frame(key, first_k, cx, cy, col); return; }
         }
         if (!INTERIOR) {
@@ -2718,6 +2731,213 @@ struct RenderCtx {
     // the centre ray.  The traversal computes every distance from the eye, never from the previous room, so the
     // results are bit-identical to a start in the eye's room (guarded by test_fast_path_equals_full_sample_path's
     // MWB_DEBUG=8 leg).
+    // One (ray, mesh) pair: the walk of mesh slot bi along (eye, dv) by this lane alone, every lane of the wave with a pair of its own
+    // (dense: walk_meshes' loop with the candidate phase taken out).  th: nothing farther matters; -> hit, t, triangle.
+    __device__ __forceinline__ bool walk_pair(bool active, int bi, const float *dv, float th, float &t_out, int &tri_out) const {
+        const f4n *gd = (const f4n *)mesh_data;
+        const f4n *nodes = gd, *tris = gd;
+        float lo[3] = {0, 0, 0}, ld[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+        int node = 0, n_nodes = 0, best = -1, leaf_first = 0, leaf_cnt = 0;
+        unsigned c_visits = 0, c_tris = 0, c_iters = 0;
+        if (active) {
+            const float *blk = fc + bi * FC_BOX_STRIDE;
+            mesh_local_dir(blk, dv, ld);
+            lo[0] = blk[FC_BOX_LO]; lo[1] = blk[FC_BOX_LO + 1]; lo[2] = blk[FC_BOX_LO + 2];
+            inv[0] = __builtin_amdgcn_rcpf(ld[0]); inv[1] = __builtin_amdgcn_rcpf(ld[1]); inv[2] = __builtin_amdgcn_rcpf(ld[2]);
+            const uint4 md = mdesc[__float_as_int(blk[FC_LIT_BOX + FE_MESH_GEOM])];
+            const uint32_t oct = md.w == 8u ? ((ld[0] < 0.0f ? 1u : 0u) | (ld[1] < 0.0f ? 2u : 0u) | (ld[2] < 0.0f ? 4u : 0u)) : 0u;
+            nodes = gd + md.x + (size_t)(oct * 2u * md.z); tris = gd + md.y; n_nodes = (int)md.z;
+        }
+        while (__any(node < n_nodes)) {
+            while (leaf_cnt == 0 && node < n_nodes) {
+                c_iters++;
+                const int nx = node + 1 < n_nodes ? node + 1 : node;
+                const f4n a = nodes[2 * node], bb = nodes[2 * node + 1], a2 = nodes[2 * nx], b2 = nodes[2 * nx + 1];
+                auto visit = [&](const f4n &a, const f4n &bb) {
+                    c_visits++;
+                    float t0 = (a.x - lo[0]) * inv[0], t1 = (bb.x - lo[0]) * inv[0];
+                    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+                    t0 = (a.y - lo[1]) * inv[1]; t1 = (bb.y - lo[1]) * inv[1];
+                    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                    t0 = (a.z - lo[2]) * inv[2]; t1 = (bb.z - lo[2]) * inv[2];
+                    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                    const uint32_t fcnt = (uint32_t)__float_as_int(bb.w);
+                    const bool hit = tn <= tf * 1.00001f && tf > 0.0f && tn <= th;
+                    const int cnt = (int)(fcnt >> 24);
+                    const bool down = hit && cnt == 0;
+                    node = down ? node + 1 : __float_as_int(a.w);
+                    if (hit && cnt) { leaf_first = (int)(fcnt & 0xFFFFFFu); leaf_cnt = cnt; }
+                    return down;
+                };
+                if (visit(a, bb)) visit(a2, b2);
+            }
+            if (leaf_cnt) {
+                c_iters++;
+                f4n p0 = tris[3 * leaf_first], p1 = tris[3 * leaf_first + 1], p2 = tris[3 * leaf_first + 2];
+                for (int q = 0; q < leaf_cnt; q++) {
+                    const f4n q0 = p0, q1 = p1, q2 = p2;
+                    if (q + 1 < leaf_cnt) { p0 = tris[3 * (leaf_first + q + 1)]; p1 = tris[3 * (leaf_first + q + 1) + 1]; p2 = tris[3 * (leaf_first + q + 1) + 2]; }
+                    const float4 r0 = make_float4(q0.x, q0.y, q0.z, q0.w), r1 = make_float4(q1.x, q1.y, q1.z, q1.w), r2 = make_float4(q2.x, q2.y, q2.z, q2.w);
+                    float t, u, v, det;
+                    c_tris++;
+                    if (mesh_tri(lo, ld, r0, r1, r2, true, t, u, v, det)) {
+                        const int idx = __float_as_int(r2.y);
+                        // t == th with no hit of this walk yet: kept - th may be another pair's result for the same ray, and the
+                        // merge (t, non-mesh first, slot, triangle) decides, whatever the order the pairs finish in
+                        if (t < th || (t == th && (best < 0 || idx < best))) { th = t; best = idx; }
+                    }
+                }
+            }
+            leaf_cnt = 0;
+        }
+        if ((exp_flags & 4) && dbg_counters) {
+            if (active) { atomicAdd(dbg_counters + 0, 1ull); atomicAdd(dbg_counters + 1, 1ull); }
+            atomicAdd(dbg_counters + 2, (unsigned long long)c_visits); atomicAdd(dbg_counters + 3, (unsigned long long)c_tris);
+            unsigned mx = c_iters;
+            for (int o = 32; o; o >>= 1) { const unsigned v = __shfl_xor(mx, o); mx = v > mx ? v : mx; }
+            if ((threadIdx.x & 63) == 0) { atomicAdd(dbg_counters + 4, (unsigned long long)mx); atomicAdd(dbg_counters + 5, 1ull); }
+        }
+        t_out = th; tri_out = best;
+        return best >= 0;
+    }
+
+    // Entity tasks: a batch of up to 64 pixels out of the mesh-pixel queue (lane = pixel; valid: this lane holds one).  pixel_full's
+    // result, bit for bit, with the mesh walks REDISTRIBUTED over the wave: a pixel inside a ball's outline has eight walks to do and
+    // its neighbour outside none, so with one pixel per lane a wave's loop ran as long as its busiest lane (a third of the lanes busy).
+    // Per half of the samples (4): every lane traces rooms, boxes and frames for its own pixel's samples and leaves the nearest
+    // surface in LDS as an ordered word (t, then non-mesh before mesh, then slot, then triangle - the drawing order's tie rules);
+    // every (sample ray, mesh) pair whose gate sphere the ray passes goes to a list; the list is walked 64 pairs at a time by
+    // whichever lanes (walk_pair), results merged with a 64-bit atomic minimum; the lanes then read their own pixels' results back.
+    __device__ __forceinline__ void pixels_mesh(int px, int py, int skip, bool valid) const {
+        const int lane = threadIdx.x & (WAVE - 1);
+        const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
+        int start_room = cam_room;
+        if (valid && skip > 0) {
+            float dc[3];
+            make_ray(cam, cx, cy, dc);
+            const int r = walk_rooms(rooms, cam_room, cam.eye, dc, skip);
+            start_room = r >= 0 ? r : cam_room;
+        }
+        const uint32_t my_boxes = valid && boxes_in_view ? item_boxes(px, py) : 0u;
+        uint32_t any_boxes = 0;
+#pragma unroll
+        for (int bi = 0; bi < NBOX; bi++) any_boxes |= __ballot((my_boxes >> bi) & 1u) ? 1u << bi : 0u;
+        mb_pix[lane] = (uint32_t)px | ((uint32_t)py << 16);
+        uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0, meta = 0, key_s0 = 0;
+        float t_s0 = INFINITY;
+        float acc[3] = {0, 0, 0};
+#pragma unroll 1
+        for (int half = 0; half < 8 / MB_HALF; half++) {
+            if (lane == 0) *mb_count = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t knm[MB_HALF];
+#pragma unroll
+            for (int kk = 0; kk < MB_HALF; kk++) {
+                const int k = half * MB_HALF + kk;
+                float dv[3], th = INFINITY;
+                uint32_t path, key = 0;
+                make_ray(cam, cx + c_sample_x[k], cy + c_sample_y[k], dv);
+                if (valid) key = trace_from<false>(start_room, dv, th, path);
+                const float dd = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+#pragma unroll 1
+                for (uint32_t bm = any_boxes & ~mesh_slots; bm; bm &= bm - 1u) {   // boxes and frames, as in pixel_full
+                    const int bi = __builtin_ctz(bm);
+                    const float *fb_ = fc + bi * FC_BOX_STRIDE;
+                    const float cc = fb_[FC_CULL_CC];
+                    const float b = dv[0] * fb_[FC_CULL_OC] + dv[1] * fb_[FC_CULL_OC + 1] + dv[2] * fb_[FC_CULL_OC + 2];
+                    if (((my_boxes >> bi) & 1u) && (cc <= 0.0f || (b > 0.0f && b * b >= dd * cc))) {
+                        float tb;
+                        const float hxk = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fb_[FC_BOX_HX])));
+                        if (hxk == -2.0f) {
+                            const int code = trace_frame(fb_, dv, tb);
+                            if (code >= 0 && tb < th) { key = KIND_FRAME | ((uint32_t)bi << 3) | ((uint32_t)code << 8); th = tb; }
+                        } else {
+                            int face = trace_box(fb_, dv, tb);
+                            if (face >= 0 && tb < th) { key = MAKE_KEY(KIND_BOX, face, bi); th = tb; }
+                        }
+                    }
+                }
+                knm[kk] = key;
+                mb_slots[kk * WAVE + lane] = (unsigned long long)(uint32_t)__float_as_int(th) << 32;
+                if (!(exp_flags & 1)) {
+                    for (uint32_t c = my_boxes & mesh_slots; c; c &= c - 1u) {   // the gate sphere of every candidate mesh
+                        const int bi = __builtin_ctz(c);
+                        const float *blk = fc + bi * FC_BOX_STRIDE;
+                        const float cc = blk[FC_CULL_CC];
+                        const float b = dv[0] * blk[FC_CULL_OC] + dv[1] * blk[FC_CULL_OC + 1] + dv[2] * blk[FC_CULL_OC + 2];
+                        if (!(cc <= 0.0f || (b > 0.0f && b * b >= dd * cc))) continue;
+                        const int slot = atomicAdd(mb_count, 1);
+                        if (slot < MB_TASKS) mb_tasks[slot] = (uint16_t)(lane | (kk << 6) | (bi << 8));
+                        else {   // list full (dozens of meshes behind one pixel): walked on the spot, by this lane
+                            float t; int tri;
+                            // (every lane must take part in walk_pair's wave-wide loop: not here - a plain per-lane walk)
+                            uint32_t kk_key = 0; float th_l = __int_as_float((int)(mb_slots[kk * WAVE + lane] >> 32));
+                            walk_meshes(1u << bi, dv, dd, th_l, kk_key);
+                            if (kk_key) atomicMin(&mb_slots[kk * WAVE + lane], ((unsigned long long)(uint32_t)__float_as_int(th_l) << 32) | 0x80000000u | ((uint32_t)bi << 24) | (kk_key >> 8));
+                            (void)t; (void)tri;
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int n_tasks = min(*mb_count, MB_TASKS);
+#pragma unroll 1
+            for (int base = 0; base < n_tasks; base += WAVE) {
+                const bool act = base + lane < n_tasks;
+                const uint32_t tk = act ? mb_tasks[base + lane] : 0u;
+                const int src = tk & 63u, kk = (tk >> 6) & 3u, bi = tk >> 8;
+                const uint32_t sp = mb_pix[src];
+                const float scx = (float)(sp & 0xFFFFu) + 0.5f, scy = (float)(H - 1 - (int)(sp >> 16)) + 0.5f;
+                float dv[3];
+                const int k = half * MB_HALF + kk;
+                make_ray(cam, scx + c_sample_x[k], scy + c_sample_y[k], dv);
+                const float th0 = __int_as_float((int)(mb_slots[kk * WAVE + src] >> 32));
+                float t; int tri;
+                if (walk_pair(act, bi, dv, th0, t, tri) && act)
+                    atomicMin(&mb_slots[kk * WAVE + src], ((unsigned long long)(uint32_t)__float_as_int(t) << 32) | 0x80000000u | ((uint32_t)bi << 24) | (uint32_t)tri);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kk = 0; kk < MB_HALF; kk++) {   // my pixel's samples: the distinct surfaces in order of first appearance (pixel_full)
+                const int k = half * MB_HALF + kk;
+                const unsigned long long sl = mb_slots[kk * WAVE + lane];
+                const uint32_t lw = (uint32_t)sl;
+                const float th = __int_as_float((int)(sl >> 32));
+                const uint32_t key = (lw & 0x80000000u) ? (KIND_MESH | (((lw >> 24) & 31u) << 3) | ((lw & 0xFFFFFFu) << 8)) : knm[kk];
+                if (k == 0) { key_s0 = key; t_s0 = th; }
+                const bool h0 = (meta & 0xFu) && key == k0, h1 = (meta & 0xF0u) && key == k1;
+                const bool h2 = (meta & 0xF00u) && key == k2, h3 = (meta & 0xF000u) && key == k3;
+                meta += (h0 ? 1u : 0u) + (h1 ? 0x10u : 0u) + (h2 ? 0x100u : 0u) + (h3 ? 0x1000u : 0u);
+                if (!(h0 || h1 || h2 || h3)) {
+                    if (!(meta & 0xFu)) { k0 = key; meta |= 1u | ((uint32_t)k << 16); }
+                    else if (!(meta & 0xF0u)) { k1 = key; meta |= 0x10u | ((uint32_t)k << 19); }
+                    else if (!(meta & 0xF00u)) { k2 = key; meta |= 0x100u | ((uint32_t)k << 22); }
+                    else if (!(meta & 0xF000u)) { k3 = key; meta |= 0x1000u | ((uint32_t)k << 25); }
+                    else if (valid) {
+                        float col[3];
+                        shade<false>(key, k, cx, cy, col);
+                        acc[0] += col[0]; acc[1] += col[1]; acc[2] += col[2];
+                    }
+                }
+            }
+        }
+        if (!valid) return;
+#pragma unroll 1
+        for (int it = 0; it < 4 && (meta & 0xFu); it++) {
+            float col[3];
+            shade<false>(k0, (meta >> 16) & 7u, cx, cy, col);
+            const float cnt = (float)(meta & 0xFu);
+#pragma unroll
+            for (int q = 0; q < 3; q++) acc[q] += cnt * col[q];
+            k0 = k1; k1 = k2; k2 = k3;
+            meta = ((meta & 0xFFFFu) >> 4) | ((meta >> 19) << 16);
+        }
+        write_pixel<false>(px, py, acc, (key_s0 & 7u) != KIND_SKY, t_s0);
+    }
+
     __device__ __forceinline__ void pixel_full(int px, int py, int skip) const {
         const float cx = (float)px + 0.5f, cy = (float)(H - 1 - py) + 0.5f;
         int start_room = cam_room;
@@ -2786,9 +3006,8 @@ struct RenderCtx {
                         }
                     }
                 }
-                if constexpr (NBOX > MWB_MAX_BOXES) {
-                    if (!(exp_flags & 1)) walk_meshes(my_boxes & mesh_slots, dv, dd, th, key);
-                }
+                // (entity tasks: no mesh can touch a pixel that comes this way - the pixels a mesh may cover, by the pixel-inflated gate
+                // of emit(), are batched apart and go through pixels_mesh)
             }
             if (k == 0) { key_s0 = key; t_s0 = th; }
             const bool h0 = (meta & 0xFu) && key == k0, h1 = (meta & 0xF0u) && key == k1;
@@ -2906,6 +3125,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     uint16_t *mqueues = (uint16_t *)(smem + ((off + (size_t)W * H * 3 + 15) & ~(size_t)15));
     int *mleft = (int *)(mqueues + (THREADS / WAVE) * QUEUE_CAP);
     uint4 *mdesc = (uint4 *)(mleft + 4);   // entity tasks: [MWB_NUM_MESHES], see RenderCtx::mdesc
+    uint8_t *mb_base = (uint8_t *)(mdesc + MWB_NUM_MESHES) + (size_t)(tid / WAVE) * MB_WAVE_BYTES;   // this wave's batch scratch (pixels_mesh)
 
     {   // stage the room table, the frame constants and the texture descriptors
         const int rw = POLY ? MWB_POLY_ROOM_WORDS : MWB_ROOM_WORDS;
@@ -2925,6 +3145,8 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     RenderCtx<NBOX, POLY> ctx;
     ctx.rooms = rooms; ctx.fc = fc; ctx.tex = tex; ctx.texels = d.texels; ctx.fb = fb;
     ctx.mesh_desc = d.mesh_desc; ctx.mesh_data = d.mesh_data; ctx.mdesc = mdesc;
+    ctx.mb_slots = (unsigned long long *)mb_base; ctx.mb_tasks = (uint16_t *)(mb_base + MB_HALF * WAVE * 8);
+    ctx.mb_pix = (uint32_t *)(mb_base + MB_HALF * WAVE * 8 + MB_TASKS * 2); ctx.mb_count = (int *)(mb_base + MB_HALF * WAVE * 8 + MB_TASKS * 2 + WAVE * 4);
     ctx.exp_flags = d.exp_flags; ctx.mesh_slots = 0; ctx.dbg_counters = d.dbg_counters;
     if constexpr (NBOX > MWB_MAX_BOXES) {   // which slots hold a mesh in this frame
         uint32_t ms = 0;
@@ -3072,7 +3294,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             if (mq_count >= WAVE) {
                 mq_count -= WAVE;
                 const int q = mqueue[mq_count + lane];
-                if (!(d.debug_flags & 2)) ctx.pixel_full(q & wmask, (q >> wshift) & hmask, q >> qshift);
+                if (!(d.debug_flags & 2)) ctx.pixels_mesh(q & wmask, (q >> wshift) & hmask, q >> qshift, true);
             }
         }
         const unsigned long long em = __ballot(edge);
@@ -3305,9 +3527,12 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
                 const int c = mleft[w];
                 if (owner < 0) { if (g < c) owner = w; else g -= c; }
             }
-            if (owner >= 0) {
-                const int q = mqueues[owner * QUEUE_CAP + g];
-                ctx.pixel_full(q & wmask, (q >> wshift) & hmask, q >> qshift);
+            int total = 0;
+#pragma unroll
+            for (int w = 0; w < THREADS / WAVE; w++) total += mleft[w];
+            if ((tid & ~(WAVE - 1)) < total) {   // this wave has pixels to do (a wave-uniform condition: pixels_mesh is a wave's joint work)
+                const int q = owner >= 0 ? mqueues[owner * QUEUE_CAP + g] : 0;
+                ctx.pixels_mesh(q & wmask, (q >> wshift) & hmask, q >> qshift, owner >= 0);
             }
         }
     }
@@ -3577,7 +3802,7 @@ static size_t render_lds_bytes_for(const MwbDev &d, int W, int H) {
     size_t b = (((size_t)d.R_max * d.room_words * 4 + 15) & ~(size_t)15) + (size_t)d.frame_words * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
                (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)ITEM_RES_BYTES(W) + (size_t)W * H * 3;
     b = (b + 15) & ~(size_t)15;
-    if (d.ent_task) b += (RENDER_THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t) + 16 + 16 * MWB_NUM_MESHES;   // the mesh-pixel queues, their leftover counts, the mesh descriptors
+    if (d.ent_task) b += (RENDER_THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t) + 16 + 16 * MWB_NUM_MESHES + (RENDER_THREADS / WAVE) * MB_WAVE_BYTES;   // the mesh-pixel queues, their leftover counts, the mesh descriptors, the batch scratch
     return (b + 15) & ~(size_t)15;
 }
 // d: the handle's MwbDev with W / H / obs / depth / frame / want_depth / layout set for the view
