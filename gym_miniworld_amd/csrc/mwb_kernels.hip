@@ -2731,24 +2731,51 @@ struct RenderCtx {
     // the centre ray.  The traversal computes every distance from the eye, never from the previous room, so the
     // results are bit-identical to a start in the eye's room (guarded by test_fast_path_equals_full_sample_path's
     // MWB_DEBUG=8 leg).
-    // One (ray, mesh) pair: the walk of mesh slot bi along (eye, dv) by this lane alone, every lane of the wave with a pair of its own
-    // (dense: walk_meshes' loop with the candidate phase taken out).  th: nothing farther matters; -> hit, t, triangle.
-    __device__ __forceinline__ bool walk_pair(bool active, int bi, const float *dv, float th, float &t_out, int &tri_out) const {
+    // The list of (ray, mesh) pairs of a round, walked by the whole wave: a lane takes the next pair off the list (an LDS cursor) as
+    // soon as it has finished its own - walks differ in length by an order of magnitude (a ray grazing a ball's outline visits 30
+    // nodes, one that misses its box two), so with 64 pairs started and finished together the wave ran as long as its longest walk
+    // (40 % of the lanes busy).  A pair's result goes into its ray's slot with a 64-bit atomic minimum (t, then non-mesh before mesh,
+    // then slot, then triangle: the drawing order's tie rules, whatever order the pairs finish in).
+    __device__ __forceinline__ void walk_pairs(int n_tasks, int half) const {
         const f4n *gd = (const f4n *)mesh_data;
         const f4n *nodes = gd, *tris = gd;
-        float lo[3] = {0, 0, 0}, ld[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
-        int node = 0, n_nodes = 0, best = -1, leaf_first = 0, leaf_cnt = 0;
-        unsigned c_visits = 0, c_tris = 0, c_iters = 0;
-        if (active) {
-            const float *blk = fc + bi * FC_BOX_STRIDE;
-            mesh_local_dir(blk, dv, ld);
-            lo[0] = blk[FC_BOX_LO]; lo[1] = blk[FC_BOX_LO + 1]; lo[2] = blk[FC_BOX_LO + 2];
-            inv[0] = __builtin_amdgcn_rcpf(ld[0]); inv[1] = __builtin_amdgcn_rcpf(ld[1]); inv[2] = __builtin_amdgcn_rcpf(ld[2]);
-            const uint4 md = mdesc[__float_as_int(blk[FC_LIT_BOX + FE_MESH_GEOM])];
-            const uint32_t oct = md.w == 8u ? ((ld[0] < 0.0f ? 1u : 0u) | (ld[1] < 0.0f ? 2u : 0u) | (ld[2] < 0.0f ? 4u : 0u)) : 0u;
-            nodes = gd + md.x + (size_t)(oct * 2u * md.z); tris = gd + md.y; n_nodes = (int)md.z;
-        }
-        while (__any(node < n_nodes)) {
+        float lo[3] = {0, 0, 0}, ld[3] = {0, 0, 0}, inv[3] = {0, 0, 0}, th = 0.0f;
+        int node = 0, n_nodes = 0, best = -1, leaf_first = 0, leaf_cnt = 0, bi = 0, slot_idx = 0;
+        bool have = false, more = true;
+        unsigned c_visits = 0, c_tris = 0, c_iters = 0, c_walks = 0;
+        for (;;) {
+            // (a) lanes without a pair in progress: hand in the finished one, take the next
+            while (node >= n_nodes && (have || more)) {
+                if (have) {
+                    if (best >= 0) atomicMin(&mb_slots[slot_idx], ((unsigned long long)(uint32_t)__float_as_int(th) << 32) | 0x80000000u | ((uint32_t)bi << 24) | (uint32_t)best);
+                    have = false;
+                }
+                const int ti = atomicAdd(mb_count + 1, 1);
+                if (ti >= n_tasks) { more = false; break; }
+                const uint32_t tk = mb_tasks[ti];
+                const int src = tk & 63u, kk = (tk >> 6) & 3u;
+                bi = tk >> 8;
+                slot_idx = kk * WAVE + src;
+                const uint32_t sp = mb_pix[src];
+                const float scx = (float)(sp & 0xFFFFu) + 0.5f, scy = (float)(H - 1 - (int)(sp >> 16)) + 0.5f;
+                float dv[3];
+                const int k = half * MB_HALF + kk;
+                make_ray(cam, scx + c_sample_x[k], scy + c_sample_y[k], dv);
+                th = __int_as_float((int)(mb_slots[slot_idx] >> 32));   // nothing farther matters (another pair's result may already be in)
+                const float *blk = fc + bi * FC_BOX_STRIDE;
+                mesh_local_dir(blk, dv, ld);
+                lo[0] = blk[FC_BOX_LO]; lo[1] = blk[FC_BOX_LO + 1]; lo[2] = blk[FC_BOX_LO + 2];
+                // the node boxes are padded by 1e-4 of the mesh (host): a 1-ulp reciprocal cannot lose a real hit
+                inv[0] = __builtin_amdgcn_rcpf(ld[0]); inv[1] = __builtin_amdgcn_rcpf(ld[1]); inv[2] = __builtin_amdgcn_rcpf(ld[2]);
+                const uint4 md = mdesc[__float_as_int(blk[FC_LIT_BOX + FE_MESH_GEOM])];
+                // the threading that visits the nearer child first for this ray's direction (bit a: component a negative)
+                const uint32_t oct = md.w == 8u ? ((ld[0] < 0.0f ? 1u : 0u) | (ld[1] < 0.0f ? 2u : 0u) | (ld[2] < 0.0f ? 4u : 0u)) : 0u;
+                nodes = gd + md.x + (size_t)(oct * 2u * md.z); tris = gd + md.y; n_nodes = (int)md.z;
+                node = 0; best = -1; have = true;
+                c_walks++;
+            }
+            if (!__any(node < n_nodes)) break;
+            // (b) node steps only, two records per fetch (a descent costs no second round trip)
             while (leaf_cnt == 0 && node < n_nodes) {
                 c_iters++;
                 const int nx = node + 1 < n_nodes ? node + 1 : node;
@@ -2771,6 +2798,7 @@ struct RenderCtx {
                 };
                 if (visit(a, bb)) visit(a2, b2);
             }
+            // (c) leaves: spec arithmetic; triangle q + 1 requested before triangle q is tested
             if (leaf_cnt) {
                 c_iters++;
                 f4n p0 = tris[3 * leaf_first], p1 = tris[3 * leaf_first + 1], p2 = tris[3 * leaf_first + 2];
@@ -2783,7 +2811,7 @@ struct RenderCtx {
                     if (mesh_tri(lo, ld, r0, r1, r2, true, t, u, v, det)) {
                         const int idx = __float_as_int(r2.y);
                         // t == th with no hit of this walk yet: kept - th may be another pair's result for the same ray, and the
-                        // merge (t, non-mesh first, slot, triangle) decides, whatever the order the pairs finish in
+                        // merge decides
                         if (t < th || (t == th && (best < 0 || idx < best))) { th = t; best = idx; }
                     }
                 }
@@ -2791,14 +2819,12 @@ struct RenderCtx {
             leaf_cnt = 0;
         }
         if ((exp_flags & 4) && dbg_counters) {
-            if (active) { atomicAdd(dbg_counters + 0, 1ull); atomicAdd(dbg_counters + 1, 1ull); }
+            atomicAdd(dbg_counters + 0, (unsigned long long)c_walks); atomicAdd(dbg_counters + 1, (unsigned long long)c_walks);
             atomicAdd(dbg_counters + 2, (unsigned long long)c_visits); atomicAdd(dbg_counters + 3, (unsigned long long)c_tris);
             unsigned mx = c_iters;
             for (int o = 32; o; o >>= 1) { const unsigned v = __shfl_xor(mx, o); mx = v > mx ? v : mx; }
             if ((threadIdx.x & 63) == 0) { atomicAdd(dbg_counters + 4, (unsigned long long)mx); atomicAdd(dbg_counters + 5, 1ull); }
         }
-        t_out = th; tri_out = best;
-        return best >= 0;
     }
 
     // Entity tasks: a batch of up to 64 pixels out of the mesh-pixel queue (lane = pixel; valid: this lane holds one).  pixel_full's
@@ -2828,7 +2854,7 @@ struct RenderCtx {
         float acc[3] = {0, 0, 0};
 #pragma unroll 1
         for (int half = 0; half < 8 / MB_HALF; half++) {
-            if (lane == 0) *mb_count = 0;
+            if (lane == 0) { mb_count[0] = 0; mb_count[1] = 0; }   // pairs listed, pairs taken
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             uint32_t knm[MB_HALF];
@@ -2883,21 +2909,7 @@ struct RenderCtx {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int n_tasks = min(*mb_count, MB_TASKS);
-#pragma unroll 1
-            for (int base = 0; base < n_tasks; base += WAVE) {
-                const bool act = base + lane < n_tasks;
-                const uint32_t tk = act ? mb_tasks[base + lane] : 0u;
-                const int src = tk & 63u, kk = (tk >> 6) & 3u, bi = tk >> 8;
-                const uint32_t sp = mb_pix[src];
-                const float scx = (float)(sp & 0xFFFFu) + 0.5f, scy = (float)(H - 1 - (int)(sp >> 16)) + 0.5f;
-                float dv[3];
-                const int k = half * MB_HALF + kk;
-                make_ray(cam, scx + c_sample_x[k], scy + c_sample_y[k], dv);
-                const float th0 = __int_as_float((int)(mb_slots[kk * WAVE + src] >> 32));
-                float t; int tri;
-                if (walk_pair(act, bi, dv, th0, t, tri) && act)
-                    atomicMin(&mb_slots[kk * WAVE + src], ((unsigned long long)(uint32_t)__float_as_int(t) << 32) | 0x80000000u | ((uint32_t)bi << 24) | (uint32_t)tri);
-            }
+            if (n_tasks > 0) walk_pairs(n_tasks, half);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
