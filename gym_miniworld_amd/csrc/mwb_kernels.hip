@@ -2206,6 +2206,7 @@ __device__ __forceinline__ bool mesh_tri(const float *lo, const float *ld, const
 }
 // nearest front-facing triangle of the entity's mesh along (eye, dv) that is strictly nearer than t_max: its index in draw order
 // or -1.  Threaded BVH (host-built, gym_miniworld_amd/meshes.py): depth-first node order, `skip` links, no stack.
+#define MQ_CAP 320     // mesh-pixel queue entries per wave: batches wait for the end of the frame, where all waves share them
 #define MB_HALF 4      // pixels_mesh: samples per round
 #define MB_TASKS 320   //   (ray, mesh) pairs per round
 #define MB_WAVE_BYTES (MB_HALF * 64 * 8 + MB_TASKS * 2 + 64 * 4 + 16)   // per wave: slots, pairs, pixel coordinates, counter
@@ -3135,7 +3136,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     uint8_t *fb = smem + off;   // the frame is assembled in LDS and leaves as 16-byte coalesced stores
     // entity tasks: a third queue per wave for the 8-sample pixels a mesh may cover, and its leftover counts (behind the frame)
     uint16_t *mqueues = (uint16_t *)(smem + ((off + (size_t)W * H * 3 + 15) & ~(size_t)15));
-    int *mleft = (int *)(mqueues + (THREADS / WAVE) * QUEUE_CAP);
+    int *mleft = (int *)(mqueues + (THREADS / WAVE) * MQ_CAP);
     uint4 *mdesc = (uint4 *)(mleft + 4);   // entity tasks: [MWB_NUM_MESHES], see RenderCtx::mdesc
     uint8_t *mb_base = (uint8_t *)(mdesc + MWB_NUM_MESHES) + (size_t)(tid / WAVE) * MB_WAVE_BYTES;   // this wave's batch scratch (pixels_mesh)
 
@@ -3236,7 +3237,7 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
     uint32_t *iq_key = ikeys + wave * QUEUE_CAP;
     uint16_t *iq_pix = ipix + wave * QUEUE_CAP;
     int q_count = 0, iq_count = 0;   // wave-uniform
-    uint16_t *mqueue = mqueues + wave * QUEUE_CAP;
+    uint16_t *mqueue = mqueues + wave * MQ_CAP;
     int mq_count = 0;
     const int ci = lane & (TILE_CX - 1), cj = lane / TILE_CX;
     const int n_strips = (W + TILE_CX - 2) / (TILE_CX - 1);
@@ -3303,7 +3304,9 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
             if (mesh_px) mqueue[mq_count + __popcll(mm & ((1ull << lane) - 1ull))] = (uint16_t)((skip << qshift) | (py << wshift) | px);
             mq_count += __popcll(mm);
             edge = edge && !mesh_px;
-            if (mq_count >= WAVE) {
+            // Mesh pixels cluster (a ball covers a few items of one or two waves' strips): batches are NOT processed as they fill up but
+            // kept for the end of the frame, where the four waves share them evenly; only a queue about to overflow is drained here.
+            if (mq_count > MQ_CAP - WAVE) {
                 mq_count -= WAVE;
                 const int q = mqueue[mq_count + lane];
                 if (!(d.debug_flags & 2)) ctx.pixels_mesh(q & wmask, (q >> wshift) & hmask, q >> qshift, true);
@@ -3532,19 +3535,21 @@ __device__ __forceinline__ void render_env(const MwbDev &d, const int e, const i
         }
     }
     if constexpr (NBOX > MWB_MAX_BOXES) {
-        if (!(d.debug_flags & 2)) {   // the mesh pixels left over, pooled the same way
-            int g = tid, owner = -1;
-#pragma unroll
-            for (int w = 0; w < THREADS / WAVE; w++) {
-                const int c = mleft[w];
-                if (owner < 0) { if (g < c) owner = w; else g -= c; }
-            }
+        if (!(d.debug_flags & 2)) {   // the mesh pixels, pooled the same way: 64-pixel batches dealt out to the waves in turn
             int total = 0;
 #pragma unroll
             for (int w = 0; w < THREADS / WAVE; w++) total += mleft[w];
-            if ((tid & ~(WAVE - 1)) < total) {   // this wave has pixels to do (a wave-uniform condition: pixels_mesh is a wave's joint work)
-                const int q = owner >= 0 ? mqueues[owner * QUEUE_CAP + g] : 0;
-                ctx.pixels_mesh(q & wmask, (q >> wshift) & hmask, q >> qshift, owner >= 0);
+            for (int base = 0; base < total; base += THREADS) {
+                int g = base + tid, owner = -1;
+#pragma unroll
+                for (int w = 0; w < THREADS / WAVE; w++) {
+                    const int c = mleft[w];
+                    if (owner < 0) { if (g < c) owner = w; else g -= c; }
+                }
+                if (base + (tid & ~(WAVE - 1)) < total) {   // this wave has pixels to do (wave-uniform: pixels_mesh is a wave's joint work)
+                    const int q = owner >= 0 ? mqueues[owner * MQ_CAP + g] : 0;
+                    ctx.pixels_mesh(q & wmask, (q >> wshift) & hmask, q >> qshift, owner >= 0);
+                }
             }
         }
     }
@@ -3814,7 +3819,7 @@ static size_t render_lds_bytes_for(const MwbDev &d, int W, int H) {
     size_t b = (((size_t)d.R_max * d.room_words * 4 + 15) & ~(size_t)15) + (size_t)d.frame_words * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
                (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)ITEM_RES_BYTES(W) + (size_t)W * H * 3;
     b = (b + 15) & ~(size_t)15;
-    if (d.ent_task) b += (RENDER_THREADS / WAVE) * QUEUE_CAP * sizeof(uint16_t) + 16 + 16 * MWB_NUM_MESHES + (RENDER_THREADS / WAVE) * MB_WAVE_BYTES;   // the mesh-pixel queues, their leftover counts, the mesh descriptors, the batch scratch
+    if (d.ent_task) b += (RENDER_THREADS / WAVE) * MQ_CAP * sizeof(uint16_t) + 16 + 16 * MWB_NUM_MESHES + (RENDER_THREADS / WAVE) * MB_WAVE_BYTES;   // the mesh-pixel queues, their leftover counts, the mesh descriptors, the batch scratch
     return (b + 15) & ~(size_t)15;
 }
 // d: the handle's MwbDev with W / H / obs / depth / frame / want_depth / layout set for the view
