@@ -2365,6 +2365,11 @@ struct RenderCtx {
 
     // rays through the +1 pixel neighbours (for the LOD differences): the ray is affine in the window
     // coordinates, so they are the centre ray plus a per-frame constant (shading-only, tolerance-bound)
+    __device__ __forceinline__ static void neighbour_rays_of(const Cam &cam, const float *dc, float *dx, float *dy) {
+        const float sx = 2.0f * cam.invW * cam.TW, sy = 2.0f * cam.invH * cam.TH;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { dx[k] = fmaf(cam.S[k], sx, dc[k]); dy[k] = fmaf(cam.U[k], sy, dc[k]); }
+    }
     __device__ __forceinline__ void neighbour_rays(const float *dc, float *dx, float *dy) const {
         const float sx = 2.0f * cam.invW * cam.TW, sy = 2.0f * cam.invH * cam.TH;
 #pragma unroll
@@ -2544,7 +2549,11 @@ struct RenderCtx {
     // rasteriser without centroid sampling does): per-vertex fixed-function lighting with the normal R n / scale (not
     // renormalised: GL_NORMALIZE is off), clamped to 1, interpolated with the centre ray's barycentrics; where the centre ray sees
     // the triangle's back or edge, the covering sample's ray instead; a textured mesh modulates by its image.
-    __device__ __noinline__ void shade_mesh(uint32_t key, int first_k, float cx, float cy, float *col) const {
+    // (static, every input an argument: a non-inlined MEMBER function would take `this`, and a context whose address escapes lives in
+    // scratch memory for the whole kernel - 40 % slower when tried on another function)
+    __device__ __noinline__ static void shade_mesh_s(const float *fc, const MwbMeshDesc *mesh_desc, const float4 *mesh_data, const TexLds *tex, const uint32_t *texels,
+                                                     const Cam *cam_p, int exp_flags, uint32_t key, int first_k, float cx, float cy, float *col) {
+        const Cam &cam = *cam_p;
         if (exp_flags & 2) { col[0] = 0.5f; col[1] = 0.5f; col[2] = 0.5f; return; }   // experiment: flat grey meshes
         const int bi = (int)((key >> 3) & 31u), tri = (int)(key >> 8);
         const float *blk = fc + bi * FC_BOX_STRIDE;
@@ -2586,7 +2595,7 @@ struct RenderCtx {
             bool valid = false;
             if (centre_ok) {
                 float dx[3], dy[3], l1[3], l2[3], tt, u1, v1, d1, u2, v2, d2;
-                neighbour_rays(dc, dx, dy);
+                neighbour_rays_of(cam, dc, dx, dy);
                 mesh_local_dir(blk, dx, l1); mesh_local_dir(blk, dy, l2);
                 const bool ok1 = mesh_tri(lo, l1, r0, r1, r2, false, tt, u1, v1, d1), ok2 = mesh_tri(lo, l2, r0, r1, r2, false, tt, u2, v2, d2);
                 valid = ok1 && ok2;
@@ -2603,7 +2612,8 @@ struct RenderCtx {
         }
     }
     // the front of an ImageFrame / TextFrame (its picture, or one texture per character; a blank cell is plain lit white) or a black side
-    __device__ __noinline__ void shade_frame(uint32_t key, int first_k, float cx, float cy, float *col) const {
+    __device__ __noinline__ static void shade_frame_s(const float *fc, const TexLds *tex, const uint32_t *texels, const Cam *cam_p, uint32_t key, int first_k, float cx, float cy, float *col) {
+        const Cam &cam = *cam_p;
         const int bi = (int)((key >> 3) & 31u), code = (int)(key >> 8);
         const float *blk = fc + bi * FC_BOX_STRIDE;
         const float *fe = blk + FC_LIT_BOX;
@@ -2612,7 +2622,7 @@ struct RenderCtx {
         if (tex_id < 0) { col[0] = fe[FE_FRAME_LIT]; col[1] = fe[FE_FRAME_LIT + 1]; col[2] = fe[FE_FRAME_LIT + 2]; return; }
         float dc[3], dx[3], dy[3], s0, t0, s1, t1, s2, t2;
         make_ray(cam, cx, cy, dc);
-        neighbour_rays(dc, dx, dy);
+        neighbour_rays_of(cam, dc, dx, dy);
         bool valid;
         if (!frame_front_tc(blk, code, dc, s0, t0)) {
             float ds[3];
@@ -2636,10 +2646,11 @@ struct RenderCtx {
         if constexpr (!INTERIOR && NBOX > MWB_MAX_BOXES) {   // entity tasks
             if (kind == KIND_MESH) {
                 if (exp_flags & 8) { col[0] = col[1] = col[2] = 0.5f; return; }   // experiment: no call at all (the cost of the call itself)
-                shade_mesh(key, first_k, cx, cy, col);
+                const Cam cam_copy = cam;   // only this copy's address leaves the function
+                shade_mesh_s(fc, mesh_desc, mesh_data, tex, texels, &cam_copy, exp_flags, key, first_k, cx, cy, col);
                 return;
             }
-            if (kind == KIND_FRAME) { shade_frame(key, first_k, cx, cy, col); return; }
+            if (kind == KIND_FRAME) { const Cam cam_copy = cam; shade_frame_s(fc, tex, texels, &cam_copy, key, first_k, cx, cy, col); return; }
         }
         if (!INTERIOR) {
             if (kind == KIND_SKY) { col[0] = fc[FC_SKY]; col[1] = fc[FC_SKY + 1]; col[2] = fc[FC_SKY + 2]; return; }

@@ -15,7 +15,7 @@ import pytest
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-ENT_SCRATCH_LIMIT = {False: 624, True: 752}   # the entity instantiation's scratch (B/lane): bulk, side stream - to be brought down
+ENT_SCRATCH_LIMIT = {False: 640, True: 768}   # the entity instantiation's scratch (B/lane): bulk, side stream - to be brought down
 pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
 
 
