@@ -382,6 +382,15 @@ extern "C" int mwb_create(const mwb_config *cfg, mwb_handle **out) {
         return set_err(MWB_EHIP, "mwb_create: could not create the side stream / events");
     }
     for (int i = 0; i < MWB_MAX_TEX; i++) { h->tex_w[i] = 0; h->tex_h[i] = 0; }
+    if (d.tile_w == 0) {   // an observation that does not fit one workgroup's LDS (or its 16-bit pixel queue) is rendered in tiles, like mwb_render_view's frames
+        int wshift = 0;
+        while ((1 << wshift) < d.W) wshift++;
+        if (mwb_render_lds_bytes(d) > 160 * 1024 || ((size_t)d.H << wshift) > 65536) {
+            int tw = 0, th = 0;
+            mwb_view_tile(&tw, &th);
+            d.tile_w = tw < d.W ? tw : d.W; d.tile_h = th < d.H ? th : d.H;
+        }
+    }
     if (int prc = mwb_prepare_kernels(d)) {
         mwb_destroy(h);
         return set_err(prc == -2 ? MWB_EHIP : MWB_EINVAL,
@@ -825,7 +834,7 @@ extern "C" int mwb_stack_enable(mwb_handle *h, int nstack, int dtype) {
     if (h->stack) return set_err(MWB_ESTATE, "mwb_stack_enable: already enabled");
     // a fused window is filled by the render kernels as they produce frames: enabled after the first observation it would
     // lack the current frame until the next pass (the non-fused forms rebuild theirs from the observation buffer)
-    if (fused && h->dev.tile_w > 0) return set_err(MWB_EINVAL, "mwb_stack_enable: MWB_STACK_FUSED is not available for the tasks rendered in tiles (the mesh-entity tasks): use MWB_STACK_SLIDING");
+    if (fused && h->dev.tile_w > 0) return set_err(MWB_EINVAL, "mwb_stack_enable: MWB_STACK_FUSED is not available when observations are rendered in tiles (large frames, MWB_TILE): use MWB_STACK_SLIDING");
     if (fused && h->have_obs) return set_err(MWB_ESTATE, "mwb_stack_enable: MWB_STACK_FUSED must be enabled before the first mwb_reset / mwb_step / mwb_render");
     if (fused && dtype == 0 && (d.W * d.H) % 16) return set_err(MWB_EINVAL, "mwb_stack_enable: a fused uint8 stack needs W*H to be a multiple of 16");
     USE_DEVICE(h->cfg.device);

@@ -220,6 +220,7 @@ void mwb_launch_step(const MwbDev &d, const int32_t *actions, const uint8_t *ski
 void mwb_launch_clear_list(const MwbDev &d, hipStream_t s);
 void mwb_launch_order(const MwbDev &d, hipStream_t s);   // envs by decreasing measured frame cost -> the map not in use
 void mwb_launch_mark_reset(const MwbDev &d, const uint8_t *mask, hipStream_t s);
+void mwb_view_tile(int *w, int *h);   // the tile mwb_render_view (and large observations) are rendered in
 void mwb_launch_reset(const MwbDev &d, int max_blocks, hipStream_t s);   // grid-strides over reset_list
 // mode 0: every env; 1: only envs with reset_set; 2: only envs without (lets reset overlap the bulk render)
 void mwb_launch_prep(const MwbDev &d, int mode, hipStream_t s);

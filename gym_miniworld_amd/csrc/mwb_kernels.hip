@@ -3857,8 +3857,10 @@ static int launch_tiles(const MwbDev &d, int tile_w, int tile_h, hipStream_t s) 
     return 0;
 }
 int mwb_launch_render_view(const MwbDev &d, hipStream_t s) { return launch_tiles<0>(d, VIEW_TILE_W, VIEW_TILE_H, s); }
+void mwb_view_tile(int *w, int *h) { *w = VIEW_TILE_W; *h = VIEW_TILE_H; }
 
 size_t mwb_render_lds_bytes(const MwbDev &d) {
+    if (d.tile_w > 0) return render_lds_bytes_for(d, d.tile_w, d.tile_h);   // observations rendered in tiles (large frames)
     if (d.ent_task) return render_lds_bytes_for(d, d.W, d.H);
     size_t b = (((size_t)d.R_max * d.room_words * 4 + 15) & ~(size_t)15) + (size_t)d.frame_words * 4 + sizeof(TexLds) * d.n_tex + 16 + 2 * (RENDER_THREADS / WAVE) * sizeof(int) +
                (RENDER_THREADS / WAVE) * QUEUE_CAP * (2 * sizeof(uint16_t) + sizeof(uint32_t)) + (size_t)ITEM_RES_BYTES(d.W) + (size_t)d.W * d.H * 3;
@@ -3887,8 +3889,9 @@ int mwb_prepare_kernels(const MwbDev &d) {
     if (r > 160 * 1024 || q > 160 * 1024) return -1;
     {   // the render kernel's pixel queues hold (py << ceil(log2 W)) | px in 16 bits
         int wshift = 0;
-        while ((1 << wshift) < d.W) wshift++;
-        if (((size_t)d.H << wshift) > 65536) return -3;
+        const int qw = d.tile_w > 0 ? d.tile_w : d.W, qh = d.tile_w > 0 ? d.tile_h : d.H;
+        while ((1 << wshift) < qw) wshift++;
+        if (((size_t)qh << wshift) > 65536) return -3;
     }
     if (r > 64 * 1024 && hipFuncSetAttribute((const void *)reset_fn(d.task), hipFuncAttributeMaxDynamicSharedMemorySize, (int)r) != hipSuccess) return -2;
     if (q > 64 * 1024) {   // large mazes, or any task at a large observation size (the W*H*3 frame is in LDS too)
@@ -3924,7 +3927,7 @@ void mwb_launch_render(const MwbDev &d, int mode, hipStream_t s) {
     const dim3 g(d.N + d.split_envs), b(RENDER_THREADS);
     const size_t lds = mwb_render_lds_bytes(d);
     const dim3 gl(d.N < LIST_GRID ? d.N : LIST_GRID);
-    if (d.ent_task && d.tile_w > 0) {   // every frame as a few tiles, one workgroup each (see render_view_kernel)
+    if (d.tile_w > 0) {   // every frame as a few tiles, one workgroup each (see render_view_kernel): frames too large for one workgroup's LDS
         if (mode == 1) (void)launch_tiles<1>(d, d.tile_w, d.tile_h, s);
         else if (mode == 2) (void)launch_tiles<2>(d, d.tile_w, d.tile_h, s);
         else (void)launch_tiles<0>(d, d.tile_w, d.tile_h, s);

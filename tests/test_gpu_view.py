@@ -48,3 +48,46 @@ def test_view_equals_oracle_at_other_sizes(oracle_mod, env_id, task, args, dr):
             assert d.max() <= 1 and np.abs(dep[i] - refd).max() <= 1e-4, (env_id, W, H, i, int(d.max()), int((d > 1).sum()))
     assert np.array_equal(b.obs.cpu().numpy(), obs)   # the observation buffers are untouched
     b.close()
+
+
+@pytest.mark.parametrize("env_id,task,args,layout", [("MiniWorld-Hallway-v0", "Hallway", None, "HWC"), ("MiniWorld-FourRooms-v0", "FourRooms", None, "CWH"),
+                                                     ("MiniWorld-PutNext-v0", "PutNext", None, "HWC")])
+def test_observations_too_large_for_one_workgroup_are_rendered_in_tiles(oracle_mod, env_id, task, args, layout):
+    """obs_width / obs_height are constructor arguments of the reference without an upper limit (miniworld.py:459-460): a 320 x 240
+    observation (230 KB, more than a workgroup's LDS) is rendered in tiles by reset and by every step - frames +-1 and depth
+    1e-4 m against the oracle at that size, through auto-resets, in both layouts"""
+    import torch
+    from gym_miniworld_amd.batch import BatchedMiniWorld
+    O = oracle_mod
+    n, W, H = 6, 320, 240
+    b = BatchedMiniWorld(env_id, num_envs=n, seed=5, domain_rand=1, want_depth=True, obs_width=W, obs_height=H, layout=layout, max_episode_steps=7)
+    envs = [O.OracleEnv(task, seed=5 + i, domain_rand=1, task_args=args, obs_width=W, obs_height=H, max_episode_steps=7) for i in range(n)]
+    b.reset()
+    for e in envs:
+        e.reset(render=False)
+    rng = np.random.default_rng(2)
+
+    def check(tag):
+        obs, dep = b.obs.cpu().numpy(), b.depth.cpu().numpy()[..., 0]
+        if layout == "CWH":
+            obs = obs.transpose(0, 3, 2, 1)   # [N, 3, W, H] -> [N, H, W, 3]
+        for i, e in enumerate(envs):
+            ref, refd = e.render_obs(depth=True)
+            d = np.abs(obs[i].astype(np.int16) - ref.astype(np.int16))
+            assert d.max() <= 1 and np.abs(dep[i] - refd).max() <= 1e-4, (env_id, tag, i, int(d.max()), int((d > 1).sum()))
+    check("reset")
+    n_done = 0
+    for t in range(12):
+        a = rng.integers(0, 3, n).astype(np.int32)
+        b.step(torch.from_numpy(a))
+        done = b.done.cpu().numpy()
+        for i, e in enumerate(envs):
+            _, _, dn, _ = e.step(int(a[i]))
+            assert dn == bool(done[i])
+            if dn:
+                e.reset(render=False)
+                n_done += 1
+        if t % 4 == 3 or t == 6:
+            check("t=%d" % t)
+    assert n_done >= n
+    b.close()
