@@ -121,9 +121,12 @@ class MiniWorldVecEnv(VecEnv):
                        requires (pytorch-a2c-ppo-acktr/main.py:614-619)
     graph=True      -> after two eager steps the whole step (mwb_step's kernels on both streams, the frame-stack /
                        float pass, the copies into the pinned host mirrors) is captured into one HIP graph and
-                       replayed (steps with a `mask` run eagerly).  Off by default: on ROCm 7.2 / MI355X replay is no
-                       faster than the ~10 eager launches (0.718 vs 0.715 ms per step at 8192 Maze envs) and now and
-                       then a replayed graph runs 15-40 % slower for a whole run (scripts/ab_vecenv_graph.py)
+                       replayed (steps with a `mask` run eagerly).  Off by default: on ROCm 7.2 / MI355X a replayed graph
+                       puts the main chain's bulk render on an auxiliary hardware queue and the side chain on the
+                       capturing stream's, so the side chain loses its priority and head start (~4 % slower than the
+                       ~10 eager launches); and the SECOND graph instantiated in a process lands on a hardware queue
+                       where every kernel runs 2-5x longer (+40 % per step) unless GPU_MAX_HW_QUEUES=2 is exported
+                       (profiles/r03_graph_replay_queues.txt, scripts/ab_graph_replay.py, graph_branch_overlap.py)
     """
 
     def __init__(self, env_id, num_envs, seed=1, device=0, domain_rand=False, transpose=True, to_float=True,
