@@ -2756,8 +2756,9 @@ struct RenderCtx {
         bool have = false, more = true;
         unsigned c_visits = 0, c_tris = 0, c_iters = 0, c_walks = 0;
         for (;;) {
+            const bool tasks_left = mb_count[1] < n_tasks;   // wave-uniform (one LDS word): is there anything to refill idle lanes with
             // (a) lanes without a pair in progress: hand in the finished one, take the next
-            while (node >= n_nodes && (have || more)) {
+            while (leaf_cnt == 0 && node >= n_nodes && (have || more)) {   // (a lane waiting at its mesh's last leaf is not done)
                 if (have) {
                     if (best >= 0) atomicMin(&mb_slots[slot_idx], ((unsigned long long)(uint32_t)__float_as_int(th) << 32) | 0x80000000u | ((uint32_t)bi << 24) | (uint32_t)best);
                     have = false;
@@ -2786,9 +2787,19 @@ struct RenderCtx {
                 node = 0; best = -1; have = true;
                 c_walks++;
             }
-            if (!__any(node < n_nodes)) break;
-            // (b) node steps only, two records per fetch (a descent costs no second round trip)
-            while (leaf_cnt == 0 && node < n_nodes) {
+            if (!__any(node < n_nodes || leaf_cnt)) break;
+            // (b) node steps only, two records per fetch (a descent costs no second round trip).  Most walks end without ever
+            // reaching a leaf (a ray through a ball's gate sphere that misses the ball): the loop is left as soon as a quarter of
+            // the lanes sit idle with pairs still on the list (back to (a)), or enough lanes wait at a leaf to make the leaf phase -
+            // eight triangle tests for the whole wave - worth its ~700 instructions.
+            for (;;) {
+                const bool stepping = leaf_cnt == 0 && node < n_nodes;
+                const unsigned long long ms = __ballot(stepping);
+                if (!ms) break;
+                const int n_leaf = __popcll(__ballot(leaf_cnt != 0));
+                const int n_idle = WAVE - __popcll(ms) - n_leaf;
+                if ((tasks_left && n_idle >= WAVE / 4) || n_leaf >= WAVE / 2) break;
+                if (!stepping) continue;
                 c_iters++;
                 const int nx = node + 1 < n_nodes ? node + 1 : node;
                 const f4n a = nodes[2 * node], bb = nodes[2 * node + 1], a2 = nodes[2 * nx], b2 = nodes[2 * nx + 1];
@@ -2810,8 +2821,11 @@ struct RenderCtx {
                 };
                 if (visit(a, bb)) visit(a2, b2);
             }
-            // (c) leaves: spec arithmetic; triangle q + 1 requested before triangle q is tested
-            if (leaf_cnt) {
+            // (c) leaves: spec arithmetic; triangle q + 1 requested before triangle q is tested.  Postponed while few lanes wait and
+            // others can still move on.
+            const bool can_step = __any(leaf_cnt == 0 && node < n_nodes);
+            const int n_at_leaf = __popcll(__ballot(leaf_cnt != 0));
+            if (leaf_cnt && (n_at_leaf >= WAVE / 2 || !can_step || !tasks_left)) {
                 c_iters++;
                 f4n p0 = tris[3 * leaf_first], p1 = tris[3 * leaf_first + 1], p2 = tris[3 * leaf_first + 2];
                 for (int q = 0; q < leaf_cnt; q++) {
@@ -2827,8 +2841,8 @@ struct RenderCtx {
                         if (t < th || (t == th && (best < 0 || idx < best))) { th = t; best = idx; }
                     }
                 }
+                leaf_cnt = 0;
             }
-            leaf_cnt = 0;
         }
         if ((exp_flags & 4) && dbg_counters) {
             atomicAdd(dbg_counters + 0, (unsigned long long)c_walks); atomicAdd(dbg_counters + 1, (unsigned long long)c_walks);
