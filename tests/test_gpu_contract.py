@@ -174,7 +174,7 @@ def test_intersect_skips_the_querying_entity_and_sees_the_agent(oracle_mod):
                                                ("MiniWorld-SimToRealPush-v0", "SimToRealPush", None)])
 def test_two_box_tasks_render_large_observations(oracle_mod, env_id, task, targs):
     """200x150 needs more than the default 64 KB of dynamic LDS (the frame is assembled in LDS): the two-box render
-    kernels must opt in like the one-box ones (round-1 advisor finding)."""
+    kernels must opt in like the one-box ones (round-1 advisor finding); 640x480 goes through the tiled path."""
     from gym_miniworld_amd.batch import BatchedMiniWorld
     from gym_miniworld_amd.params import sim_to_real_params
     O = oracle_mod
@@ -191,8 +191,15 @@ def test_two_box_tasks_render_large_observations(oracle_mod, env_id, task, targs
         assert d.max() <= 1, (env_id, i, int(d.max()))
         assert np.abs(dep[i] - refd).max() <= 1e-4
     b.close()
-    with pytest.raises(Exception, match="pixel queue|LDS"):
-        BatchedMiniWorld(env_id, num_envs=1, seed=9, obs_width=640, obs_height=480)
+    # 640 x 480 fits neither one workgroup's LDS nor its 16-bit pixel queue: refused until round 3, rendered in tiles since
+    b = BatchedMiniWorld(env_id, num_envs=1, seed=9, obs_width=640, obs_height=480, want_depth=True, domain_rand=True)
+    obs = b.reset().cpu().numpy()
+    dep = b.depth.cpu().numpy()[..., 0]
+    e = O.OracleEnv(task, seed=9, domain_rand=True, task_args=targs, params=prm, obs_width=640, obs_height=480)
+    e.reset(render=False)
+    ref, refd = e.render_obs(depth=True)
+    assert np.abs(obs[0].astype(np.int16) - ref.astype(np.int16)).max() <= 1 and np.abs(dep[0] - refd).max() <= 1e-4
+    b.close()
 
 
 def test_shard_exchange_single_gpu_self_test():
