@@ -265,7 +265,7 @@ def main():
 
     run(0, Wm)
     multi = None
-    if gather is not None:
+    if gather is not None and Wm > 0:
         # self-check, outside the timed region: every rank's shard of the newest round arrived where the method delivers it
         # (per-shard checksums, all-gathered separately), on distinct devices, and what one exchange costs unoverlapped
         gather.latest()
