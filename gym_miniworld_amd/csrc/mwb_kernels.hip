@@ -2935,7 +2935,7 @@ struct RenderCtx {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int n_tasks = min(*mb_count, MB_TASKS);
-            if (n_tasks > 0) walk_pairs(n_tasks, half);
+            if (n_tasks > 0 && !(exp_flags & 16)) walk_pairs(n_tasks, half);   // MWB_EXP bit 4: pairs listed but not walked (timing experiments)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
