@@ -133,6 +133,7 @@ class MiniWorldVecEnv(VecEnv):
                  frame_stack=0, torch_api=True, feature_info=False, first_env_index=0, graph=False, **kwargs):
         import torch
         from .batch import BatchedMiniWorld
+        from . import _lib
         self.torch = torch
         self.batch = BatchedMiniWorld(env_id, num_envs=num_envs, seed=seed, domain_rand=domain_rand, device=device,
                                       layout="CWH" if transpose else "HWC", first_env_index=first_env_index, **kwargs)
@@ -146,8 +147,14 @@ class MiniWorldVecEnv(VecEnv):
             # fused in the library: the render kernels write each new frame (uint8 -> float on the way out of LDS) into a
             # sliding window of planes and zero the history of the envs they regenerate: no stack pass at all (a replayed
             # graph would freeze the host-side window position: the shifting stack there)
-            fuse = not graph and (to_float or (b.W * b.H) % 16 == 0) and not b.ent_task   # (the mesh-entity tasks render in tiles)
-            self.stackedobs = b.stack_enable(self.nstack, "float32" if to_float else "uint8", sliding=not graph, fused=fuse)
+            fuse = not graph and (to_float or (b.W * b.H) % 16 == 0)
+            try:
+                self.stackedobs = b.stack_enable(self.nstack, "float32" if to_float else "uint8", sliding=not graph, fused=fuse)
+            except _lib.MwbError:
+                if not fuse:
+                    raise
+                # observations rendered in tiles (frames too large for one workgroup's LDS, MWB_TILE): the sliding window, one pass
+                self.stackedobs = b.stack_enable(self.nstack, "float32" if to_float else "uint8", sliding=not graph, fused=False)
         VecEnv.__init__(self, num_envs, Box(0, 255, shape, np.float32 if to_float else np.uint8), Discrete(b.n_actions))
         self.device = b.device
         self.feature_info = feature_info

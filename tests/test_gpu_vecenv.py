@@ -38,13 +38,16 @@ def test_vecenv_matches_per_env_oracle_with_autoreset(oracle_mod):
     v.close()
 
 
-def test_frame_stack_semantics():
-    """VecPyTorchFrameStack (envs.py:135-165) restated in numpy on the same observation stream."""
+@pytest.mark.parametrize("env_id", ["MiniWorld-OneRoomS6-v0", "MiniWorld-CollectHealth-v0", "MiniWorld-PickupObjs-v0"])
+def test_frame_stack_semantics(env_id):
+    """VecPyTorchFrameStack (envs.py:135-165) restated in numpy on the same observation stream (the fused window: also the entity
+    tasks' render kernel writes it)."""
     import torch
     from gym_miniworld_amd.vec_env import MiniWorldVecEnv
     n = 5
-    v = MiniWorldVecEnv("MiniWorld-OneRoomS6-v0", n, seed=3, frame_stack=4)
-    plain = MiniWorldVecEnv("MiniWorld-OneRoomS6-v0", n, seed=3, frame_stack=0)
+    kw = {"max_episode_steps": 40} if "PickupObjs" in env_id else {}
+    v = MiniWorldVecEnv(env_id, n, seed=3, frame_stack=4, **kw)
+    plain = MiniWorldVecEnv(env_id, n, seed=3, frame_stack=0, **kw)
     assert v.observation_space.shape == (12, 80, 60)
     st = v.reset().cpu().numpy()
     ob = plain.reset().cpu().numpy()
