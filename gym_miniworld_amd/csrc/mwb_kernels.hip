@@ -2875,6 +2875,7 @@ struct RenderCtx {
 #pragma unroll
         for (int bi = 0; bi < NBOX; bi++) any_boxes |= __ballot((my_boxes >> bi) & 1u) ? 1u << bi : 0u;
         mb_pix[lane] = (uint32_t)px | ((uint32_t)py << 16);
+        const int task_cap = (exp_flags & 32) ? 8 : MB_TASKS;   // MWB_EXP bit 5: a list of 8 pairs, so that tests reach the overflow path
         uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0, meta = 0, key_s0 = 0;
         float t_s0 = INFINITY;
         float acc[3] = {0, 0, 0};
@@ -2920,7 +2921,7 @@ struct RenderCtx {
                         const float b = dv[0] * blk[FC_CULL_OC] + dv[1] * blk[FC_CULL_OC + 1] + dv[2] * blk[FC_CULL_OC + 2];
                         if (!(cc <= 0.0f || (b > 0.0f && b * b >= dd * cc))) continue;
                         const int slot = atomicAdd(mb_count, 1);
-                        if (slot < MB_TASKS) mb_tasks[slot] = (uint16_t)(lane | (kk << 6) | (bi << 8));
+                        if (slot < task_cap) mb_tasks[slot] = (uint16_t)(lane | (kk << 6) | (bi << 8));
                         else {   // list full (dozens of meshes behind one pixel): walked on the spot, by this lane
                             float t; int tri;
                             // (every lane must take part in walk_pair's wave-wide loop: not here - a plain per-lane walk)
@@ -2934,7 +2935,7 @@ struct RenderCtx {
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int n_tasks = min(*mb_count, MB_TASKS);
+            const int n_tasks = min(*mb_count, task_cap);
             if (n_tasks > 0 && !(exp_flags & 16)) walk_pairs(n_tasks, half);   // MWB_EXP bit 4: pairs listed but not walked (timing experiments)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
